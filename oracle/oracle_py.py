@@ -1,0 +1,220 @@
+"""ctypes binding of the CPU oracle (oracle/poa_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under smoothxg_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpoa_oracle.so")
+
+
+class Params(C.Structure):
+    _fields_ = [("m", C.c_int8), ("n", C.c_int8), ("g", C.c_int8), ("e", C.c_int8),
+                ("q", C.c_int8), ("c", C.c_int8), ("mode", C.c_uint8)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "poa_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        vp, i32p, u8p, u32p, u64p, i64p = (C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_int64))
+        L.poa_graph_new.restype = vp
+        L.poa_graph_free.argtypes = [vp]
+        for f in ("poa_graph_num_nodes", "poa_graph_num_edges", "poa_graph_num_seqs"):
+            getattr(L, f).argtypes = [vp]
+        L.poa_align.argtypes = [vp, u8p, C.c_int, C.POINTER(Params), i32p, i32p, i32p, u64p]
+        L.poa_align_csr.argtypes = [C.c_int, u8p, i32p, i32p, u8p, u8p, C.c_int, C.POINTER(Params),
+                                    i32p, i32p, i32p]
+        L.poa_add_alignment.argtypes = [vp, i32p, i32p, C.c_int, u8p, C.c_int, C.c_uint32]
+        L.poa_graph_nodes.argtypes = [vp, u8p, i32p, i32p]
+        L.poa_graph_edges.argtypes = [vp, i32p, i32p, u32p]
+        L.poa_graph_rows.argtypes = [vp, u8p, i32p, i32p, u8p, i32p]
+        L.poa_graph_seq_len.argtypes = [vp, C.c_int]
+        L.poa_graph_seq_path.argtypes = [vp, C.c_int, i32p]
+        L.poa_consensus.argtypes = [vp, i32p]
+        L.poa_msa.argtypes = [vp, C.c_int, C.c_char_p]
+        L.poa_block_run.restype = vp
+        L.poa_block_run.argtypes = [u8p, i32p, C.c_int, u32p, C.POINTER(Params), i32p, u64p]
+        L.poa_blocks_run_omp.argtypes = [u8p, i64p, i32p, C.c_int, u32p, C.POINTER(Params), C.c_int,
+                                         i32p, u64p, i32p, i32p]
+        L.poa_xxh64.restype = C.c_uint64
+        L.poa_xxh64.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
+        L.poa_rescore.restype = C.c_int32
+        L.poa_rescore.argtypes = [vp, u8p, C.c_int, C.POINTER(Params), i32p, i32p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def mkparams(m=1, n=-4, g=-6, e=-2, q=-26, c=-1, mode=0):
+    return Params(m, n, g, e, q, c, mode)
+
+
+class Graph:
+    """Owning handle on an oracle POA graph."""
+
+    def __init__(self, handle=None):
+        self.h = handle if handle is not None else lib().poa_graph_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().poa_graph_free(self.h)
+            self.h = None
+
+    @property
+    def n_nodes(self):
+        return lib().poa_graph_num_nodes(self.h)
+
+    @property
+    def n_edges(self):
+        return lib().poa_graph_num_edges(self.h)
+
+    @property
+    def n_seqs(self):
+        return lib().poa_graph_num_seqs(self.h)
+
+    def align(self, seq, params):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        cap = self.n_nodes + len(seq) + 1
+        an = np.empty(cap, np.int32)
+        ap = np.empty(cap, np.int32)
+        sc = C.c_int32(0)
+        cells = C.c_uint64(0)
+        n = lib().poa_align(self.h, _p(seq, C.c_uint8), len(seq), C.byref(params), _p(an, C.c_int32),
+                            _p(ap, C.c_int32), C.byref(sc), C.byref(cells))
+        return an[:n].copy(), ap[:n].copy(), sc.value, cells.value
+
+    def add_alignment(self, an, ap, seq, weight=1):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        an = np.ascontiguousarray(an, np.int32)
+        ap = np.ascontiguousarray(ap, np.int32)
+        lib().poa_add_alignment(self.h, _p(an, C.c_int32), _p(ap, C.c_int32), len(an),
+                                _p(seq, C.c_uint8), len(seq), weight)
+
+    def rescore(self, seq, params, an, ap):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        an = np.ascontiguousarray(an, np.int32)
+        ap = np.ascontiguousarray(ap, np.int32)
+        return lib().poa_rescore(self.h, _p(seq, C.c_uint8), len(seq), C.byref(params),
+                                 _p(an, C.c_int32), _p(ap, C.c_int32), len(an))
+
+    def nodes(self):
+        n = self.n_nodes
+        code = np.empty(n, np.uint8)
+        rank = np.empty(n, np.int32)
+        grp = np.empty(n, np.int32)
+        lib().poa_graph_nodes(self.h, _p(code, C.c_uint8), _p(rank, C.c_int32), _p(grp, C.c_int32))
+        return code, rank, grp
+
+    def edges(self):
+        n = self.n_edges
+        t = np.empty(n, np.int32)
+        h = np.empty(n, np.int32)
+        w = np.empty(n, np.uint32)
+        lib().poa_graph_edges(self.h, _p(t, C.c_int32), _p(h, C.c_int32), _p(w, C.c_uint32))
+        return t, h, w
+
+    def rows(self):
+        """CSR in rank space: codes, off, pred(row idx), sink, row_node."""
+        n = self.n_nodes
+        codes = np.empty(n, np.uint8)
+        off = np.empty(n + 1, np.int32)
+        pred = np.empty(self.n_edges + 1, np.int32)
+        sink = np.empty(n, np.uint8)
+        row_node = np.empty(n, np.int32)
+        lib().poa_graph_rows(self.h, _p(codes, C.c_uint8), _p(off, C.c_int32), _p(pred, C.c_int32),
+                             _p(sink, C.c_uint8), _p(row_node, C.c_int32))
+        return codes, off, pred[:off[n]].copy(), sink, row_node
+
+    def seq_path(self, s):
+        n = lib().poa_graph_seq_len(self.h, s)
+        out = np.empty(n, np.int32)
+        lib().poa_graph_seq_path(self.h, s, _p(out, C.c_int32))
+        return out
+
+    def consensus(self):
+        out = np.empty(max(self.n_nodes, 1), np.int32)
+        n = lib().poa_consensus(self.h, _p(out, C.c_int32))
+        return out[:n].copy()
+
+    def msa(self, with_consensus=False):
+        ncol = lib().poa_msa(self.h, int(with_consensus), None)
+        rows = self.n_seqs + (1 if with_consensus else 0)
+        buf = C.create_string_buffer(max(rows * ncol, 1))
+        lib().poa_msa(self.h, int(with_consensus), buf)
+        raw = buf.raw[:rows * ncol]
+        return [raw[i * ncol:(i + 1) * ncol].decode() for i in range(rows)]
+
+
+def align_csr(codes, off, pred, sink, seq, params):
+    codes = np.ascontiguousarray(codes, np.uint8)
+    off = np.ascontiguousarray(off, np.int32)
+    pred = np.ascontiguousarray(pred if len(pred) else np.zeros(1), np.int32)
+    sink = np.ascontiguousarray(sink, np.uint8)
+    seq = np.ascontiguousarray(seq, np.uint8)
+    n = len(codes)
+    cap = n + len(seq) + 1
+    an = np.empty(cap, np.int32)
+    ap = np.empty(cap, np.int32)
+    sc = C.c_int32(0)
+    k = lib().poa_align_csr(n, _p(codes, C.c_uint8), _p(off, C.c_int32), _p(pred, C.c_int32),
+                            _p(sink, C.c_uint8), _p(seq, C.c_uint8), len(seq), C.byref(params),
+                            _p(an, C.c_int32), _p(ap, C.c_int32), C.byref(sc))
+    return an[:k].copy(), ap[:k].copy(), sc.value
+
+
+def block_run(seqs, weights, params):
+    """seqs: list of uint8 arrays.  Returns (Graph, scores, cells)."""
+    bases = np.concatenate([np.asarray(s, np.uint8) for s in seqs]) if seqs else np.zeros(0, np.uint8)
+    bases = np.ascontiguousarray(bases if len(bases) else np.zeros(1, np.uint8))
+    off = np.zeros(len(seqs) + 1, np.int32)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    w = np.ascontiguousarray(weights if weights is not None else np.ones(len(seqs)), np.uint32)
+    scores = np.zeros(max(len(seqs), 1), np.int32)
+    cells = np.zeros(max(len(seqs), 1), np.uint64)
+    h = lib().poa_block_run(_p(bases, C.c_uint8), _p(off, C.c_int32), len(seqs), _p(w, C.c_uint32),
+                            C.byref(params), _p(scores, C.c_int32), _p(cells, C.c_uint64))
+    return Graph(h), scores[:len(seqs)], cells[:len(seqs)]
+
+
+def blocks_run_omp(bases, seq_off, blk_off, weights, params, n_threads):
+    """Flat batch (same layout as include/sxg_poa.h).  Returns (scores, cells_total, n_nodes, n_edges)."""
+    bases = np.ascontiguousarray(bases, np.uint8)
+    seq_off = np.ascontiguousarray(seq_off, np.int64)
+    blk_off = np.ascontiguousarray(blk_off, np.int32)
+    nb = len(blk_off) - 1
+    ns = int(blk_off[-1])
+    w = np.ascontiguousarray(weights if weights is not None else np.ones(ns), np.uint32)
+    scores = np.zeros(max(ns, 1), np.int32)
+    nn = np.zeros(max(nb, 1), np.int32)
+    ne = np.zeros(max(nb, 1), np.int32)
+    total = C.c_uint64(0)
+    lib().poa_blocks_run_omp(_p(bases, C.c_uint8), _p(seq_off, C.c_int64), _p(blk_off, C.c_int32), nb,
+                             _p(w, C.c_uint32), C.byref(params), n_threads, _p(scores, C.c_int32),
+                             C.byref(total), _p(nn, C.c_int32), _p(ne, C.c_int32))
+    return scores[:ns], total.value, nn[:nb], ne[:nb]
+
+
+def xxh64(data: bytes, seed=0):
+    return lib().poa_xxh64(data, len(data), seed)

@@ -1,0 +1,665 @@
+/*
+ * poa_oracle.c -- CPU ORACLE (test infrastructure, PARITY UNPINNED; see poa_oracle.h).
+ *
+ * Restates, in scalar C, what the reference asks of spoa at
+ *   src/smooth.cpp:752-755  AlignmentEngine::Create(type, m,n,g,e,q,c)
+ *   src/smooth.cpp:761      Align(seq, graph)          -> poa_align()
+ *   src/smooth.cpp:764      AddAlignment(aln,seq,w)    -> poa_add_alignment()
+ *   src/smooth.cpp:773      GenerateConsensus()        -> poa_consensus()
+ *   src/smooth.cpp:785-786  GenerateMultipleSequenceAlignment() -> poa_msa()
+ *   src/smooth.cpp:716      XXH64(seq,len,0)           -> poa_xxh64()
+ * spoa itself is absent (deps/spoa is an empty submodule), so the recurrences follow the
+ * published algorithms and every tie-break is a decree of THIS file:
+ *
+ * SEMANTICS (the spec the HIP path must reproduce bit-for-bit)
+ *  S1 gap model (as spoa's Create is documented to choose): g>=e -> linear (e=q=c=g);
+ *     else g<=q || e>=c -> affine (q=g, c=e); else convex (two-piece).  One general
+ *     two-piece recurrence is evaluated; linear/affine are its degenerate cases.
+ *  S2 matrix: row 0 = virtual source, row r+1 = node of topological rank r, columns 0..L.
+ *     pred rows of a node = rank+1 of its in-edge tails in EDGE INSERTION ORDER; a node
+ *     without in-edges has the single pred row 0.
+ *     F[i][j] = max_p max(H[p][j]+g, F[p][j]+e)      (gap in the sequence, piece 1)
+ *     O[i][j] = max_p max(H[p][j]+q, O[p][j]+c)      (piece 2)
+ *     D[i][j] = max_p H[p][j-1] + (code_i==seq[j-1] ? m : n)         (j>=1)
+ *     E[i][j] = max(H[i][j-1]+g, E[i][j-1]+e), Q likewise with q,c   (j>=1)
+ *     H[i][j] = max(D,F,O,E,Q); SW additionally clamps at 0.
+ *     Row 0: SW H=0; NW H[0][0]=0, H[0][j]=max(g+(j-1)e, q+(j-1)c); F=O=-inf.
+ *  S3 ties: the FIRST candidate in this order wins: H: STOP(SW,H==0) > D > F > O > E > Q;
+ *     D: preds in list order; F/O: preds in list order, within a pred OPEN before EXTEND;
+ *     E/Q: OPEN before EXTEND.  ("later candidate replaces only if strictly greater".)
+ *  S4 end cell: SW = first cell in (row,col) order with the strictly greatest H>0 (none ->
+ *     empty alignment); NW = first sink row (no out-edge) in rank order with the strictly
+ *     greatest H[.][L].
+ *  S5 traceback = replay of the recorded choices; emits (node,pos) pairs: D -> (node,j-1),
+ *     F/O step -> (node,-1), E/Q step -> (-1,j-1); SW stops at STOP, NW at (0,0).
+ *  S6 AddAlignment: positions without an aligned node become new nodes; an aligned
+ *     position reuses the node (same letter) or its aligned sibling with that letter, else
+ *     a new sibling joins the aligned group.  New node ids are handed out in SEQUENCE
+ *     ORDER.  Each consecutive pair of path nodes gets edge weight += 2*weight (both end
+ *     bases contribute, as spoa documents); new edges are appended to the tail's out-list
+ *     and the head's in-list.
+ *  S7 topological order is maintained INCREMENTALLY (any valid order with contiguous
+ *     aligned groups is a legal POA order; this one is data-parallel): a new sibling is
+ *     placed right after the last old member of its group; a run of new unaligned nodes is
+ *     placed right before the group of the next aligned path node (or right after the
+ *     group of the previous one if there is none, or at the end).  Same slot -> sequence
+ *     order.  new_rank(k-th new node) = slot_k + k.
+ *  S8 consensus = heaviest bundle with branch completion; MSA column = aligned group in
+ *     rank order.
+ */
+#include "poa_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NEG (-(1 << 29))
+enum { SRC_STOP = 0, SRC_D = 1, SRC_F = 2, SRC_O = 3, SRC_E = 4, SRC_Q = 5 };
+#define TB_FEXT 0x08
+#define TB_OEXT 0x10
+#define TB_EEXT 0x20
+#define TB_QEXT 0x40
+
+struct poa_graph {
+    int n_nodes, cap_nodes;
+    uint8_t *code;
+    int32_t *rank;   /* node -> rank */
+    int32_t *order;  /* rank -> node */
+    int32_t *leader; /* node -> first node of its aligned group */
+    int32_t *gmem;   /* [leader*5 + code] -> node | -1 (valid at leader rows) */
+    int32_t *in_head, *in_tail, *out_head, *out_tail, *in_deg, *out_deg;
+    int n_edges, cap_edges;
+    int32_t *e_tail, *e_head, *e_next_in, *e_next_out;
+    uint32_t *e_w;
+    int n_seqs, cap_seqs;
+    int64_t *seq_off; /* n_seqs+1 */
+    int32_t *path;
+    int64_t cap_path;
+};
+
+static void *xrealloc(void *p, size_t n) {
+    void *r = realloc(p, n ? n : 1);
+    if (!r) { fprintf(stderr, "poa_oracle: out of memory\n"); abort(); }
+    return r;
+}
+
+poa_graph_t *poa_graph_new(void) {
+    poa_graph_t *g = (poa_graph_t *)calloc(1, sizeof(*g));
+    g->seq_off = (int64_t *)calloc(1, sizeof(int64_t));
+    return g;
+}
+void poa_graph_free(poa_graph_t *g) {
+    if (!g) return;
+    free(g->code); free(g->rank); free(g->order); free(g->leader); free(g->gmem);
+    free(g->in_head); free(g->in_tail); free(g->out_head); free(g->out_tail);
+    free(g->in_deg); free(g->out_deg);
+    free(g->e_tail); free(g->e_head); free(g->e_next_in); free(g->e_next_out); free(g->e_w);
+    free(g->seq_off); free(g->path);
+    free(g);
+}
+int poa_graph_num_nodes(const poa_graph_t *g) { return g->n_nodes; }
+int poa_graph_num_edges(const poa_graph_t *g) { return g->n_edges; }
+int poa_graph_num_seqs(const poa_graph_t *g) { return g->n_seqs; }
+
+static void reserve_nodes(poa_graph_t *g, int n) {
+    if (n <= g->cap_nodes) return;
+    int c = g->cap_nodes ? g->cap_nodes : 1024;
+    while (c < n) c *= 2;
+    g->code = (uint8_t *)xrealloc(g->code, c);
+#define RS(f) g->f = (int32_t *)xrealloc(g->f, sizeof(int32_t) * (size_t)c)
+    RS(rank); RS(order); RS(leader); RS(in_head); RS(in_tail); RS(out_head); RS(out_tail);
+    RS(in_deg); RS(out_deg);
+#undef RS
+    g->gmem = (int32_t *)xrealloc(g->gmem, sizeof(int32_t) * 5 * (size_t)c);
+    g->cap_nodes = c;
+}
+static void reserve_edges(poa_graph_t *g, int n) {
+    if (n <= g->cap_edges) return;
+    int c = g->cap_edges ? g->cap_edges : 1024;
+    while (c < n) c *= 2;
+#define RS(f) g->f = (int32_t *)xrealloc(g->f, sizeof(int32_t) * (size_t)c)
+    RS(e_tail); RS(e_head); RS(e_next_in); RS(e_next_out);
+#undef RS
+    g->e_w = (uint32_t *)xrealloc(g->e_w, sizeof(uint32_t) * (size_t)c);
+    g->cap_edges = c;
+}
+
+static int new_node(poa_graph_t *g, uint8_t code) {
+    reserve_nodes(g, g->n_nodes + 1);
+    int v = g->n_nodes++;
+    g->code[v] = code;
+    g->rank[v] = -1;
+    g->leader[v] = v;
+    for (int c = 0; c < 5; ++c) g->gmem[5 * v + c] = -1;
+    g->gmem[5 * v + code] = v;
+    g->in_head[v] = g->in_tail[v] = g->out_head[v] = g->out_tail[v] = -1;
+    g->in_deg[v] = g->out_deg[v] = 0;
+    return v;
+}
+
+/* S6: edge (u,v) += w; appended to u's out-list / v's in-list when new. */
+static void add_edge(poa_graph_t *g, int u, int v, uint32_t w) {
+    for (int e = g->out_head[u]; e >= 0; e = g->e_next_out[e])
+        if (g->e_head[e] == v) { g->e_w[e] += w; return; }
+    reserve_edges(g, g->n_edges + 1);
+    int e = g->n_edges++;
+    g->e_tail[e] = u; g->e_head[e] = v; g->e_w[e] = w;
+    g->e_next_in[e] = g->e_next_out[e] = -1;
+    if (g->out_tail[u] >= 0) g->e_next_out[g->out_tail[u]] = e; else g->out_head[u] = e;
+    g->out_tail[u] = e; g->out_deg[u]++;
+    if (g->in_tail[v] >= 0) g->e_next_in[g->in_tail[v]] = e; else g->in_head[v] = e;
+    g->in_tail[v] = e; g->in_deg[v]++;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* The DP over a CSR-in-rank-space graph (S1-S5).                                        */
+
+typedef struct {
+    int m, n, g, e, q, c, sw;
+} norm_params_t;
+
+static norm_params_t normalise(const poa_params_t *p) {
+    norm_params_t r;
+    r.m = p->m; r.n = p->n; r.g = p->g; r.e = p->e; r.q = p->q; r.c = p->c;
+    r.sw = (p->mode == POA_MODE_SW);
+    if (r.g >= r.e) { r.e = r.g; r.q = r.g; r.c = r.g; }            /* linear  */
+    else if (r.g <= r.q || r.e >= r.c) { r.q = r.g; r.c = r.e; }    /* affine  */
+    return r;                                                        /* convex  */
+}
+
+static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int32_t *pred,
+                      const uint8_t *sink, const int32_t *row_node, const uint8_t *seq, int L,
+                      const poa_params_t *pp, int32_t *out_node, int32_t *out_pos,
+                      int32_t *score) {
+    norm_params_t P = normalise(pp);
+    if (score) *score = 0;
+    if (N == 0 || L == 0) return 0;
+    const size_t W = (size_t)L + 1;
+    /* rows of H,F,O kept until their last reader is done */
+    int32_t **Hm = (int32_t **)calloc((size_t)N + 1, sizeof(int32_t *));
+    int32_t *last_use = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    for (int i = 0; i <= N; ++i) last_use[i] = i;
+    for (int i = 1; i <= N; ++i)
+        for (int k = off[i - 1]; k < off[i]; ++k)
+            if (last_use[pred[k]] < i) last_use[pred[k]] = i;
+    /* free lists keyed by last_use */
+    int32_t *free_head = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 2));
+    int32_t *free_next = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    for (int i = 0; i <= N + 1; ++i) free_head[i] = -1;
+    for (int i = 0; i <= N; ++i) { free_next[i] = free_head[last_use[i]]; free_head[last_use[i]] = i; }
+
+    uint8_t *tb = (uint8_t *)malloc(((size_t)N + 1) * W);
+    /* ordinals of the winning pred for D,F,O on multi-pred rows */
+    int32_t *mp_index = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    size_t n_mp = 0;
+    for (int i = 1; i <= N; ++i) mp_index[i] = (off[i] - off[i - 1] > 1) ? (int32_t)n_mp++ : -1;
+    int32_t *tbx = (int32_t *)malloc(sizeof(int32_t) * 3 * (n_mp ? n_mp : 1) * W);
+
+    /* row 0 */
+    Hm[0] = (int32_t *)malloc(sizeof(int32_t) * 3 * W);
+    {
+        int32_t *H = Hm[0], *F = H + W, *O = F + W;
+        for (int j = 0; j <= L; ++j) {
+            F[j] = O[j] = NEG;
+            if (P.sw || j == 0) H[j] = 0;
+            else {
+                int a = P.g + (j - 1) * P.e, b = P.q + (j - 1) * P.c;
+                H[j] = a > b ? a : b;
+            }
+        }
+    }
+    int best_i = -1, best_j = -1, best = 0;
+    static const int32_t zero_pred = 0;
+    for (int i = 1; i <= N; ++i) {
+        int np = off[i] - off[i - 1];
+        const int32_t *pl = pred + off[i - 1];
+        if (np == 0) { np = 1; pl = &zero_pred; }
+        int32_t *H = (int32_t *)malloc(sizeof(int32_t) * 3 * W), *F = H + W, *O = F + W;
+        Hm[i] = H;
+        uint8_t *t = tb + (size_t)i * W;
+        int32_t *tx = mp_index[i] >= 0 ? tbx + 3 * (size_t)mp_index[i] * W : NULL;
+        const int code = codes[i - 1];
+        int E = NEG, Q = NEG;
+        for (int j = 0; j <= L; ++j) {
+            int f = 0, o = 0, d = NEG, fo = 0, oo = 0, dd = 0, fx = 0, ox = 0;
+            for (int k = 0; k < np; ++k) {
+                const int32_t *Hp = Hm[pl[k]], *Fp = Hp + W, *Op = Fp + W;
+                int c1 = Hp[j] + P.g, c2 = Fp[j] + P.e;
+                if (k == 0 || c1 > f) { f = c1; fo = k; fx = 0; }
+                if (c2 > f) { f = c2; fo = k; fx = 1; }
+                c1 = Hp[j] + P.q; c2 = Op[j] + P.c;
+                if (k == 0 || c1 > o) { o = c1; oo = k; ox = 0; }
+                if (c2 > o) { o = c2; oo = k; ox = 1; }
+                if (j > 0) { int c3 = Hp[j - 1]; if (k == 0 || c3 > d) { d = c3; dd = k; } }
+            }
+            int ex = 0, qx = 0;
+            if (j > 0) {
+                d += (code == seq[j - 1]) ? P.m : P.n;
+                int c1 = H[j - 1] + P.g, c2 = E + P.e;
+                E = c1; if (c2 > c1) { E = c2; ex = 1; }
+                c1 = H[j - 1] + P.q; c2 = Q + P.c;
+                Q = c1; if (c2 > c1) { Q = c2; qx = 1; }
+            } else { d = NEG; E = NEG; Q = NEG; }
+            int h = d, src = SRC_D;
+            if (f > h) { h = f; src = SRC_F; }
+            if (o > h) { h = o; src = SRC_O; }
+            if (E > h) { h = E; src = SRC_E; }
+            if (Q > h) { h = Q; src = SRC_Q; }
+            if (P.sw && h <= 0) { h = 0; src = SRC_STOP; }
+            H[j] = h; F[j] = f; O[j] = o;
+            t[j] = (uint8_t)(src | (fx ? TB_FEXT : 0) | (ox ? TB_OEXT : 0) | (ex ? TB_EEXT : 0) |
+                             (qx ? TB_QEXT : 0));
+            if (tx) { tx[3 * (size_t)j] = dd; tx[3 * (size_t)j + 1] = fo; tx[3 * (size_t)j + 2] = oo; }
+            if (P.sw && h > best) { best = h; best_i = i; best_j = j; }
+        }
+        if (!P.sw && sink[i - 1] && (best_i < 0 || H[L] > best)) { best = H[L]; best_i = i; best_j = L; }
+        /* release rows nobody will read again */
+        for (int r = free_head[i]; r >= 0; r = free_next[r]) { free(Hm[r]); Hm[r] = NULL; }
+    }
+    for (int i = 0; i <= N; ++i) free(Hm[i]);
+    free(Hm); free(last_use); free(free_head); free(free_next);
+
+    int n = 0;
+    if (best_i >= 0) {
+        if (score) *score = best;
+        int i = best_i, j = best_j, st = SRC_STOP; /* st: STOP == "in H" */
+        for (;;) {
+            if (i == 0) { /* virtual row: only NW gets here */
+                if (j == 0) break;
+                out_node[n] = -1; out_pos[n] = j - 1; ++n; --j;
+                continue;
+            }
+            const uint8_t t = tb[(size_t)i * W + j];
+            const int32_t *tx = mp_index[i] >= 0 ? tbx + 3 * ((size_t)mp_index[i] * W + j) : NULL;
+            const int32_t *pl = pred + off[i - 1];
+            const int has = off[i] - off[i - 1];
+            if (st == SRC_STOP) {
+                int src = t & 7;
+                if (src == SRC_STOP) break;
+                if (src == SRC_D) {
+                    out_node[n] = row_node[i - 1]; out_pos[n] = j - 1; ++n;
+                    i = has ? pl[tx ? tx[0] : 0] : 0; --j;
+                } else st = src;
+            } else if (st == SRC_F || st == SRC_O) {
+                int ext = st == SRC_F ? (t & TB_FEXT) : (t & TB_OEXT);
+                int ord = tx ? tx[st == SRC_F ? 1 : 2] : 0;
+                out_node[n] = row_node[i - 1]; out_pos[n] = -1; ++n;
+                i = has ? pl[ord] : 0;
+                if (!ext) st = SRC_STOP;
+            } else { /* E or Q */
+                int ext = st == SRC_E ? (t & TB_EEXT) : (t & TB_QEXT);
+                out_node[n] = -1; out_pos[n] = j - 1; ++n; --j;
+                if (!ext) st = SRC_STOP;
+            }
+        }
+        for (int a = 0, b = n - 1; a < b; ++a, --b) {
+            int32_t x = out_node[a]; out_node[a] = out_node[b]; out_node[b] = x;
+            x = out_pos[a]; out_pos[a] = out_pos[b]; out_pos[b] = x;
+        }
+    }
+    free(tb); free(tbx); free(mp_index);
+    return n;
+}
+
+/* Stand-alone entry over a caller-supplied CSR (used to check the HIP align-only path). */
+int poa_align_csr(int N, const uint8_t *codes, const int32_t *off, const int32_t *pred,
+                  const uint8_t *sink, const uint8_t *seq, int L, const poa_params_t *p,
+                  int32_t *out_node, int32_t *out_pos, int32_t *score) {
+    int32_t *row_node = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N ? N : 1));
+    for (int i = 0; i < N; ++i) row_node[i] = i; /* report ranks */
+    int n = align_rows(N, codes, off, pred, sink, row_node, seq, L, p, out_node, out_pos, score);
+    free(row_node);
+    return n;
+}
+
+void poa_graph_rows(const poa_graph_t *g, uint8_t *codes, int32_t *off, int32_t *pred,
+                    uint8_t *sink, int32_t *row_node) {
+    int k = 0;
+    off[0] = 0;
+    for (int r = 0; r < g->n_nodes; ++r) {
+        int v = g->order[r];
+        codes[r] = g->code[v];
+        sink[r] = g->out_deg[v] == 0;
+        if (row_node) row_node[r] = v;
+        for (int e = g->in_head[v]; e >= 0; e = g->e_next_in[e]) pred[k++] = g->rank[g->e_tail[e]] + 1;
+        off[r + 1] = k;
+    }
+}
+
+int poa_align(const poa_graph_t *g, const uint8_t *seq, int len, const poa_params_t *p,
+              int32_t *out_node, int32_t *out_pos, int32_t *score, uint64_t *cells) {
+    int N = g->n_nodes;
+    if (cells) *cells = (uint64_t)N * (uint64_t)len;
+    if (score) *score = 0;
+    if (N == 0 || len == 0) return 0;
+    uint8_t *codes = (uint8_t *)malloc((size_t)N), *sink = (uint8_t *)malloc((size_t)N);
+    int32_t *off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    int32_t *pred = (int32_t *)malloc(sizeof(int32_t) * ((size_t)g->n_edges + 1));
+    int32_t *row_node = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+    poa_graph_rows(g, codes, off, pred, sink, row_node);
+    int n = align_rows(N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score);
+    free(codes); free(sink); free(off); free(pred); free(row_node);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* S6 + S7                                                                               */
+
+static int group_start(const poa_graph_t *g, int leader, int n_old) {
+    int r = 0x7fffffff;
+    for (int c = 0; c < 5; ++c) {
+        int v = g->gmem[5 * leader + c];
+        if (v >= 0 && v < n_old && g->rank[v] < r) r = g->rank[v];
+    }
+    return r;
+}
+static int group_end(const poa_graph_t *g, int leader, int n_old) {
+    int r = -1;
+    for (int c = 0; c < 5; ++c) {
+        int v = g->gmem[5 * leader + c];
+        if (v >= 0 && v < n_old && g->rank[v] > r) r = g->rank[v];
+    }
+    return r;
+}
+
+void poa_add_alignment(poa_graph_t *g, const int32_t *aln_node, const int32_t *aln_pos,
+                       int n_pairs, const uint8_t *seq, int len, uint32_t weight) {
+    if (len <= 0) return;
+    const int n_old = g->n_nodes;
+    int32_t *posnode = (int32_t *)malloc(sizeof(int32_t) * (size_t)len);
+    int32_t *target = (int32_t *)malloc(sizeof(int32_t) * (size_t)len);
+    int8_t *kind = (int8_t *)malloc((size_t)len); /* 0 old, 1 new sibling, 2 new unaligned */
+    for (int i = 0; i < len; ++i) posnode[i] = -1;
+    for (int k = 0; k < n_pairs; ++k)
+        if (aln_pos[k] >= 0 && aln_node[k] >= 0) posnode[aln_pos[k]] = aln_node[k];
+
+    for (int i = 0; i < len; ++i) {
+        const uint8_t c = seq[i] > 4 ? 4 : seq[i];
+        const int a = posnode[i];
+        if (a >= 0) {
+            const int ld = g->leader[a];
+            int v = g->gmem[5 * ld + c];
+            if (v >= 0) { target[i] = v; kind[i] = 0; }
+            else {
+                v = new_node(g, c);
+                g->leader[v] = ld;
+                g->gmem[5 * ld + c] = v;
+                target[i] = v; kind[i] = 1;
+            }
+        } else { target[i] = new_node(g, c); kind[i] = 2; }
+    }
+    /* S7 slots, in sequence order */
+    {
+        const int n_new = g->n_nodes - n_old;
+        int32_t *slot = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_new ? n_new : 1));
+        int k = 0;
+        for (int i = 0; i < len; ++i) {
+            if (kind[i] == 0) continue;
+            if (kind[i] == 1) slot[k++] = group_end(g, g->leader[target[i]], n_old) + 1;
+            else {
+                int s = i + 1;
+                while (s < len && kind[s] == 2) ++s;
+                int p = i - 1;
+                while (p >= 0 && kind[p] == 2) --p;
+                if (s < len) slot[k++] = group_start(g, g->leader[target[s]], n_old);
+                else if (p >= 0) slot[k++] = group_end(g, g->leader[target[p]], n_old) + 1;
+                else slot[k++] = n_old;
+            }
+        }
+        /* merge */
+        int32_t *new_order = (int32_t *)malloc(sizeof(int32_t) * (size_t)g->n_nodes);
+        int r_old = 0, w = 0;
+        for (k = 0; k < n_new; ++k) {
+            while (r_old < slot[k]) new_order[w++] = g->order[r_old++];
+            new_order[w++] = n_old + k;
+        }
+        while (r_old < n_old) new_order[w++] = g->order[r_old++];
+        for (int r = 0; r < g->n_nodes; ++r) { g->order[r] = new_order[r]; g->rank[new_order[r]] = r; }
+        free(new_order); free(slot);
+    }
+    for (int i = 1; i < len; ++i) add_edge(g, target[i - 1], target[i], 2 * weight);
+    /* record the path */
+    if (g->n_seqs + 2 > g->cap_seqs) {
+        g->cap_seqs = g->cap_seqs ? 2 * g->cap_seqs : 64;
+        g->seq_off = (int64_t *)xrealloc(g->seq_off, sizeof(int64_t) * ((size_t)g->cap_seqs + 1));
+    }
+    int64_t base = g->seq_off[g->n_seqs];
+    if (base + len > g->cap_path) {
+        g->cap_path = 2 * (base + len);
+        g->path = (int32_t *)xrealloc(g->path, sizeof(int32_t) * (size_t)g->cap_path);
+    }
+    memcpy(g->path + base, target, sizeof(int32_t) * (size_t)len);
+    g->seq_off[++g->n_seqs] = base + len;
+    free(posnode); free(target); free(kind);
+}
+
+void poa_graph_nodes(const poa_graph_t *g, uint8_t *code, int32_t *rank, int32_t *group) {
+    for (int v = 0; v < g->n_nodes; ++v) {
+        if (code) code[v] = g->code[v];
+        if (rank) rank[v] = g->rank[v];
+        if (group) group[v] = g->leader[v];
+    }
+}
+void poa_graph_edges(const poa_graph_t *g, int32_t *tail, int32_t *head, uint32_t *weight) {
+    for (int e = 0; e < g->n_edges; ++e) {
+        if (tail) tail[e] = g->e_tail[e];
+        if (head) head[e] = g->e_head[e];
+        if (weight) weight[e] = g->e_w[e];
+    }
+}
+int poa_graph_seq_len(const poa_graph_t *g, int s) { return (int)(g->seq_off[s + 1] - g->seq_off[s]); }
+void poa_graph_seq_path(const poa_graph_t *g, int s, int32_t *nodes) {
+    memcpy(nodes, g->path + g->seq_off[s], sizeof(int32_t) * (size_t)poa_graph_seq_len(g, s));
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* S8 heaviest bundle (Lee 2003) with branch completion.                                 */
+
+static int branch_completion(const poa_graph_t *g, int r, int64_t *sc, int32_t *pr) {
+    const int start = g->order[r];
+    for (int e = g->out_head[start]; e >= 0; e = g->e_next_out[e])
+        for (int f = g->in_head[g->e_head[e]]; f >= 0; f = g->e_next_in[f])
+            if (g->e_tail[f] != start) sc[g->e_tail[f]] = -1;
+    int64_t max_score = 0;
+    int max_node = -1;
+    for (int i = r + 1; i < g->n_nodes; ++i) {
+        const int v = g->order[i];
+        sc[v] = -1; pr[v] = -1;
+        for (int e = g->in_head[v]; e >= 0; e = g->e_next_in[e]) {
+            const int t = g->e_tail[e];
+            if (sc[t] == -1) continue;
+            const int64_t w = g->e_w[e];
+            if (sc[v] < w || (sc[v] == w && sc[pr[v]] <= sc[t])) { sc[v] = w; pr[v] = t; }
+        }
+        if (pr[v] != -1) sc[v] += sc[pr[v]];
+        if (max_score < sc[v]) { max_score = sc[v]; max_node = v; }
+    }
+    return max_node;
+}
+
+int poa_consensus(const poa_graph_t *g, int32_t *out_nodes) {
+    const int N = g->n_nodes;
+    if (N == 0) return 0;
+    int64_t *sc = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    int32_t *pr = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+    for (int v = 0; v < N; ++v) { sc[v] = -1; pr[v] = -1; }
+    int mx = -1;
+    for (int r = 0; r < N; ++r) {
+        const int v = g->order[r];
+        for (int e = g->in_head[v]; e >= 0; e = g->e_next_in[e]) {
+            const int t = g->e_tail[e];
+            const int64_t w = g->e_w[e];
+            if (sc[v] < w || (sc[v] == w && sc[pr[v]] <= sc[t])) { sc[v] = w; pr[v] = t; }
+        }
+        if (pr[v] != -1) sc[v] += sc[pr[v]];
+        if (mx == -1 || sc[mx] < sc[v]) mx = v;
+    }
+    while (g->out_deg[mx] != 0) {
+        int nx = branch_completion(g, g->rank[mx], sc, pr);
+        if (nx < 0) break;
+        mx = nx;
+    }
+    int n = 0;
+    for (int v = mx; v != -1; v = pr[v]) out_nodes[n++] = v;
+    for (int a = 0, b = n - 1; a < b; ++a, --b) { int32_t x = out_nodes[a]; out_nodes[a] = out_nodes[b]; out_nodes[b] = x; }
+    free(sc); free(pr);
+    return n;
+}
+
+int poa_msa(const poa_graph_t *g, int with_consensus, char *out) {
+    static const char dec[5] = {'A', 'C', 'G', 'T', 'N'};
+    const int N = g->n_nodes;
+    int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N ? N : 1));
+    int ncol = 0;
+    for (int r = 0; r < N; ++r) {
+        const int v = g->order[r];
+        if (r > 0 && g->leader[g->order[r - 1]] == g->leader[v]) col[v] = ncol - 1;
+        else col[v] = ncol++;
+    }
+    if (out) {
+        const int rows = g->n_seqs + (with_consensus ? 1 : 0);
+        memset(out, '-', (size_t)rows * (size_t)ncol);
+        for (int s = 0; s < g->n_seqs; ++s)
+            for (int64_t k = g->seq_off[s]; k < g->seq_off[s + 1]; ++k)
+                out[(size_t)s * ncol + col[g->path[k]]] = dec[g->code[g->path[k]]];
+        if (with_consensus) {
+            int32_t *cn = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N ? N : 1));
+            int n = poa_consensus(g, cn);
+            for (int k = 0; k < n; ++k) out[(size_t)g->n_seqs * ncol + col[cn[k]]] = dec[g->code[cn[k]]];
+            free(cn);
+        }
+    }
+    free(col);
+    return ncol;
+}
+
+/* ------------------------------------------------------------------------------------ */
+
+poa_graph_t *poa_block_run(const uint8_t *bases, const int32_t *seq_off, int n_seqs,
+                           const uint32_t *weights, const poa_params_t *p,
+                           int32_t *scores, uint64_t *cells) {
+    poa_graph_t *g = poa_graph_new();
+    int64_t maxpairs = 16;
+    for (int s = 0; s < n_seqs; ++s) maxpairs += 2 * (int64_t)(seq_off[s + 1] - seq_off[s]);
+    int32_t *an = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
+    int32_t *ap = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
+    for (int s = 0; s < n_seqs; ++s) {
+        const uint8_t *seq = bases + seq_off[s];
+        const int len = seq_off[s + 1] - seq_off[s];
+        int32_t sc = 0;
+        uint64_t cl = 0;
+        int n = poa_align(g, seq, len, p, an, ap, &sc, &cl);
+        if (scores) scores[s] = sc;
+        if (cells) cells[s] = cl;
+        poa_add_alignment(g, an, ap, n, seq, len, weights ? weights[s] : 1);
+    }
+    free(an); free(ap);
+    return g;
+}
+
+int poa_blocks_run_omp(const uint8_t *bases, const int64_t *seq_off, const int32_t *blk_off,
+                       int n_blocks, const uint32_t *weights, const poa_params_t *p,
+                       int n_threads, int32_t *scores, uint64_t *cells_total,
+                       int32_t *n_nodes_out, int32_t *n_edges_out) {
+    uint64_t total = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+#endif
+    for (int b = 0; b < n_blocks; ++b) {
+        const int s0 = blk_off[b], ns = blk_off[b + 1] - s0;
+        int32_t *off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)ns + 1));
+        for (int s = 0; s <= ns; ++s) off[s] = (int32_t)(seq_off[s0 + s] - seq_off[s0]);
+        uint64_t *cl = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(ns ? ns : 1));
+        poa_graph_t *g = poa_block_run(bases + seq_off[s0], off, ns, weights ? weights + s0 : NULL, p,
+                                       scores ? scores + s0 : NULL, cl);
+        for (int s = 0; s < ns; ++s) total += cl[s];
+        if (n_nodes_out) n_nodes_out[b] = g->n_nodes;
+        if (n_edges_out) n_edges_out[b] = g->n_edges;
+        poa_graph_free(g);
+        free(off); free(cl);
+    }
+    if (cells_total) *cells_total = total;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Independent scorer of an alignment (test helper).                                      */
+
+static int gap_cost(const norm_params_t *P, int k) {
+    int a = P->g + (k - 1) * P->e, b = P->q + (k - 1) * P->c;
+    return a > b ? a : b;
+}
+static int has_edge(const poa_graph_t *g, int u, int v) {
+    for (int e = g->out_head[u]; e >= 0; e = g->e_next_out[e]) if (g->e_head[e] == v) return 1;
+    return 0;
+}
+int32_t poa_rescore(const poa_graph_t *g, const uint8_t *seq, int len, const poa_params_t *pp,
+                    const int32_t *an, const int32_t *ap, int n) {
+    norm_params_t P = normalise(pp);
+    int32_t s = 0;
+    int last_node = -1, last_pos = -1, run = 0, run_kind = 0; /* 1 = node gap, 2 = seq gap */
+    for (int k = 0; k < n; ++k) {
+        const int v = an[k], j = ap[k];
+        if (v < 0 && j < 0) return INT32_MIN;
+        if (v >= 0) {
+            if (v >= g->n_nodes) return INT32_MIN;
+            if (last_node >= 0 && !has_edge(g, last_node, v)) return INT32_MIN;
+            if (last_node < 0 && !P.sw && g->in_deg[v] != 0) return INT32_MIN;
+            last_node = v;
+        }
+        if (j >= 0) {
+            if (j >= len) return INT32_MIN;
+            if (last_pos >= 0 ? j != last_pos + 1 : (!P.sw && j != 0)) return INT32_MIN;
+            last_pos = j;
+        }
+        const int kd = (v >= 0 && j >= 0) ? 0 : (v >= 0 ? 1 : 2);
+        if (kd != run_kind) { if (run_kind) s += gap_cost(&P, run); run = 0; run_kind = kd; }
+        if (kd == 0) s += (g->code[v] == seq[j]) ? P.m : P.n; else ++run;
+    }
+    if (run_kind) s += gap_cost(&P, run);
+    if (!P.sw && n > 0) {
+        if (last_pos != len - 1) return INT32_MIN;
+        if (last_node >= 0 && g->out_deg[last_node] != 0) return INT32_MIN;
+    }
+    return s;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* XXH64 -- restated from the published xxHash specification (Cyan4973/xxHash,            */
+/* doc/xxhash_spec.md); the reference calls it at src/smooth.cpp:716 with seed 0.         */
+
+#define XP1 0x9E3779B185EBCA87ULL
+#define XP2 0xC2B2AE3D27D4EB4FULL
+#define XP3 0x165667B19E3779F9ULL
+#define XP4 0x85EBCA77C2B2AE63ULL
+#define XP5 0x27D4EB2F165667C5ULL
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline uint64_t xround(uint64_t acc, uint64_t in) { return rotl64(acc + in * XP2, 31) * XP1; }
+static inline uint64_t xmerge(uint64_t h, uint64_t v) { return (h ^ xround(0, v)) * XP1 + XP4; }
+
+uint64_t poa_xxh64(const void *data, uint64_t len, uint64_t seed) {
+    const uint8_t *p = (const uint8_t *)data, *end = p + len;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + XP1 + XP2, v2 = seed + XP2, v3 = seed, v4 = seed - XP1;
+        const uint8_t *lim = end - 32;
+        do {
+            v1 = xround(v1, rd64(p)); v2 = xround(v2, rd64(p + 8));
+            v3 = xround(v3, rd64(p + 16)); v4 = xround(v4, rd64(p + 24));
+            p += 32;
+        } while (p <= lim);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+    } else h = seed + XP5;
+    h += len;
+    while (p + 8 <= end) { h ^= xround(0, rd64(p)); h = rotl64(h, 27) * XP1 + XP4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)rd32(p) * XP1; h = rotl64(h, 23) * XP2 + XP3; p += 4; }
+    while (p < end) { h ^= (*p) * XP5; h = rotl64(h, 11) * XP1; ++p; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    return h;
+}
