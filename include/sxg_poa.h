@@ -1,0 +1,178 @@
+/*
+ * sxg_poa.h -- C ABI of the MI355X-native blocked partial-order-alignment engine.
+ *
+ * Drop-in boundary for the per-block POA of pangenome/smoothxg.  The reference has no
+ * plugin/FFI interface for this path; the seam is the block of spoa calls inside
+ *   smooth_spoa()  src/smooth.cpp:752-786   (Create / Align / AddAlignment / consensus / MSA)
+ * executed once per block by the OpenMP loop of
+ *   smooth_and_lace()  src/smooth.cpp:1931-2312.
+ * This library replaces that inner sequence for a whole BATCH of blocks per call:
+ * everything above it (XG access, padding, dedup: src/smooth.cpp:676-743) and below it
+ * (build_odgi_SPOA, unchop, lacing: src/smooth.cpp:2576-2654, 935-1010, src/main.cpp:599+)
+ * stays with the caller.  INTEGRATION.md shows the binding a smoothxg maintainer adds.
+ *
+ * Conventions
+ *   - bases are codes 0..4 = A,C,G,T,N (the XG alphabet, src/xg.cpp:24-53); >4 is read as N.
+ *   - scoring uses spoa's sign convention exactly as smooth_spoa receives it
+ *     (src/smooth.cpp:2098-2106): m > 0, n,g,e,q,c <= 0; mode 0 = local (kSW, default,
+ *     src/main.cpp:487), 1 = global (kNW).
+ *   - all functions return 0 on success or a negative SXG_E_* code; they never throw,
+ *     exit() or abort() (the reference exit(1)s, src/smooth.cpp:943).  The text of the
+ *     last error of the calling thread is available from sxg_poa_last_error().
+ *   - every *_out struct is library-owned; release it with the matching *_free.
+ *   - a handle is bound to one GPU and one HIP stream; one in-flight batch per handle.
+ *     Use one handle per host thread / per rank.
+ */
+#ifndef SXG_POA_H
+#define SXG_POA_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SXG_POA_ABI_VERSION 1
+
+#define SXG_MODE_LOCAL 0  /* spoa::AlignmentType::kSW */
+#define SXG_MODE_GLOBAL 1 /* spoa::AlignmentType::kNW */
+
+/* return codes */
+#define SXG_OK 0
+#define SXG_E_INVALID (-1)   /* bad argument */
+#define SXG_E_NODEVICE (-2)  /* no usable HIP device / HIP runtime error */
+#define SXG_E_NOMEM (-3)     /* device or host allocation failed */
+#define SXG_E_BLOCK (-4)     /* at least one block failed; see out->status[] */
+
+/* per-block status (out->status[b]) */
+#define SXG_ST_OK 0
+#define SXG_ST_ROWS_OVERFLOW 1
+#define SXG_ST_POOL_OVERFLOW 2
+#define SXG_ST_TBX_OVERFLOW 3
+#define SXG_ST_NODES_OVERFLOW 4
+#define SXG_ST_TOO_LONG 5 /* a sequence exceeds SXG_POA_MAX_SEQ_LEN */
+
+#define SXG_POA_MAX_SEQ_LEN 24575
+
+/* The six scores + alignment type that smooth_spoa hands to
+ * spoa::AlignmentEngine::Create (src/smooth.cpp:752-755).                                */
+typedef struct sxg_poa_params {
+    int8_t m, n, g, e, q, c;
+    uint8_t mode;
+    uint8_t reserved;
+} sxg_poa_params;
+
+typedef struct sxg_poa_handle sxg_poa_handle;
+
+/* A batch of blocks.  Block b owns sequences blk_off[b] .. blk_off[b+1]-1, in the order
+ * they are to be aligned (smoothxg: longest first, src/blocks.cpp:206-219); sequence s owns
+ * bases[seq_off[s] .. seq_off[s+1]).  weights[s] is the dedup multiplicity passed to
+ * AddAlignment (src/smooth.cpp:764); NULL = all 1.                                        */
+typedef struct sxg_poa_batch_in {
+    int32_t n_blocks;
+    const int32_t *blk_off;       /* [n_blocks+1] */
+    const int64_t *seq_off;       /* [n_seqs+1]   */
+    const uint8_t *bases;         /* [seq_off[n_seqs]] */
+    const uint32_t *weights;      /* [n_seqs] or NULL */
+    const sxg_poa_params *params; /* [n_blocks] if per_block_params else [1] */
+    int32_t per_block_params;
+    int32_t want_consensus; /* GenerateConsensus(), src/smooth.cpp:773 */
+    int32_t want_msa;       /* GenerateMultipleSequenceAlignment(), src/smooth.cpp:785 */
+} sxg_poa_batch_in;
+
+/* Per-block POA results, dense and block-major.  Node ids are block-local, 0-based, in
+ * creation order (build_odgi_SPOA adds 1, src/smooth.cpp:2587).                            */
+typedef struct sxg_poa_batch_out {
+    int32_t n_blocks;
+    int64_t n_seqs;
+    int32_t *status;       /* [n_blocks] SXG_ST_* */
+    int64_t *node_off;     /* [n_blocks+1] */
+    uint8_t *node_code;    /* letter of every node */
+    int32_t *node_rank;    /* topological rank inside the block */
+    int32_t *node_group;   /* aligned-group leader (node id); group == MSA column class */
+    int64_t *edge_off;     /* [n_blocks+1] */
+    int32_t *edge_tail;    /* edges in creation order */
+    int32_t *edge_head;
+    uint32_t *edge_weight;
+    int32_t *seq_path_nodes; /* [total bases] node of every base, indexed like in->bases;
+                                replaces sequences()[i] + Successor(i), src/smooth.cpp:2604-2610 */
+    int32_t *score;          /* [n_seqs] optimal alignment score of sequence s vs. the graph
+                                of its predecessors (0 for the first sequence of a block)    */
+    uint64_t *cells;         /* [n_seqs] DP cells = graph nodes x sequence length           */
+    int64_t *cons_off;       /* [n_blocks+1] (NULL unless want_consensus) */
+    int32_t *cons_nodes;     /* consensus node ids, src/smooth.cpp:2624-2637 */
+    int64_t *msa_off;        /* [n_blocks+1] byte offsets into msa (NULL unless want_msa) */
+    int32_t *msa_cols;       /* [n_blocks] columns; rows = #seqs (+1 consensus row if wanted) */
+    char *msa;               /* row-major 'A','C','G','T','N','-' (GAP_CHAR, src/smooth.cpp:8-11) */
+    void *_owner;
+} sxg_poa_batch_out;
+
+/* Stand-alone Align(sequence, graph) problems (src/smooth.cpp:761).  Graph p is given in
+ * topological order: row r of problem p is global row row_off[p]+r; its predecessors are
+ * preds[pred_off[R] .. pred_off[R+1]) as 1-based row numbers LOCAL to the problem (rank+1),
+ * in edge-insertion order; an empty list means "source".                                   */
+typedef struct sxg_poa_align_in {
+    int32_t n;
+    const int64_t *row_off;  /* [n+1] */
+    const uint8_t *row_code; /* [rows] */
+    const uint8_t *row_sink; /* [rows] 1 = node has no out-edge */
+    const int64_t *pred_off; /* [rows+1] */
+    const int32_t *preds;
+    const int64_t *seq_off; /* [n+1] */
+    const uint8_t *bases;
+    const sxg_poa_params *params;
+    int32_t per_problem_params;
+} sxg_poa_align_in;
+
+/* Alignment p = pairs pair_off[p]..pair_off[p+1]: (row | -1, sequence position | -1) in
+ * forward order -- spoa::Alignment with ranks in place of node ids.                         */
+typedef struct sxg_poa_align_out {
+    int32_t n;
+    int32_t *status;
+    int32_t *score;
+    int64_t *pair_off;
+    int32_t *pair_row;
+    int32_t *pair_pos;
+    void *_owner;
+} sxg_poa_align_out;
+
+/* Timing / accounting of the last execute on a handle. */
+typedef struct sxg_poa_stats {
+    double kernel_ms;     /* HIP-event time of the POA kernels on the handle's stream */
+    uint64_t cells;       /* DP cells evaluated */
+    uint64_t dp_launches; /* number of POA kernel launches */
+    uint64_t algo_bytes;  /* algorithmic bytes (2*n_cross*sizeof(score)+1 per cell) */
+    int32_t n_slots;      /* resident workgroups used */
+    int32_t retries;      /* blocks re-run with a larger arena */
+    uint64_t device_bytes;/* device memory held by the handle */
+} sxg_poa_stats;
+
+int sxg_poa_abi_version(void);
+int sxg_poa_device_count(void);
+const char *sxg_poa_last_error(void);
+
+int sxg_poa_create(int device, sxg_poa_handle **out);
+void sxg_poa_destroy(sxg_poa_handle *h);
+
+/* One-shot: upload, run, download. */
+int sxg_poa_batch_run(sxg_poa_handle *h, const sxg_poa_batch_in *in, sxg_poa_batch_out *out);
+/* Staged form (what bench.py times): inputs become resident in HBM with _upload; _execute
+ * runs the whole batch on the device and leaves results in HBM; _download copies them out. */
+int sxg_poa_batch_upload(sxg_poa_handle *h, const sxg_poa_batch_in *in);
+int sxg_poa_batch_execute(sxg_poa_handle *h);
+int sxg_poa_batch_download(sxg_poa_handle *h, sxg_poa_batch_out *out);
+void sxg_poa_batch_free(sxg_poa_batch_out *out);
+
+int sxg_poa_align_batch(sxg_poa_handle *h, const sxg_poa_align_in *in, sxg_poa_align_out *out);
+void sxg_poa_align_free(sxg_poa_align_out *out);
+
+int sxg_poa_get_stats(sxg_poa_handle *h, sxg_poa_stats *out);
+/* Cap on device memory the handle may use for scratch arenas (bytes; 0 = default 3/4 of free). */
+int sxg_poa_set_memory_budget(sxg_poa_handle *h, uint64_t bytes);
+
+/* XXH64 of a sequence: the dedup key smooth_spoa uses (src/smooth.cpp:716, seed 0). */
+uint64_t sxg_xxh64(const void *data, uint64_t len, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

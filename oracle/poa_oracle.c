@@ -266,8 +266,8 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
         if (score) *score = best;
         int i = best_i, j = best_j, st = SRC_STOP; /* st: STOP == "in H" */
         for (;;) {
-            if (i == 0) { /* virtual row: only NW gets here */
-                if (j == 0) break;
+            if (i == 0) { /* virtual row: H[0][j] = 0 ends a local alignment */
+                if (j == 0 || P.sw) break;
                 out_node[n] = -1; out_pos[n] = j - 1; ++n; --j;
                 continue;
             }

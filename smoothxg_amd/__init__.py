@@ -1,0 +1,7 @@
+"""smoothxg_amd -- MI355X-native blocked partial-order-alignment engine (smoothxg hot path).
+
+Only what the path needs: csrc/ (HIP kernels + the C ABI of include/sxg_poa.h), the ctypes
+host mirror (poa.py), the synthetic workload generator (synth.py) and block sharding
+(shard.py).  The CPU oracle lives in oracle/ and is never imported from here.
+"""
+from .poa import PoaEngine, PoaError, Params, params_from_cli, load_library, xxh64  # noqa: F401

@@ -1,0 +1,1013 @@
+// sxg_poa.hip -- kernels + host side of the C ABI declared in include/sxg_poa.h.
+//
+// One persistent workgroup ("slot") owns one smoothxg block at a time and runs the whole
+// sequential chain of src/smooth.cpp:760-769 on the device:
+//     for every sequence: rows <- graph; DP fill; traceback; fuse; re-rank
+// Slots pull blocks from a cost-sorted queue (largest first), so thousands of blocks are
+// processed per launch with no host round trip between the alignments of a block.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sxg_poa.h"
+#include "poa_dp.hip.h"
+#include "poa_graph_dev.h"
+
+using namespace sxg;
+
+// =======================================================================================
+// device side
+// =======================================================================================
+
+struct SlotLayout {  // byte offsets inside one slot arena (all 16-byte aligned)
+    size_t hdr, code, rank, order, order_tmp, leader, gmem, in_head, in_tail, out_head, out_tail, in_deg,
+        out_deg, e_tail, e_head, e_next_in, e_next_out, e_w, posnode, target, newidx, nexta, preva, slotadd,
+        kind, r_code, r_flags, r_pred_off, r_preds, r_slot, r_tbx, r_sseq, r_row_node, tb, tbx16, tbx32, pool,
+        row0, cons_sc, cons_pr, pair_row, pair_pos, total;
+    int nodes_cap, rows_cap, pool_slots, tbx16_cap, tbx32_cap, scratch_len, Lpad, word_bytes;
+};
+
+static size_t lay(size_t& cur, size_t bytes) {
+    size_t o = cur;
+    cur += (bytes + 255) & ~(size_t)255;
+    return o;
+}
+
+static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int tbx16_cap, int tbx32_cap, int Lpad,
+                              int word_bytes, bool pairs) {
+    SlotLayout L;
+    memset(&L, 0, sizeof(L));
+    L.nodes_cap = nodes_cap; L.rows_cap = rows_cap; L.pool_slots = pool_slots;
+    L.tbx16_cap = tbx16_cap; L.tbx32_cap = tbx32_cap; L.Lpad = Lpad; L.word_bytes = word_bytes;
+    const size_t C = (size_t)nodes_cap + 4, S = (size_t)std::max(nodes_cap, Lpad) + 4, Rr = (size_t)rows_cap + 4;
+    L.scratch_len = (int)S;
+    size_t cur = 0;
+    L.hdr = lay(cur, 64);
+    L.code = lay(cur, C);
+    L.rank = lay(cur, 4 * C); L.order = lay(cur, 4 * C); L.order_tmp = lay(cur, 4 * C); L.leader = lay(cur, 4 * C);
+    L.gmem = lay(cur, 20 * C);
+    L.in_head = lay(cur, 4 * C); L.in_tail = lay(cur, 4 * C); L.out_head = lay(cur, 4 * C);
+    L.out_tail = lay(cur, 4 * C); L.in_deg = lay(cur, 4 * C); L.out_deg = lay(cur, 4 * C);
+    L.e_tail = lay(cur, 4 * C); L.e_head = lay(cur, 4 * C); L.e_next_in = lay(cur, 4 * C);
+    L.e_next_out = lay(cur, 4 * C); L.e_w = lay(cur, 4 * C);
+    L.posnode = lay(cur, 4 * S); L.target = lay(cur, 4 * S); L.newidx = lay(cur, 4 * S);
+    L.nexta = lay(cur, 4 * S); L.preva = lay(cur, 4 * S); L.slotadd = lay(cur, 4 * S); L.kind = lay(cur, S);
+    L.r_code = lay(cur, Rr); L.r_flags = lay(cur, Rr); L.r_pred_off = lay(cur, 4 * Rr);
+    L.r_preds = lay(cur, 4 * C); L.r_slot = lay(cur, 4 * Rr); L.r_tbx = lay(cur, 4 * Rr);
+    L.r_sseq = lay(cur, 4 * Rr); L.r_row_node = lay(cur, 4 * Rr);
+    L.tb = lay(cur, ((size_t)rows_cap + 1) * Lpad);
+    L.tbx16 = lay(cur, (size_t)std::max(tbx16_cap, 1) * Lpad * 2);
+    L.tbx32 = lay(cur, (size_t)std::max(tbx32_cap, 1) * Lpad * 4);
+    L.pool = lay(cur, (size_t)pool_slots * Lpad * word_bytes);
+    L.row0 = lay(cur, (size_t)Lpad * word_bytes);
+    L.cons_sc = lay(cur, 8 * C); L.cons_pr = lay(cur, 4 * C);
+    if (pairs) { L.pair_row = lay(cur, 4 * (Rr + Lpad)); L.pair_pos = lay(cur, 4 * (Rr + Lpad)); }
+    L.total = cur;
+    return L;
+}
+
+struct SlotViews {
+    GraphView G;
+    RowsView R;
+    DpBuffers B;
+    int64_t* cons_sc;
+    int32_t* cons_pr;
+    int32_t *pair_row, *pair_pos;
+};
+
+__device__ static SlotViews slot_views(uint8_t* base, const SlotLayout& L) {
+    SlotViews V;
+    int32_t* hdr = (int32_t*)(base + L.hdr);
+    V.G.n_nodes = hdr; V.G.n_edges = hdr + 1;
+    V.G.code = base + L.code;
+#define P32(f) (int32_t*)(base + L.f)
+    V.G.rank = P32(rank); V.G.order = P32(order); V.G.order_tmp = P32(order_tmp); V.G.leader = P32(leader);
+    V.G.gmem = P32(gmem); V.G.in_head = P32(in_head); V.G.in_tail = P32(in_tail); V.G.out_head = P32(out_head);
+    V.G.out_tail = P32(out_tail); V.G.in_deg = P32(in_deg); V.G.out_deg = P32(out_deg);
+    V.G.e_tail = P32(e_tail); V.G.e_head = P32(e_head); V.G.e_next_in = P32(e_next_in);
+    V.G.e_next_out = P32(e_next_out); V.G.e_w = (uint32_t*)(base + L.e_w);
+    V.G.posnode = P32(posnode); V.G.target = P32(target); V.G.newidx = P32(newidx); V.G.nexta = P32(nexta);
+    V.G.preva = P32(preva); V.G.slotadd = P32(slotadd); V.G.kind = (int8_t*)(base + L.kind);
+    V.R.code = base + L.r_code; V.R.flags = base + L.r_flags; V.R.pred_off = P32(r_pred_off);
+    V.R.preds = P32(r_preds); V.R.slot = P32(r_slot); V.R.tbx = P32(r_tbx); V.R.sseq = P32(r_sseq);
+    V.R.row_node = P32(r_row_node);
+    V.B.tb = base + L.tb; V.B.tbx16 = (uint16_t*)(base + L.tbx16); V.B.tbx32 = (uint32_t*)(base + L.tbx32);
+    V.B.pool = base + L.pool; V.B.row0 = base + L.row0;
+    V.cons_sc = (int64_t*)(base + L.cons_sc); V.cons_pr = P32(cons_pr);
+    V.pair_row = P32(pair_row); V.pair_pos = P32(pair_pos);
+#undef P32
+    return V;
+}
+
+__host__ __device__ static inline Scoring normalise(const sxg_poa_params& p) {
+    Scoring S;
+    S.m = p.m; S.n = p.n; S.g = p.g; S.e = p.e; S.q = p.q; S.c = p.c;
+    S.sw = p.mode == SXG_MODE_LOCAL;
+    S.convex = 0;
+    if (S.g >= S.e) { S.e = S.g; S.q = S.g; S.c = S.g; }
+    else if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
+    else S.convex = 1;
+    return S;
+}
+
+struct BlockArgs {
+    // inputs (device)
+    const int32_t* blk_off; const int64_t* seq_off; const uint8_t* bases; const uint32_t* weights;
+    const sxg_poa_params* params; int per_block_params;
+    // work list of this launch
+    const int32_t* work; int n_work; int32_t* queue;
+    // slots
+    uint8_t* arena; SlotLayout lay;
+    // outputs (device), worst-case layout: block b's nodes/edges start at seq_off[blk_off[b]]
+    int32_t* status; int32_t* n_nodes; int32_t* n_edges; int32_t* n_cons;
+    uint8_t* node_code; int32_t* node_rank; int32_t* node_group;
+    int32_t* edge_tail; int32_t* edge_head; uint32_t* edge_weight;
+    int32_t* paths; int32_t* score; unsigned long long* cells; int32_t* cons_nodes;
+    int want_consensus;
+};
+
+template <int T, int W, bool CVX, bool H16>
+__global__ __launch_bounds__(T) void poa_block_kernel(const BlockArgs A) {
+    __shared__ __attribute__((aligned(16))) int lds[160];
+    __shared__ int s_work;
+    WgCtx ctx{lds + 128};
+    const int t = threadIdx.x;
+    SlotViews V = slot_views(A.arena + (size_t)blockIdx.x * A.lay.total, A.lay);
+    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.tbx16_cap, A.lay.tbx32_cap};
+    for (;;) {
+        __syncthreads();
+        if (t == 0) s_work = atomicAdd(A.queue, 1);
+        __syncthreads();
+        const int wi = s_work;
+        if (wi >= A.n_work) break;
+        const int b = A.work[wi];
+        const int s0 = A.blk_off[b], s1 = A.blk_off[b + 1];
+        const int64_t base0 = A.seq_off[s0];
+        const Scoring S = normalise(A.params[A.per_block_params ? b : 0]);
+        if (t == 0) { *V.G.n_nodes = 0; *V.G.n_edges = 0; }
+        __syncthreads();
+        int status = ST_OK;
+        for (int s = s0; s < s1 && status == ST_OK; ++s) {
+            const int64_t so = A.seq_off[s];
+            const int len = (int)(A.seq_off[s + 1] - so);
+            const uint8_t* seq = A.bases + so;
+            for (int i = t; i < len; i += T) V.G.posnode[i] = -1;
+            __syncthreads();
+            const int N = *V.G.n_nodes;
+            int score = 0;
+            if (len + 1 > T * W) { status = ST_TOO_LONG; break; }
+            if (N + len > A.lay.nodes_cap) { status = ST_NODES_OVERFLOW; break; }
+            if (N > 0 && len > 0) {
+                status = prep_rows(ctx, V.G, V.R, caps);
+                if (status != ST_OK) break;
+                DpResult res;
+                dp_fill<T, W, CVX, H16>(S, V.R, N, seq, len, V.B, lds, res);
+                __syncthreads();
+                if (t == 0 && res.bi >= 0)
+                    traceback<false>(V.R, V.B, T * W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
+                score = res.bi >= 0 ? res.best : 0;
+                __syncthreads();
+            }
+            if (t == 0) { A.score[s] = score; A.cells[s] = (unsigned long long)N * (unsigned long long)len; }
+            add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
+        }
+        __syncthreads();
+        // results of the block
+        const int N = *V.G.n_nodes, E = *V.G.n_edges;
+        if (status == ST_OK) {
+            for (int v = t; v < N; v += T) {
+                A.node_code[base0 + v] = V.G.code[v];
+                A.node_rank[base0 + v] = V.G.rank[v];
+                A.node_group[base0 + v] = V.G.leader[v];
+            }
+            for (int e = t; e < E; e += T) {
+                A.edge_tail[base0 + e] = V.G.e_tail[e];
+                A.edge_head[base0 + e] = V.G.e_head[e];
+                A.edge_weight[base0 + e] = V.G.e_w[e];
+            }
+            int nc = 0;
+            if (A.want_consensus && t == 0) nc = consensus_serial(V.G, V.cons_sc, V.cons_pr, A.cons_nodes + base0);
+            if (t == 0) { A.n_nodes[b] = N; A.n_edges[b] = E; A.n_cons[b] = nc; }
+        } else if (t == 0) { A.n_nodes[b] = 0; A.n_edges[b] = 0; A.n_cons[b] = 0; }
+        if (t == 0) A.status[b] = status;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+struct AlignArgs {
+    const int64_t* row_off; const uint8_t* row_code; const uint8_t* row_sink; const int64_t* pred_off;
+    const int32_t* preds; const int64_t* seq_off; const uint8_t* bases; const sxg_poa_params* params;
+    int per_problem_params;
+    const int32_t* work; int n_work; int32_t* queue;
+    uint8_t* arena; SlotLayout lay;
+    int32_t* status; int32_t* score; int32_t* n_pairs;
+    int32_t* pair_row; int32_t* pair_pos;  // worst-case layout: problem p at row_off[p] + seq_off[p]
+};
+
+template <int T, int W, bool CVX, bool H16>
+__global__ __launch_bounds__(T) void poa_align_kernel(const AlignArgs A) {
+    __shared__ __attribute__((aligned(16))) int lds[160];
+    __shared__ int s_work;
+    WgCtx ctx{lds + 128};
+    const int t = threadIdx.x;
+    SlotViews V = slot_views(A.arena + (size_t)blockIdx.x * A.lay.total, A.lay);
+    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.tbx16_cap, A.lay.tbx32_cap};
+    for (;;) {
+        __syncthreads();
+        if (t == 0) s_work = atomicAdd(A.queue, 1);
+        __syncthreads();
+        const int wi = s_work;
+        if (wi >= A.n_work) break;
+        const int p = A.work[wi];
+        const int64_t r0 = A.row_off[p];
+        const int N = (int)(A.row_off[p + 1] - r0);
+        const int64_t so = A.seq_off[p];
+        const int len = (int)(A.seq_off[p + 1] - so);
+        const Scoring S = normalise(A.params[A.per_problem_params ? p : 0]);
+        const int64_t e0 = A.pred_off[r0];
+        int status = ST_OK, score = 0, npairs = 0;
+        const int64_t out0 = r0 + so;
+        if (len + 1 > T * W) status = ST_TOO_LONG;
+        else if (N > A.lay.rows_cap) status = ST_ROWS_OVERFLOW;
+        else if (N > 0 && len > 0) {
+            for (int r = t; r < N; r += T) {
+                V.R.code[r] = A.row_code[r0 + r];
+                V.R.pred_off[r] = (int)(A.pred_off[r0 + r] - e0);
+                V.R.row_node[r] = r;
+                V.R.slot[r] = r;
+                V.R.flags[r] = A.row_sink[r0 + r] ? ROW_SINK : 0;
+            }
+            if (t == 0) V.R.pred_off[N] = (int)(A.pred_off[r0 + N] - e0);
+            __syncthreads();
+            const int E = V.R.pred_off[N];
+            for (int k = t; k < E; k += T) V.R.preds[k] = A.preds[e0 + k];
+            __syncthreads();
+            for (int r = t; r < N; r += T)
+                for (int k = V.R.pred_off[r]; k < V.R.pred_off[r + 1]; ++k) {
+                    const int pr = V.R.preds[k];  // 1-based row of the predecessor
+                    if (pr >= 1 && pr != r) {     // not the previous rank -> that row must be stored
+                        atomicOr((unsigned*)(V.R.flags + ((pr - 1) & ~3)), (unsigned)ROW_STORE << (8 * ((pr - 1) & 3)));
+                        atomicMax(&V.R.slot[pr - 1], r);
+                    }
+                }
+            status = finish_rows(ctx, N, V.R, caps);
+            if (status == ST_OK) {
+                DpResult res;
+                dp_fill<T, W, CVX, H16>(S, V.R, N, A.bases + so, len, V.B, lds, res);
+                __syncthreads();
+                if (t == 0 && res.bi >= 0) {
+                    npairs = traceback<true>(V.R, V.B, T * W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
+                    score = res.best;
+                    for (int k = 0; k < npairs; ++k) {  // reverse into the output
+                        A.pair_row[out0 + k] = V.pair_row[npairs - 1 - k] - 1;
+                        A.pair_pos[out0 + k] = V.pair_pos[npairs - 1 - k];
+                    }
+                }
+            }
+        }
+        if (t == 0) { A.status[p] = status; A.score[p] = score; A.n_pairs[p] = npairs; }
+    }
+}
+
+// dense <- worst-case gather (one workgroup per block, grid-stride over blocks)
+template <class Tv>
+__global__ void gather_kernel(const Tv* __restrict__ src, Tv* __restrict__ dst, const int64_t* __restrict__ src_off,
+                              const int64_t* __restrict__ dst_off, int n) {
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        const int64_t s = src_off[b], d = dst_off[b], cnt = dst_off[b + 1] - d;
+        for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) dst[d + i] = src[s + i];
+    }
+}
+
+// =======================================================================================
+// host side
+// =======================================================================================
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                              \
+    do {                                                                                       \
+        hipError_t _e = (x);                                                                   \
+        if (_e != hipSuccess)                                                                  \
+            return fail(_e == hipErrorOutOfMemory ? SXG_E_NOMEM : SXG_E_NODEVICE,              \
+                        std::string(#x) + ": " + hipGetErrorString(_e));                       \
+    } while (0)
+
+struct Variant { int T, W; };
+// smallest first; Lpad = T*W must exceed the longest sequence of a block
+static const Variant kVariants[] = {{64, 8}, {64, 16}, {128, 16}, {256, 12}, {256, 16}, {256, 20},
+                                    {256, 24}, {512, 16}, {512, 24}, {1024, 24}};
+static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+
+template <class Args> using KernelFn = void (*)(const Args);
+
+template <int T, int W> static KernelFn<BlockArgs> pick_block(bool cvx, bool h16) {
+    if (cvx) return h16 ? poa_block_kernel<T, W, true, true> : poa_block_kernel<T, W, true, false>;
+    return h16 ? poa_block_kernel<T, W, false, true> : poa_block_kernel<T, W, false, false>;
+}
+template <int T, int W> static KernelFn<AlignArgs> pick_align(bool cvx, bool h16) {
+    if (cvx) return h16 ? poa_align_kernel<T, W, true, true> : poa_align_kernel<T, W, true, false>;
+    return h16 ? poa_align_kernel<T, W, false, true> : poa_align_kernel<T, W, false, false>;
+}
+static KernelFn<BlockArgs> block_kernel(int v, bool cvx, bool h16) {
+    switch (v) {
+        case 0: return pick_block<64, 8>(cvx, h16);
+        case 1: return pick_block<64, 16>(cvx, h16);
+        case 2: return pick_block<128, 16>(cvx, h16);
+        case 3: return pick_block<256, 12>(cvx, h16);
+        case 4: return pick_block<256, 16>(cvx, h16);
+        case 5: return pick_block<256, 20>(cvx, h16);
+        case 6: return pick_block<256, 24>(cvx, h16);
+        case 7: return pick_block<512, 16>(cvx, h16);
+        case 8: return pick_block<512, 24>(cvx, h16);
+        default: return pick_block<1024, 24>(cvx, h16);
+    }
+}
+static KernelFn<AlignArgs> align_kernel(int v, bool cvx, bool h16) {
+    switch (v) {
+        case 0: return pick_align<64, 8>(cvx, h16);
+        case 1: return pick_align<64, 16>(cvx, h16);
+        case 2: return pick_align<128, 16>(cvx, h16);
+        case 3: return pick_align<256, 12>(cvx, h16);
+        case 4: return pick_align<256, 16>(cvx, h16);
+        case 5: return pick_align<256, 20>(cvx, h16);
+        case 6: return pick_align<256, 24>(cvx, h16);
+        case 7: return pick_align<512, 16>(cvx, h16);
+        case 8: return pick_align<512, 24>(cvx, h16);
+        default: return pick_align<1024, 24>(cvx, h16);
+    }
+}
+static int variant_for_len(int maxlen) {
+    for (int v = 0; v < kNumVariants; ++v)
+        if (kVariants[v].T * kVariants[v].W >= maxlen + 1) return v;
+    return -1;
+}
+
+// Is an int16 H safe for the packed row words?  |H| bound: SW 0..m*L; NW additionally the
+// all-gap path through at most rows_max nodes.
+static bool h16_safe(const Scoring& S, int maxlen, int rows_max) {
+    long hi = (long)std::abs(S.m) * maxlen;
+    long lo = 0;
+    if (!S.sw) {
+        const long ext = std::max(std::max(std::abs(S.e), std::abs(S.c)), 1);
+        lo = std::abs(S.g) + std::abs(S.q) + ((long)rows_max + maxlen) * ext + (long)std::abs(S.n) * maxlen;
+    }
+    return hi < 30000 && lo < 30000;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SXG_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            want = bytes;
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) { p = nullptr; return fail(SXG_E_NOMEM, "hipMalloc failed for " + std::to_string(bytes) + " bytes"); }
+        cap = want;
+        return SXG_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class Tp> Tp* as() const { return (Tp*)p; }
+};
+
+struct BlockMeta {
+    int maxlen = 0, nseq = 0, variant = -1;
+    int64_t sumlen = 0;
+    double cost = 0;
+    bool cvx = false, sw = true;
+    Scoring S;
+};
+
+struct sxg_poa_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cu = 256;
+    uint64_t mem_budget = 0;
+    // resident batch
+    bool have_batch = false, executed = false;
+    int n_blocks = 0;
+    int64_t n_seqs = 0, n_bases = 0;
+    int want_consensus = 0, want_msa = 0, per_block_params = 0;
+    std::vector<int32_t> h_blk_off;
+    std::vector<int64_t> h_seq_off;
+    std::vector<sxg_poa_params> h_params;
+    std::vector<BlockMeta> meta;
+    DevBuf d_blk_off, d_seq_off, d_bases, d_weights, d_params;
+    bool has_weights = false;
+    DevBuf d_status, d_nn, d_ne, d_nc, d_node_code, d_node_rank, d_node_group, d_edge_tail, d_edge_head, d_edge_w,
+        d_paths, d_score, d_cells, d_cons, d_work, d_queue, d_arena;
+    DevBuf d_tmp_a, d_tmp_b, d_tmp_c, d_tmp_d;
+    sxg_poa_stats stats{};
+};
+
+extern "C" int sxg_poa_abi_version(void) { return SXG_POA_ABI_VERSION; }
+extern "C" const char* sxg_poa_last_error(void) { return g_err.c_str(); }
+extern "C" int sxg_poa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int sxg_poa_create(int device, sxg_poa_handle** out) {
+    if (!out) return fail(SXG_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SXG_E_NODEVICE, "no HIP device available");
+    if (device < 0 || device >= n) return fail(SXG_E_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    sxg_poa_handle* h = new sxg_poa_handle();
+    h->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    h->num_cu = prop.multiProcessorCount;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    *out = h;
+    return SXG_OK;
+}
+
+static void release_all(sxg_poa_handle* h) {
+    DevBuf* bufs[] = {&h->d_blk_off, &h->d_seq_off, &h->d_bases, &h->d_weights, &h->d_params, &h->d_status, &h->d_nn,
+                      &h->d_ne, &h->d_nc, &h->d_node_code, &h->d_node_rank, &h->d_node_group, &h->d_edge_tail,
+                      &h->d_edge_head, &h->d_edge_w, &h->d_paths, &h->d_score, &h->d_cells, &h->d_cons, &h->d_work,
+                      &h->d_queue, &h->d_arena, &h->d_tmp_a, &h->d_tmp_b, &h->d_tmp_c, &h->d_tmp_d};
+    for (DevBuf* b : bufs) b->release();
+}
+
+extern "C" void sxg_poa_destroy(sxg_poa_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    release_all(h);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int sxg_poa_set_memory_budget(sxg_poa_handle* h, uint64_t bytes) {
+    if (!h) return fail(SXG_E_INVALID, "handle is NULL");
+    h->mem_budget = bytes;
+    return SXG_OK;
+}
+
+extern "C" int sxg_poa_get_stats(sxg_poa_handle* h, sxg_poa_stats* out) {
+    if (!h || !out) return fail(SXG_E_INVALID, "NULL argument");
+    *out = h->stats;
+    return SXG_OK;
+}
+
+static uint64_t arena_budget(sxg_poa_handle* h) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 8ull << 30;
+    uint64_t avail = (uint64_t)fr + h->d_arena.cap;  // the arena we already hold can be reused
+    uint64_t b = avail / 4 * 3;
+    if (h->mem_budget && h->mem_budget < b) b = h->mem_budget;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* in) {
+    if (!h || !in) return fail(SXG_E_INVALID, "NULL argument");
+    if (in->n_blocks < 0 || (in->n_blocks > 0 && (!in->blk_off || !in->seq_off || !in->params)))
+        return fail(SXG_E_INVALID, "batch_in has NULL arrays");
+    HIPCHK(hipSetDevice(h->device));
+    h->have_batch = false; h->executed = false;
+    const int nb = in->n_blocks;
+    if (nb > 0 && in->blk_off[0] != 0) return fail(SXG_E_INVALID, "blk_off[0] must be 0");
+    const int64_t ns = nb ? in->blk_off[nb] : 0;
+    for (int b = 0; b < nb; ++b)
+        if (in->blk_off[b + 1] < in->blk_off[b]) return fail(SXG_E_INVALID, "blk_off not monotone");
+    if (ns > 0 && in->seq_off[0] != 0) return fail(SXG_E_INVALID, "seq_off[0] must be 0");
+    for (int64_t s = 0; s < ns; ++s)
+        if (in->seq_off[s + 1] < in->seq_off[s]) return fail(SXG_E_INVALID, "seq_off not monotone");
+    const int64_t nbases = ns ? in->seq_off[ns] : 0;
+    if (nbases > 0 && !in->bases) return fail(SXG_E_INVALID, "bases is NULL");
+    const int np = in->per_block_params ? nb : 1;
+    for (int k = 0; k < np && nb > 0; ++k) {
+        const sxg_poa_params& p = in->params[k];
+        if (p.m < 0 || p.n > 0 || p.g > 0 || p.e > 0 || p.q > 0 || p.c > 0 || p.mode > 1)
+            return fail(SXG_E_INVALID, "scores must follow spoa's sign convention (m>=0, others <=0), mode 0|1");
+    }
+    h->n_blocks = nb; h->n_seqs = ns; h->n_bases = nbases;
+    h->want_consensus = in->want_consensus; h->want_msa = in->want_msa;
+    h->per_block_params = in->per_block_params;
+    h->h_blk_off.assign(in->blk_off, in->blk_off + nb + 1);
+    h->h_seq_off.assign(in->seq_off, in->seq_off + ns + 1);
+    h->h_params.assign(in->params, in->params + np);
+    h->meta.assign(nb, BlockMeta());
+    for (int b = 0; b < nb; ++b) {
+        BlockMeta& m = h->meta[b];
+        m.S = normalise(h->h_params[in->per_block_params ? b : 0]);
+        m.cvx = m.S.convex; m.sw = m.S.sw;
+        m.nseq = in->blk_off[b + 1] - in->blk_off[b];
+        double prev = 0;
+        for (int s = in->blk_off[b]; s < in->blk_off[b + 1]; ++s) {
+            const int64_t len = in->seq_off[s + 1] - in->seq_off[s];
+            m.maxlen = (int)std::max<int64_t>(m.maxlen, len);
+            m.sumlen += len;
+            // cost_b = sum_k L_k * (L_1 + 0.05 * sum_{j<k} L_j)
+            const double l1 = (double)(in->seq_off[in->blk_off[b] + 1] - in->seq_off[in->blk_off[b]]);
+            if (s > in->blk_off[b]) m.cost += (double)len * (l1 + 0.05 * prev);
+            prev += (double)len;
+        }
+        m.variant = variant_for_len(m.maxlen);
+    }
+    // sanitise letters while copying to a staging buffer
+    std::vector<uint8_t> stage((size_t)std::max<int64_t>(nbases, 1));
+    for (int64_t i = 0; i < nbases; ++i) stage[i] = in->bases[i] > 4 ? 4 : in->bases[i];
+    int rc;
+    if ((rc = h->d_blk_off.ensure(4 * (size_t)(nb + 1)))) return rc;
+    if ((rc = h->d_seq_off.ensure(8 * (size_t)(ns + 1)))) return rc;
+    if ((rc = h->d_bases.ensure((size_t)nbases + 16))) return rc;
+    if ((rc = h->d_params.ensure(sizeof(sxg_poa_params) * (size_t)std::max(np, 1)))) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_blk_off.p, in->blk_off, 4 * (size_t)(nb + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_seq_off.p, in->seq_off, 8 * (size_t)(ns + 1), hipMemcpyHostToDevice, h->stream));
+    if (nbases) HIPCHK(hipMemcpyAsync(h->d_bases.p, stage.data(), (size_t)nbases, hipMemcpyHostToDevice, h->stream));
+    if (nb) HIPCHK(hipMemcpyAsync(h->d_params.p, in->params, sizeof(sxg_poa_params) * (size_t)np, hipMemcpyHostToDevice, h->stream));
+    h->has_weights = in->weights != nullptr;
+    if (h->has_weights) {
+        if ((rc = h->d_weights.ensure(4 * (size_t)std::max<int64_t>(ns, 1)))) return rc;
+        if (ns) HIPCHK(hipMemcpyAsync(h->d_weights.p, in->weights, 4 * (size_t)ns, hipMemcpyHostToDevice, h->stream));
+    }
+    const size_t NB = (size_t)std::max<int64_t>(nbases, 1), NS = (size_t)std::max<int64_t>(ns, 1), NBL = (size_t)std::max(nb, 1);
+    if ((rc = h->d_status.ensure(4 * NBL)) || (rc = h->d_nn.ensure(4 * NBL)) || (rc = h->d_ne.ensure(4 * NBL)) ||
+        (rc = h->d_nc.ensure(4 * NBL)) || (rc = h->d_node_code.ensure(NB)) || (rc = h->d_node_rank.ensure(4 * NB)) ||
+        (rc = h->d_node_group.ensure(4 * NB)) || (rc = h->d_edge_tail.ensure(4 * NB)) ||
+        (rc = h->d_edge_head.ensure(4 * NB)) || (rc = h->d_edge_w.ensure(4 * NB)) || (rc = h->d_paths.ensure(4 * NB)) ||
+        (rc = h->d_score.ensure(4 * NS)) || (rc = h->d_cells.ensure(8 * NS)) || (rc = h->d_queue.ensure(256)) ||
+        (rc = h->d_work.ensure(4 * NBL)))
+        return rc;
+    if (h->want_consensus && (rc = h->d_cons.ensure(4 * NB))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_batch = true;
+    return SXG_OK;
+}
+
+struct LaunchPlan {
+    int variant; bool cvx, h16;
+    std::vector<int32_t> work;  // block ids, largest cost first
+};
+
+static int run_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt, float* ms_total) {
+    const Variant V = kVariants[P.variant];
+    const int Lpad = V.T * V.W;
+    int nodes_cap = 0, maxlen = 0;
+    for (int b : P.work) {
+        nodes_cap = (int)std::max<int64_t>(nodes_cap, h->meta[b].sumlen);
+        maxlen = std::max(maxlen, h->meta[b].maxlen);
+    }
+    nodes_cap += 8;
+    int rows_cap, pool_slots, tbx16_cap, tbx32_cap;
+    if (attempt == 0) {
+        rows_cap = std::min(nodes_cap, 2 * maxlen + 1024);
+        pool_slots = std::min(rows_cap + 1, 768);
+        tbx16_cap = rows_cap / 2 + 64;
+        tbx32_cap = 16;
+    } else if (attempt == 1) {
+        rows_cap = std::min(nodes_cap, 6 * maxlen + 4096);
+        pool_slots = std::min(rows_cap + 1, 8192);
+        tbx16_cap = rows_cap;
+        tbx32_cap = 256;
+    } else {
+        rows_cap = nodes_cap; pool_slots = rows_cap + 1; tbx16_cap = rows_cap; tbx32_cap = rows_cap;
+    }
+    if (rows_cap >= (1 << 20)) rows_cap = (1 << 20) - 1;
+    const SlotLayout lay = make_layout(nodes_cap, rows_cap, pool_slots, tbx16_cap, tbx32_cap, Lpad, P.h16 ? 4 : 8, false);
+    auto kern = block_kernel(P.variant, P.cvx, P.h16);
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, V.T, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const uint64_t budget = arena_budget(h);
+    int64_t n_slots = std::min<int64_t>((int64_t)P.work.size(), (int64_t)h->num_cu * per_cu);
+    n_slots = std::min<int64_t>(n_slots, (int64_t)(budget / lay.total));
+    if (n_slots < 1) return fail(SXG_E_NOMEM, "memory budget too small for a single block arena (" + std::to_string(lay.total) + " bytes)");
+    int rc;
+    if ((rc = h->d_arena.ensure((size_t)n_slots * lay.total))) return rc;
+    if ((rc = h->d_work.ensure(4 * P.work.size()))) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_work.p, P.work.data(), 4 * P.work.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_queue.p, 0, 4, h->stream));
+    BlockArgs A;
+    A.blk_off = h->d_blk_off.as<int32_t>(); A.seq_off = h->d_seq_off.as<int64_t>(); A.bases = h->d_bases.as<uint8_t>();
+    A.weights = h->has_weights ? h->d_weights.as<uint32_t>() : nullptr;
+    A.params = h->d_params.as<sxg_poa_params>(); A.per_block_params = h->per_block_params;
+    A.work = h->d_work.as<int32_t>(); A.n_work = (int)P.work.size(); A.queue = h->d_queue.as<int32_t>();
+    A.arena = h->d_arena.as<uint8_t>(); A.lay = lay;
+    A.status = h->d_status.as<int32_t>(); A.n_nodes = h->d_nn.as<int32_t>(); A.n_edges = h->d_ne.as<int32_t>();
+    A.n_cons = h->d_nc.as<int32_t>(); A.node_code = h->d_node_code.as<uint8_t>();
+    A.node_rank = h->d_node_rank.as<int32_t>(); A.node_group = h->d_node_group.as<int32_t>();
+    A.edge_tail = h->d_edge_tail.as<int32_t>(); A.edge_head = h->d_edge_head.as<int32_t>();
+    A.edge_weight = h->d_edge_w.as<uint32_t>(); A.paths = h->d_paths.as<int32_t>(); A.score = h->d_score.as<int32_t>();
+    A.cells = h->d_cells.as<unsigned long long>(); A.cons_nodes = h->d_cons.as<int32_t>();
+    A.want_consensus = h->want_consensus;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_slots), dim3(V.T), 0, h->stream, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_total += ms;
+    h->stats.dp_launches += 1;
+    h->stats.n_slots = std::max<int>(h->stats.n_slots, (int)n_slots);
+    h->stats.device_bytes = std::max<uint64_t>(h->stats.device_bytes, (uint64_t)n_slots * lay.total);
+    return SXG_OK;
+}
+
+extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
+    if (!h) return fail(SXG_E_INVALID, "handle is NULL");
+    if (!h->have_batch) return fail(SXG_E_INVALID, "no batch uploaded");
+    HIPCHK(hipSetDevice(h->device));
+    h->stats = sxg_poa_stats{};
+    const int nb = h->n_blocks;
+    std::vector<int32_t> status(std::max(nb, 1), 0);
+    float ms_total = 0;
+    // blocks whose longest sequence exceeds the largest variant fail up front
+    std::vector<int32_t> pending;
+    for (int b = 0; b < nb; ++b) {
+        if (h->meta[b].variant < 0) status[b] = ST_TOO_LONG; else pending.push_back(b);
+    }
+    if (nb) HIPCHK(hipMemcpyAsync(h->d_status.p, status.data(), 4 * (size_t)nb, hipMemcpyHostToDevice, h->stream));
+    if (nb) {
+        HIPCHK(hipMemsetAsync(h->d_nn.p, 0, 4 * (size_t)nb, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_ne.p, 0, 4 * (size_t)nb, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_nc.p, 0, 4 * (size_t)nb, h->stream));
+    }
+    for (int attempt = 0; attempt < 3 && !pending.empty(); ++attempt) {
+        // group by (variant, convex, h16)
+        std::vector<LaunchPlan> plans;
+        for (int b : pending) {
+            const BlockMeta& m = h->meta[b];
+            const int rows_max = (int)std::min<int64_t>(m.sumlen + 8, (1 << 20) - 1);
+            const bool h16 = h16_safe(m.S, m.maxlen, rows_max);
+            LaunchPlan* pl = nullptr;
+            for (auto& q : plans)
+                if (q.variant == m.variant && q.cvx == m.cvx && q.h16 == h16) { pl = &q; break; }
+            if (!pl) { plans.push_back(LaunchPlan{m.variant, m.cvx, h16, {}}); pl = &plans.back(); }
+            pl->work.push_back(b);
+        }
+        std::sort(plans.begin(), plans.end(), [](const LaunchPlan& a, const LaunchPlan& b) { return a.variant > b.variant; });
+        for (auto& pl : plans) {
+            std::stable_sort(pl.work.begin(), pl.work.end(),
+                             [&](int a, int b) { return h->meta[a].cost > h->meta[b].cost; });
+            int rc = run_plan(h, pl, attempt, &ms_total);
+            if (rc) return rc;
+        }
+        HIPCHK(hipMemcpy(status.data(), h->d_status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        std::vector<int32_t> again;
+        for (int b : pending)
+            if (status[b] == ST_ROWS_OVERFLOW || status[b] == ST_POOL_OVERFLOW || status[b] == ST_TBX_OVERFLOW) again.push_back(b);
+        if (attempt < 2) h->stats.retries += (int)again.size();
+        pending.swap(again);
+    }
+    // accounting
+    std::vector<unsigned long long> cells((size_t)std::max<int64_t>(h->n_seqs, 1));
+    if (h->n_seqs) HIPCHK(hipMemcpy(cells.data(), h->d_cells.p, 8 * (size_t)h->n_seqs, hipMemcpyDeviceToHost));
+    uint64_t total = 0, bytes = 0;
+    for (int b = 0; b < nb; ++b) {
+        if (status[b] != ST_OK) continue;
+        uint64_t cb = 0;
+        for (int s = h->h_blk_off[b]; s < h->h_blk_off[b + 1]; ++s) cb += cells[s];
+        const BlockMeta& m = h->meta[b];
+        const int ncross = m.S.convex ? 3 : (m.S.g == m.S.e ? 1 : 2);
+        const int rows_max = (int)std::min<int64_t>(m.sumlen + 8, (1 << 20) - 1);
+        const int sz = h16_safe(m.S, m.maxlen, rows_max) ? 2 : 4;
+        total += cb;
+        bytes += cb * (uint64_t)(2 * ncross * sz + 1);
+    }
+    h->stats.kernel_ms = ms_total;
+    h->stats.cells = total;
+    h->stats.algo_bytes = bytes;
+    h->executed = true;
+    for (int b = 0; b < nb; ++b)
+        if (status[b] != ST_OK) return fail(SXG_E_BLOCK, "block " + std::to_string(b) + " failed with status " + std::to_string(status[b]));
+    return SXG_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+struct OutOwner {
+    std::vector<int32_t> status, node_rank, node_group, edge_tail, edge_head, seq_path_nodes, score, cons_nodes, msa_cols;
+    std::vector<int64_t> node_off, edge_off, cons_off, msa_off;
+    std::vector<uint8_t> node_code;
+    std::vector<uint32_t> edge_weight;
+    std::vector<uint64_t> cells;
+    std::vector<char> msa;
+};
+
+template <class Tv>
+static int gather_download(sxg_poa_handle* h, const DevBuf& src, const std::vector<int64_t>& dst_off, DevBuf& d_srcoff,
+                           DevBuf& d_dstoff, DevBuf& d_dense, std::vector<Tv>& out) {
+    const int nb = h->n_blocks;
+    const int64_t total = dst_off[nb];
+    out.resize((size_t)std::max<int64_t>(total, 1));
+    if (total == 0) return SXG_OK;
+    int rc;
+    if ((rc = d_dense.ensure(sizeof(Tv) * (size_t)total))) return rc;
+    hipLaunchKernelGGL((gather_kernel<Tv>), dim3((unsigned)std::min(nb, 4096)), dim3(256), 0, h->stream, src.as<Tv>(),
+                       d_dense.as<Tv>(), d_srcoff.as<int64_t>(), d_dstoff.as<int64_t>(), nb);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out.data(), d_dense.p, sizeof(Tv) * (size_t)total, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SXG_OK;
+}
+
+extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out) {
+    if (!h || !out) return fail(SXG_E_INVALID, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    if (!h->have_batch || !h->executed) return fail(SXG_E_INVALID, "no executed batch to download");
+    HIPCHK(hipSetDevice(h->device));
+    const int nb = h->n_blocks;
+    const int64_t ns = h->n_seqs;
+    OutOwner* o = new OutOwner();
+    out->_owner = o;
+    out->n_blocks = nb; out->n_seqs = ns;
+    o->status.resize(std::max(nb, 1));
+    std::vector<int32_t> nn(std::max(nb, 1)), ne(std::max(nb, 1)), nc(std::max(nb, 1));
+    if (nb) {
+        HIPCHK(hipMemcpy(o->status.data(), h->d_status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nn.data(), h->d_nn.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ne.data(), h->d_ne.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nc.data(), h->d_nc.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+    }
+    o->node_off.assign(nb + 1, 0); o->edge_off.assign(nb + 1, 0); o->cons_off.assign(nb + 1, 0);
+    std::vector<int64_t> src_off(nb + 1, 0);
+    for (int b = 0; b < nb; ++b) {
+        o->node_off[b + 1] = o->node_off[b] + nn[b];
+        o->edge_off[b + 1] = o->edge_off[b] + ne[b];
+        o->cons_off[b + 1] = o->cons_off[b] + nc[b];
+        src_off[b] = h->h_seq_off[h->h_blk_off[b]];
+    }
+    int rc;
+    if ((rc = h->d_tmp_a.ensure(8 * (size_t)(nb + 1))) || (rc = h->d_tmp_b.ensure(8 * (size_t)(nb + 1)))) { sxg_poa_batch_free(out); return rc; }
+    HIPCHK(hipMemcpy(h->d_tmp_a.p, src_off.data(), 8 * (size_t)(nb + 1), hipMemcpyHostToDevice));
+    auto put_off = [&](const std::vector<int64_t>& off) -> int {
+        hipError_t e = hipMemcpy(h->d_tmp_b.p, off.data(), 8 * (size_t)(nb + 1), hipMemcpyHostToDevice);
+        return e == hipSuccess ? SXG_OK : fail(SXG_E_NODEVICE, hipGetErrorString(e));
+    };
+#define GD(T, src, off, dst)                                                                         \
+    if ((rc = put_off(off)) || (rc = gather_download<T>(h, src, off, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, dst))) { \
+        sxg_poa_batch_free(out);                                                                     \
+        return rc;                                                                                   \
+    }
+    GD(uint8_t, h->d_node_code, o->node_off, o->node_code)
+    GD(int32_t, h->d_node_rank, o->node_off, o->node_rank)
+    GD(int32_t, h->d_node_group, o->node_off, o->node_group)
+    GD(int32_t, h->d_edge_tail, o->edge_off, o->edge_tail)
+    GD(int32_t, h->d_edge_head, o->edge_off, o->edge_head)
+    GD(uint32_t, h->d_edge_w, o->edge_off, o->edge_weight)
+    if (h->want_consensus) { GD(int32_t, h->d_cons, o->cons_off, o->cons_nodes) }
+#undef GD
+    o->seq_path_nodes.resize((size_t)std::max<int64_t>(h->n_bases, 1));
+    o->score.resize((size_t)std::max<int64_t>(ns, 1));
+    o->cells.resize((size_t)std::max<int64_t>(ns, 1));
+    if (h->n_bases) HIPCHK(hipMemcpy(o->seq_path_nodes.data(), h->d_paths.p, 4 * (size_t)h->n_bases, hipMemcpyDeviceToHost));
+    if (ns) {
+        HIPCHK(hipMemcpy(o->score.data(), h->d_score.p, 4 * (size_t)ns, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(o->cells.data(), h->d_cells.p, 8 * (size_t)ns, hipMemcpyDeviceToHost));
+    }
+    out->status = o->status.data();
+    out->node_off = o->node_off.data(); out->node_code = o->node_code.data(); out->node_rank = o->node_rank.data();
+    out->node_group = o->node_group.data(); out->edge_off = o->edge_off.data(); out->edge_tail = o->edge_tail.data();
+    out->edge_head = o->edge_head.data(); out->edge_weight = o->edge_weight.data();
+    out->seq_path_nodes = o->seq_path_nodes.data(); out->score = o->score.data(); out->cells = o->cells.data();
+    if (h->want_consensus) { out->cons_off = o->cons_off.data(); out->cons_nodes = o->cons_nodes.data(); }
+    if (h->want_msa) {
+        // S8: MSA column = aligned group in rank order; pure formatting of device results
+        static const char dec[5] = {'A', 'C', 'G', 'T', 'N'};
+        o->msa_off.assign(nb + 1, 0); o->msa_cols.assign(std::max(nb, 1), 0);
+        std::vector<std::vector<int32_t>> cols(nb);
+        for (int b = 0; b < nb; ++b) {
+            const int64_t n0 = o->node_off[b];
+            const int n = nn[b];
+            std::vector<int32_t> by_rank(n);
+            for (int v = 0; v < n; ++v) by_rank[o->node_rank[n0 + v]] = v;
+            cols[b].assign(n, 0);
+            int ncol = 0;
+            for (int r = 0; r < n; ++r) {
+                const int v = by_rank[r];
+                if (r > 0 && o->node_group[n0 + by_rank[r - 1]] == o->node_group[n0 + v]) cols[b][v] = ncol - 1;
+                else cols[b][v] = ncol++;
+            }
+            o->msa_cols[b] = ncol;
+            const int rows = (h->h_blk_off[b + 1] - h->h_blk_off[b]) + (h->want_consensus ? 1 : 0);
+            o->msa_off[b + 1] = o->msa_off[b] + (o->status[b] == ST_OK ? (int64_t)rows * ncol : 0);
+        }
+        o->msa.assign((size_t)std::max<int64_t>(o->msa_off[nb], 1), '-');
+        for (int b = 0; b < nb; ++b) {
+            if (o->status[b] != ST_OK) continue;
+            const int64_t n0 = o->node_off[b];
+            const int ncol = o->msa_cols[b];
+            char* base = o->msa.data() + o->msa_off[b];
+            int row = 0;
+            for (int s = h->h_blk_off[b]; s < h->h_blk_off[b + 1]; ++s, ++row)
+                for (int64_t k = h->h_seq_off[s]; k < h->h_seq_off[s + 1]; ++k) {
+                    const int v = o->seq_path_nodes[k];
+                    base[(int64_t)row * ncol + cols[b][v]] = dec[o->node_code[n0 + v]];
+                }
+            if (h->want_consensus)
+                for (int64_t k = o->cons_off[b]; k < o->cons_off[b + 1]; ++k) {
+                    const int v = o->cons_nodes[k];
+                    base[(int64_t)row * ncol + cols[b][v]] = dec[o->node_code[n0 + v]];
+                }
+        }
+        out->msa_off = o->msa_off.data(); out->msa_cols = o->msa_cols.data(); out->msa = o->msa.data();
+    }
+    return SXG_OK;
+}
+
+extern "C" void sxg_poa_batch_free(sxg_poa_batch_out* out) {
+    if (!out) return;
+    delete (OutOwner*)out->_owner;
+    memset(out, 0, sizeof(*out));
+}
+
+extern "C" int sxg_poa_batch_run(sxg_poa_handle* h, const sxg_poa_batch_in* in, sxg_poa_batch_out* out) {
+    if (out) memset(out, 0, sizeof(*out));
+    int rc = sxg_poa_batch_upload(h, in);
+    if (rc) return rc;
+    rc = sxg_poa_batch_execute(h);
+    if (rc && rc != SXG_E_BLOCK) return rc;
+    const std::string keep = g_err;
+    int rc2 = sxg_poa_batch_download(h, out);
+    if (rc2) return rc2;
+    if (rc) g_err = keep;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+struct AlignOwner {
+    std::vector<int32_t> status, score, pair_row, pair_pos;
+    std::vector<int64_t> pair_off;
+};
+
+extern "C" void sxg_poa_align_free(sxg_poa_align_out* out) {
+    if (!out) return;
+    delete (AlignOwner*)out->_owner;
+    memset(out, 0, sizeof(*out));
+}
+
+extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in, sxg_poa_align_out* out) {
+    if (!h || !in || !out) return fail(SXG_E_INVALID, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    const int n = in->n;
+    if (n < 0 || (n > 0 && (!in->row_off || !in->pred_off || !in->seq_off || !in->params)))
+        return fail(SXG_E_INVALID, "align_in has NULL arrays");
+    HIPCHK(hipSetDevice(h->device));
+    h->have_batch = false; h->executed = false;
+    const int64_t rows = n ? in->row_off[n] : 0, nbases = n ? in->seq_off[n] : 0, ne = rows ? in->pred_off[rows] : 0;
+    // validate topology: every predecessor is an earlier row of the same problem
+    for (int p = 0; p < n; ++p) {
+        const int64_t r0 = in->row_off[p], r1 = in->row_off[p + 1];
+        if (r1 < r0 || in->seq_off[p + 1] < in->seq_off[p]) return fail(SXG_E_INVALID, "offsets not monotone");
+        if (r1 - r0 >= (1 << 20)) return fail(SXG_E_INVALID, "graph too large");
+        for (int64_t r = r0; r < r1; ++r)
+            for (int64_t k = in->pred_off[r]; k < in->pred_off[r + 1]; ++k)
+                if (in->preds[k] < 1 || in->preds[k] > r - r0) return fail(SXG_E_INVALID, "predecessor rows must precede their successor");
+    }
+    AlignOwner* o = new AlignOwner();
+    out->_owner = o; out->n = n;
+    o->status.assign(std::max(n, 1), 0); o->score.assign(std::max(n, 1), 0); o->pair_off.assign(n + 1, 0);
+    DevBuf d_row_off, d_code, d_sink, d_pred_off, d_preds, d_seq_off, d_bases, d_params, d_status, d_score, d_np, d_pr, d_pp, d_work,
+        d_queue, d_arena;
+    auto cleanup = [&]() {
+        DevBuf* bs[] = {&d_row_off, &d_code, &d_sink, &d_pred_off, &d_preds, &d_seq_off, &d_bases, &d_params, &d_status, &d_score,
+                        &d_np, &d_pr, &d_pp, &d_work, &d_queue, &d_arena};
+        for (DevBuf* b : bs) b->release();
+    };
+#define CK(x) do { int _rc = (x); if (_rc) { cleanup(); sxg_poa_align_free(out); return _rc; } } while (0)
+#define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cleanup(); sxg_poa_align_free(out); return fail(SXG_E_NODEVICE, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
+    const int np = in->per_problem_params ? n : 1;
+    std::vector<uint8_t> stage((size_t)std::max<int64_t>(nbases, 1));
+    for (int64_t i = 0; i < nbases; ++i) stage[i] = in->bases[i] > 4 ? 4 : in->bases[i];
+    std::vector<uint8_t> codes((size_t)std::max<int64_t>(rows, 1));
+    for (int64_t i = 0; i < rows; ++i) codes[i] = in->row_code[i] > 4 ? 4 : in->row_code[i];
+    const size_t outcap = (size_t)(rows + nbases + 1);
+    CK(d_row_off.ensure(8 * (size_t)(n + 1))); CK(d_code.ensure((size_t)rows + 16)); CK(d_sink.ensure((size_t)rows + 16));
+    CK(d_pred_off.ensure(8 * (size_t)(rows + 1))); CK(d_preds.ensure(4 * (size_t)(ne + 1))); CK(d_seq_off.ensure(8 * (size_t)(n + 1)));
+    CK(d_bases.ensure((size_t)nbases + 16)); CK(d_params.ensure(sizeof(sxg_poa_params) * (size_t)std::max(np, 1)));
+    CK(d_status.ensure(4 * (size_t)std::max(n, 1))); CK(d_score.ensure(4 * (size_t)std::max(n, 1))); CK(d_np.ensure(4 * (size_t)std::max(n, 1)));
+    CK(d_pr.ensure(4 * outcap)); CK(d_pp.ensure(4 * outcap)); CK(d_work.ensure(4 * (size_t)std::max(n, 1))); CK(d_queue.ensure(256));
+    if (n) {
+        HCK(hipMemcpy(d_row_off.p, in->row_off, 8 * (size_t)(n + 1), hipMemcpyHostToDevice));
+        HCK(hipMemcpy(d_seq_off.p, in->seq_off, 8 * (size_t)(n + 1), hipMemcpyHostToDevice));
+        HCK(hipMemcpy(d_pred_off.p, in->pred_off, 8 * (size_t)(rows + 1), hipMemcpyHostToDevice));
+        HCK(hipMemcpy(d_params.p, in->params, sizeof(sxg_poa_params) * (size_t)np, hipMemcpyHostToDevice));
+        if (rows) {
+            HCK(hipMemcpy(d_code.p, codes.data(), (size_t)rows, hipMemcpyHostToDevice));
+            HCK(hipMemcpy(d_sink.p, in->row_sink, (size_t)rows, hipMemcpyHostToDevice));
+        }
+        if (ne) HCK(hipMemcpy(d_preds.p, in->preds, 4 * (size_t)ne, hipMemcpyHostToDevice));
+        if (nbases) HCK(hipMemcpy(d_bases.p, stage.data(), (size_t)nbases, hipMemcpyHostToDevice));
+        HCK(hipMemset(d_status.p, 0, 4 * (size_t)n)); HCK(hipMemset(d_score.p, 0, 4 * (size_t)n)); HCK(hipMemset(d_np.p, 0, 4 * (size_t)n));
+    }
+    // plans
+    struct APlan { int variant; bool cvx, h16; std::vector<int32_t> work; int rows_cap = 0; };
+    std::vector<APlan> plans;
+    for (int p = 0; p < n; ++p) {
+        const Scoring S = normalise(in->params[in->per_problem_params ? p : 0]);
+        const int len = (int)(in->seq_off[p + 1] - in->seq_off[p]), N = (int)(in->row_off[p + 1] - in->row_off[p]);
+        const int v = variant_for_len(len);
+        if (v < 0) { o->status[p] = ST_TOO_LONG; continue; }
+        const bool h16 = h16_safe(S, len, N);
+        APlan* pl = nullptr;
+        for (auto& q : plans) if (q.variant == v && q.cvx == (bool)S.convex && q.h16 == h16) { pl = &q; break; }
+        if (!pl) { plans.push_back(APlan{v, (bool)S.convex, h16, {}, 0}); pl = &plans.back(); }
+        pl->work.push_back(p);
+        pl->rows_cap = std::max(pl->rows_cap, N);
+    }
+    if (n) HCK(hipMemcpy(d_status.p, o->status.data(), 4 * (size_t)n, hipMemcpyHostToDevice));
+    for (auto& pl : plans) {
+        const Variant V = kVariants[pl.variant];
+        const int rows_cap = pl.rows_cap + 1;
+        const SlotLayout lay = make_layout(8, rows_cap, rows_cap + 1, rows_cap, rows_cap, V.T * V.W, pl.h16 ? 4 : 8, true);
+        SlotLayout lay2 = lay;
+        // r_preds is sized by nodes_cap in make_layout; the align path needs the edge count instead
+        int64_t maxe = 0;
+        for (int p : pl.work) maxe = std::max<int64_t>(maxe, in->pred_off[in->row_off[p + 1]] - in->pred_off[in->row_off[p]]);
+        lay2 = make_layout((int)std::max<int64_t>(maxe + 8, rows_cap + 8), rows_cap, rows_cap + 1, rows_cap, rows_cap, V.T * V.W,
+                           pl.h16 ? 4 : 8, true);
+        auto kern = align_kernel(pl.variant, pl.cvx, pl.h16);
+        int per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, V.T, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        const uint64_t budget = arena_budget(h);
+        int64_t n_slots = std::min<int64_t>((int64_t)pl.work.size(), (int64_t)h->num_cu * per_cu);
+        n_slots = std::min<int64_t>(n_slots, (int64_t)(budget / lay2.total));
+        if (n_slots < 1) { cleanup(); sxg_poa_align_free(out); return fail(SXG_E_NOMEM, "memory budget too small for one alignment arena"); }
+        CK(d_arena.ensure((size_t)n_slots * lay2.total));
+        HCK(hipMemcpy(d_work.p, pl.work.data(), 4 * pl.work.size(), hipMemcpyHostToDevice));
+        HCK(hipMemset(d_queue.p, 0, 4));
+        AlignArgs A;
+        A.row_off = d_row_off.as<int64_t>(); A.row_code = d_code.as<uint8_t>(); A.row_sink = d_sink.as<uint8_t>();
+        A.pred_off = d_pred_off.as<int64_t>(); A.preds = d_preds.as<int32_t>(); A.seq_off = d_seq_off.as<int64_t>();
+        A.bases = d_bases.as<uint8_t>(); A.params = d_params.as<sxg_poa_params>(); A.per_problem_params = in->per_problem_params;
+        A.work = d_work.as<int32_t>(); A.n_work = (int)pl.work.size(); A.queue = d_queue.as<int32_t>();
+        A.arena = d_arena.as<uint8_t>(); A.lay = lay2;
+        A.status = d_status.as<int32_t>(); A.score = d_score.as<int32_t>(); A.n_pairs = d_np.as<int32_t>();
+        A.pair_row = d_pr.as<int32_t>(); A.pair_pos = d_pp.as<int32_t>();
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_slots), dim3(V.T), 0, h->stream, A);
+        HCK(hipGetLastError());
+        HCK(hipStreamSynchronize(h->stream));
+    }
+    std::vector<int32_t> npairs(std::max(n, 1), 0), pr(outcap), pp(outcap);
+    if (n) {
+        HCK(hipMemcpy(o->status.data(), d_status.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        HCK(hipMemcpy(o->score.data(), d_score.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        HCK(hipMemcpy(npairs.data(), d_np.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        HCK(hipMemcpy(pr.data(), d_pr.p, 4 * outcap, hipMemcpyDeviceToHost));
+        HCK(hipMemcpy(pp.data(), d_pp.p, 4 * outcap, hipMemcpyDeviceToHost));
+    }
+    for (int p = 0; p < n; ++p) o->pair_off[p + 1] = o->pair_off[p] + npairs[p];
+    o->pair_row.resize((size_t)std::max<int64_t>(o->pair_off[n], 1)); o->pair_pos.resize(o->pair_row.size());
+    for (int p = 0; p < n; ++p) {
+        const int64_t s0 = in->row_off[p] + in->seq_off[p];
+        std::copy(pr.begin() + s0, pr.begin() + s0 + npairs[p], o->pair_row.begin() + o->pair_off[p]);
+        std::copy(pp.begin() + s0, pp.begin() + s0 + npairs[p], o->pair_pos.begin() + o->pair_off[p]);
+    }
+    cleanup();
+#undef CK
+#undef HCK
+    out->status = o->status.data(); out->score = o->score.data(); out->pair_off = o->pair_off.data();
+    out->pair_row = o->pair_row.data(); out->pair_pos = o->pair_pos.data();
+    for (int p = 0; p < n; ++p)
+        if (o->status[p] != ST_OK) return fail(SXG_E_BLOCK, "problem " + std::to_string(p) + " failed with status " + std::to_string(o->status[p]));
+    return SXG_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// XXH64 (published xxHash specification); dedup key of src/smooth.cpp:716.
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+extern "C" uint64_t sxg_xxh64(const void* data, uint64_t len, uint64_t seed) {
+    const uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL,
+                   P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    auto rd64 = [](const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; };
+    auto rd32 = [](const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; };
+    auto round = [&](uint64_t acc, uint64_t in) { return rotl64(acc + in * P2, 31) * P1; };
+    auto merge = [&](uint64_t hh, uint64_t v) { return (hh ^ round(0, v)) * P1 + P4; };
+    const uint8_t *p = (const uint8_t*)data, *end = p + len;
+    uint64_t hh;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        const uint8_t* lim = end - 32;
+        do {
+            v1 = round(v1, rd64(p)); v2 = round(v2, rd64(p + 8)); v3 = round(v3, rd64(p + 16)); v4 = round(v4, rd64(p + 24));
+            p += 32;
+        } while (p <= lim);
+        hh = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        hh = merge(hh, v1); hh = merge(hh, v2); hh = merge(hh, v3); hh = merge(hh, v4);
+    } else hh = seed + P5;
+    hh += len;
+    while (p + 8 <= end) { hh ^= round(0, rd64(p)); hh = rotl64(hh, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { hh ^= (uint64_t)rd32(p) * P1; hh = rotl64(hh, 23) * P2 + P3; p += 4; }
+    while (p < end) { hh ^= (*p) * P5; hh = rotl64(hh, 11) * P1; ++p; }
+    hh ^= hh >> 33; hh *= P2; hh ^= hh >> 29; hh *= P3; hh ^= hh >> 32;
+    return hh;
+}

@@ -1,0 +1,78 @@
+// graph_emul.cpp -- TEST HARNESS ONLY.  Compiles the product's data-parallel graph code
+// (smoothxg_amd/csrc/poa_graph_dev.h) for the host with a one-thread execution context and
+// drives it with the oracle's DP, so the graph-update / rank / row-prep / consensus logic
+// can be checked against the oracle without a GPU.  Never part of the shipped library.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../smoothxg_amd/csrc/poa_graph_dev.h"
+#include "../../oracle/poa_oracle.h"
+
+using namespace sxg;
+
+struct SerialCtx {
+    int tid() const { return 0; }
+    int nthreads() const { return 1; }
+    void sync() {}
+    int scan_excl_add(int v, int* total) { *total = v; return 0; }
+    int scan_incl_max(int v) { return v; }
+    int reduce_max(int v) { return v; }
+    int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
+};
+
+extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int n_seqs,
+                              const uint32_t* weights, const poa_params_t* p, int pool_slots,
+                              int32_t* out_counts /* n_nodes, n_edges, n_cons */, uint8_t* code,
+                              int32_t* rank, int32_t* leader, int32_t* e_tail, int32_t* e_head,
+                              uint32_t* e_w, int32_t* paths, int32_t* scores, int32_t* cons) {
+    int64_t cap = 1, maxlen = 1;
+    for (int s = 0; s < n_seqs; ++s) {
+        cap += seq_off[s + 1] - seq_off[s];
+        if (seq_off[s + 1] - seq_off[s] > maxlen) maxlen = seq_off[s + 1] - seq_off[s];
+    }
+    const size_t C = (size_t)cap + 2;
+    std::vector<int32_t> hdr(2, 0), rk(C), ord(C), ordt(C), ld(C), gm(5 * C), ih(C), it(C), oh(C), ot(C),
+        id(C), od(C), et(C), eh(C), eni(C), eno(C), posn(C), tgt(C), nidx(C), nxa(C), pva(C), sla(C);
+    std::vector<uint32_t> ew(C);
+    std::vector<uint8_t> cd(C);
+    std::vector<int8_t> kd(C);
+    GraphView G{&hdr[0], &hdr[1], cd.data(), rk.data(), ord.data(), ordt.data(), ld.data(), gm.data(),
+                ih.data(), it.data(), oh.data(), ot.data(), id.data(), od.data(), et.data(), eh.data(),
+                eni.data(), eno.data(), ew.data(), posn.data(), tgt.data(), nidx.data(), nxa.data(),
+                pva.data(), sla.data(), kd.data()};
+    std::vector<uint8_t> rcode(C), rflags(C), sink(C);
+    std::vector<int32_t> poff(C + 1), preds(C), slot(C), tbx(C), sseq(C + 1), rnode(C);
+    RowsView R{rcode.data(), rflags.data(), poff.data(), preds.data(), slot.data(), tbx.data(), sseq.data(),
+               rnode.data()};
+    RowCaps caps{(int)C, pool_slots, (int)C, (int)C};
+    SerialCtx c;
+    std::vector<int32_t> an(2 * C), ap(2 * C);
+    for (int s = 0; s < n_seqs; ++s) {
+        const uint8_t* seq = bases + seq_off[s];
+        const int len = seq_off[s + 1] - seq_off[s];
+        for (int i = 0; i < len; ++i) posn[i] = -1;
+        int32_t sc = 0;
+        if (hdr[0] > 0 && len > 0) {
+            int st = prep_rows(c, G, R, caps);
+            if (st != ST_OK) return st;
+            for (int r = 0; r < hdr[0]; ++r) sink[r] = (rflags[r] & ROW_SINK) ? 1 : 0;
+            int n = poa_align_csr(hdr[0], rcode.data(), poff.data(), preds.data(), sink.data(), seq, len, p,
+                                  an.data(), ap.data(), &sc);
+            for (int k = 0; k < n; ++k)
+                if (an[k] >= 0 && ap[k] >= 0) posn[ap[k]] = rnode[an[k]];
+        }
+        if (scores) scores[s] = sc;
+        add_alignment(c, G, seq, len, weights ? weights[s] : 1u, paths + seq_off[s]);
+    }
+    std::vector<int64_t> csc(C);
+    std::vector<int32_t> cpr(C);
+    out_counts[0] = hdr[0]; out_counts[1] = hdr[1];
+    out_counts[2] = consensus_serial(G, csc.data(), cpr.data(), cons);
+    memcpy(code, cd.data(), hdr[0]);
+    memcpy(rank, rk.data(), 4 * (size_t)hdr[0]);
+    memcpy(leader, ld.data(), 4 * (size_t)hdr[0]);
+    memcpy(e_tail, et.data(), 4 * (size_t)hdr[1]);
+    memcpy(e_head, eh.data(), 4 * (size_t)hdr[1]);
+    memcpy(e_w, ew.data(), 4 * (size_t)hdr[1]);
+    return 0;
+}

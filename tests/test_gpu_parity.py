@@ -1,0 +1,110 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import PARAM_SETS, assert_block_equal, gparams, oparams, random_block
+from smoothxg_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_graph_after(oracle, seqs, k, p):
+    g, _, _ = oracle.block_run(seqs[:k], None, p)
+    return g
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+def test_align_only_matches_oracle(engine, oracle, mode, pname):
+    """sxg_poa_align_batch == oracle Align on graphs of growing depth (A6)."""
+    rng = np.random.default_rng(7 + mode)
+    problems, expect = [], []
+    for trial in range(12):
+        S = int(rng.integers(2, 9))
+        L = int(rng.integers(8, 300))
+        seqs = random_block(rng, S, L, div=0.08)
+        p = oparams(pname, mode)
+        g = _oracle_graph_after(oracle, seqs, S - 1, p)
+        codes, off, pred, sink, row_node = g.rows()
+        q = seqs[-1]
+        an, ap, sc = oracle.align_csr(codes, off, pred, sink, q, p)
+        problems.append((codes, off, pred, sink, q))
+        expect.append((an, ap, sc))
+    got = engine.align(problems, gparams(pname, mode))
+    for k, ((pr, pp, sc, st), (an, ap, esc)) in enumerate(zip(got, expect)):
+        assert st == 0
+        assert sc == esc, f"problem {k}: score {sc} != {esc}"
+        assert len(pr) == len(an), f"problem {k}: {len(pr)} pairs != {len(an)}"
+        assert (pr == an).all() and (pp == ap).all(), f"problem {k}: alignment differs"
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+def test_blocks_match_oracle_small(engine, oracle, mode, pname):
+    """sxg_poa_batch_run == oracle for whole blocks (A6+A7), many shapes in one batch."""
+    rng = np.random.default_rng(100 + mode)
+    blocks, weights = [], []
+    for trial in range(24):
+        S = int(rng.integers(1, 14))
+        L = int(rng.integers(1, 260))
+        if trial % 5 == 0:
+            seqs = [rng.integers(0, 5, int(rng.integers(1, 40)), dtype=np.uint8) for _ in range(S)]
+        else:
+            seqs = random_block(rng, S, L, div=0.06, alphabet=5 if trial % 7 == 0 else 4)
+        blocks.append(seqs)
+        weights.append(rng.integers(1, 5, len(seqs)).astype(np.uint32))
+    res = engine.run_blocks(blocks, gparams(pname, mode), weights=weights, want_consensus=True, want_msa=True)
+    for b, (seqs, w) in enumerate(zip(blocks, weights)):
+        g, sc, cells = oracle.block_run(seqs, w, oparams(pname, mode))
+        assert_block_equal(res[b], g, sc, cells, label=f"{pname}/mode{mode}/block{b}")
+        assert (res[b].consensus == g.consensus()).all(), f"block {b}: consensus differs"
+        assert res[b].msa == g.msa(True), f"block {b}: MSA differs"
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_config2_shape_blocks(engine, oracle, mode):
+    """BASELINE config 2 shape (16 seqs x 1 kbp), synthetic generator, default convex scores."""
+    bases, seq_off, blk_off = synth.make_batch(6, 16, 1000)
+    res = engine.run_flat(bases, seq_off, blk_off, None, gparams("convex_default", mode))
+    for b in range(6):
+        seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[b], blk_off[b + 1])]
+        g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", mode))
+        assert_block_equal(res[b], g, sc, cells, label=f"c2/mode{mode}/block{b}")
+
+
+def test_mixed_lengths_pick_every_variant(engine, oracle):
+    """Blocks of very different lengths in one batch exercise several (T,W) kernel variants."""
+    rng = np.random.default_rng(5)
+    blocks = []
+    for L in (40, 500, 900, 1900, 2900, 4000, 5000, 6000):
+        blocks.append(random_block(rng, 3, L, div=0.03))
+    res = engine.run_blocks(blocks, gparams("convex_default", 0))
+    for b, seqs in enumerate(blocks):
+        g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
+        assert_block_equal(res[b], g, sc, cells, label=f"len{len(seqs[0])}")
+
+
+def test_edge_cases(engine, oracle):
+    """Empty batch, empty block, single-sequence block, length-1 sequences, duplicates."""
+    assert engine.run_blocks([], gparams("convex_default", 0)) == []
+    one = np.array([2], np.uint8)
+    blocks = [[], [one], [one, one.copy()], [np.array([0, 1, 2, 3, 4], np.uint8)] * 3,
+              [np.zeros(50, np.uint8), np.ones(50, np.uint8)]]
+    res = engine.run_blocks(blocks, gparams("convex_default", 0))
+    assert res[0].status == 0 and len(res[0].node_code) == 0
+    for b in range(1, len(blocks)):
+        g, sc, cells = oracle.block_run(blocks[b], None, oparams("convex_default", 0))
+        assert_block_equal(res[b], g, sc, cells, label=f"edge{b}")
+
+
+def test_too_long_is_reported_not_crashed(engine):
+    import smoothxg_amd as S
+    blk = [[np.zeros(30000, np.uint8), np.zeros(10, np.uint8)]]
+    res = engine.run_blocks(blk, gparams("convex_default", 0), check=False)
+    assert res[0].status == 5
+
+
+def test_invalid_arguments(engine):
+    import smoothxg_amd as S
+    with pytest.raises(S.PoaError):
+        engine.run_blocks([[np.zeros(4, np.uint8)]], S.Params(1, 4, -6, -2, -26, -1, 0, 0))  # n > 0

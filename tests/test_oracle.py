@@ -1,0 +1,208 @@
+"""CPU tests of the oracle itself (no GPU): the parts that CAN be pinned are pinned.
+
+The reference holds no golden vector for this path (parity unpinned), so
+  - XXH64 is pinned against the python `xxhash` wheel and the published empty-input vector;
+  - the DP is pinned against an independent textbook pairwise implementation (numpy) on
+    single-sequence graphs, and against an independent brute-force DAG DP written here;
+  - every alignment is re-scored independently of the DP (poa_rescore);
+  - graph invariants the reference itself relies on (src/main.cpp:770-810: every path spells
+    its sequence) are asserted;
+  - self-generated golden fixtures (tests/golden, labelled self-oracle) guard regressions.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import PARAM_SETS, oparams, random_block
+from smoothxg_amd import synth
+
+NEG = -(1 << 29)
+
+
+def test_xxh64_pinned(oracle):
+    import xxhash
+    assert oracle.xxh64(b"") == 0xEF46DB3751D8E999  # published vector
+    rng = np.random.default_rng(0)
+    for n in list(range(0, 70)) + [255, 256, 1000, 4097]:
+        d = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert oracle.xxh64(d) == xxhash.xxh64(d).intdigest()
+        assert oracle.xxh64(d, 12345) == xxhash.xxh64(d, seed=12345).intdigest()
+
+
+def _norm(p):
+    m, n, g, e, q, c = p
+    if g >= e:
+        e = q = c = g
+    elif g <= q or e >= c:
+        q, c = g, e
+    return m, n, g, e, q, c
+
+
+def _dag_dp_score(codes, off, pred, sink, seq, p, sw):
+    """Independent plain-python two-piece-affine DP over a DAG in rank order (score only)."""
+    m, n, g, e, q, c = _norm(p)
+    N, L = len(codes), len(seq)
+    H = np.full((N + 1, L + 1), NEG, np.int64)
+    F = np.full((N + 1, L + 1), NEG, np.int64)
+    Oo = np.full((N + 1, L + 1), NEG, np.int64)
+    H[0, 0] = 0
+    for j in range(1, L + 1):
+        H[0, j] = 0 if sw else max(g + (j - 1) * e, q + (j - 1) * c)
+    best = 0 if sw else None
+    for i in range(1, N + 1):
+        ps = list(pred[off[i - 1]:off[i]]) or [0]
+        E = Q = NEG
+        for j in range(0, L + 1):
+            f = max(max(H[x, j] + g, F[x, j] + e) for x in ps)
+            o = max(max(H[x, j] + q, Oo[x, j] + c) for x in ps)
+            h = max(f, o)
+            if j > 0:
+                d = max(H[x, j - 1] for x in ps) + (m if codes[i - 1] == seq[j - 1] else n)
+                E = max(H[i, j - 1] + g, E + e)
+                Q = max(H[i, j - 1] + q, Q + c)
+                h = max(h, d, E, Q)
+            if sw:
+                h = max(h, 0)
+                best = max(best, h)
+            H[i, j], F[i, j], Oo[i, j] = h, f, o
+        if not sw and sink[i - 1]:
+            best = H[i, L] if best is None else max(best, H[i, L])
+    return int(best)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+def test_dp_score_matches_independent_dag_dp(oracle, mode, pname):
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        seqs = random_block(rng, int(rng.integers(2, 7)), int(rng.integers(5, 40)), div=0.15)
+        p = oparams(pname, mode)
+        g, _, _ = oracle.block_run(seqs[:-1], None, p)
+        codes, off, pred, sink, _ = g.rows()
+        an, ap, sc = oracle.align_csr(codes, off, pred, sink, seqs[-1], p)
+        assert sc == _dag_dp_score(codes, off, pred, sink, seqs[-1], PARAM_SETS[pname], mode == 0)
+
+
+def _pairwise_gotoh(a, b, p, sw):
+    """Textbook pairwise two-piece affine alignment score, vectorised per row (numpy)."""
+    m, n, g, e, q, c = _norm(p)
+    L = len(b)
+    Hp = np.zeros(L + 1, np.int64)
+    if not sw:
+        j = np.arange(1, L + 1)
+        Hp[1:] = np.maximum(g + (j - 1) * e, q + (j - 1) * c)
+    Fp = np.full(L + 1, NEG, np.int64)
+    Op = np.full(L + 1, NEG, np.int64)
+    best = 0
+    for i in range(1, len(a) + 1):
+        F = np.maximum(Hp + g, Fp + e)
+        Oo = np.maximum(Hp + q, Op + c)
+        H = np.maximum(F, Oo)
+        sub = np.where(np.asarray(b) == a[i - 1], m, n)
+        D = Hp[:-1] + sub
+        E = Q = NEG
+        for j in range(1, L + 1):
+            E = max(H[j - 1] + g, E + e)
+            Q = max(H[j - 1] + q, Q + c)
+            H[j] = max(H[j], D[j - 1], E, Q)
+            if sw:
+                H[j] = max(H[j], 0)
+        if sw:
+            H[0] = max(H[0], 0)
+            best = max(best, int(H.max()))
+        Hp, Fp, Op = H, F, Oo
+    return best if sw else int(Hp[L])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("pname", ["convex_default", "affine_4param", "linear"])
+def test_single_sequence_graph_equals_pairwise(oracle, mode, pname):
+    rng = np.random.default_rng(11)
+    for trial in range(8):
+        a = rng.integers(0, 4, int(rng.integers(1, 60)), dtype=np.uint8)
+        b = a.copy()
+        for _ in range(int(rng.integers(0, 6))):
+            k = int(rng.integers(0, len(b)))
+            b = np.delete(b, k) if rng.random() < 0.5 and len(b) > 1 else np.insert(b, k, rng.integers(0, 4))
+        p = oparams(pname, mode)
+        g = oracle.Graph()
+        g.add_alignment([], [], a)
+        an, ap, sc, cells = g.align(b, p)
+        assert cells == len(a) * len(b)
+        assert sc == _pairwise_gotoh(a, b, PARAM_SETS[pname], mode == 0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+def test_alignment_rescores_to_dp_score_and_graph_invariants(oracle, mode, pname):
+    rng = np.random.default_rng(21)
+    p = oparams(pname, mode)
+    for trial in range(10):
+        seqs = random_block(rng, int(rng.integers(2, 12)), int(rng.integers(3, 200)), div=0.08, alphabet=5)
+        g = oracle.Graph()
+        for k, s in enumerate(seqs):
+            an, ap, sc, cells = g.align(s, p)
+            if len(an):
+                assert g.rescore(s, p, an, ap) == sc, f"trial {trial} seq {k}"
+            else:
+                assert sc == 0
+            g.add_alignment(an, ap, s, weight=1 + k % 3)
+        code, rank, grp = g.nodes()
+        t, h, w = g.edges()
+        # the reference's own self-check (src/main.cpp:770-803): paths spell their sequences
+        for k, s in enumerate(seqs):
+            assert (code[g.seq_path(k)] == s).all()
+        assert (rank[t] < rank[h]).all(), "topological order violated"
+        assert sorted(rank) == list(range(len(rank)))
+        # aligned groups are contiguous in rank and hold distinct letters
+        order = np.argsort(rank)
+        gs = grp[order]
+        changes = 1 + int((gs[1:] != gs[:-1]).sum()) if len(gs) else 0
+        assert changes == len(set(grp.tolist()))
+        for leader in set(grp.tolist()):
+            letters = code[grp == leader]
+            assert len(set(letters.tolist())) == len(letters)
+        # every base contributes 2*w to each path edge (S6)
+        tot = sum(2 * (1 + k % 3) * (len(s) - 1) for k, s in enumerate(seqs))
+        assert int(w.sum()) == tot
+        # MSA rows spell the sequences once gaps are removed; consensus is a path
+        msa = g.msa(True)
+        for k, s in enumerate(seqs):
+            assert msa[k].replace("-", "") == synth.decode(s)
+        cons = g.consensus()
+        edges = set(zip(t.tolist(), h.tolist()))
+        assert all((a, b) in edges for a, b in zip(cons[:-1], cons[1:]))
+
+
+def test_gap_model_selection(oracle):
+    """S1: linear == affine with e=g; 4-parameter form (q=g,c=e) == plain affine."""
+    rng = np.random.default_rng(2)
+    seqs = random_block(rng, 5, 60, div=0.1)
+    for mode in (0, 1):
+        a, sa, _ = oracle.block_run(seqs, None, oracle.mkparams(1, -4, -6, -2, -6, -2, mode))
+        b, sb, _ = oracle.block_run(seqs, None, oracle.mkparams(1, -4, -6, -2, -8, -2, mode))  # g<=q? no: q<g and e>=c -> affine
+        assert (sa == sb).all() and a.n_nodes == b.n_nodes
+        c, sc_, _ = oracle.block_run(seqs, None, oracle.mkparams(2, -3, -5, -5, -9, -1, mode))  # g>=e -> linear
+        d, sd, _ = oracle.block_run(seqs, None, oracle.mkparams(2, -3, -5, -5, -5, -5, mode))
+        assert (sc_ == sd).all() and c.n_nodes == d.n_nodes
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "self_oracle_blocks.json")
+
+
+def test_golden_self_oracle_fixtures(oracle):
+    """Regression fixtures generated by tests/golden/make_golden.py FROM THIS ORACLE
+    (self-oracle, not reference-derived: the reference has no vectors for this path)."""
+    with open(GOLD) as f:
+        gold = json.load(f)
+    assert gold["provenance"].startswith("self-oracle")
+    for case in gold["cases"]:
+        seqs = [synth.encode(s) for s in case["seqs"]]
+        p = oracle.mkparams(*case["params"], mode=case["mode"])
+        g, sc, cells = oracle.block_run(seqs, case["weights"], p)
+        assert sc.tolist() == case["scores"]
+        assert g.n_nodes == case["n_nodes"] and g.n_edges == case["n_edges"]
+        assert synth.decode(g.nodes()[0][g.consensus()]) == case["consensus"]
+        assert g.msa(True) == case["msa"]
