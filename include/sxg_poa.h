@@ -162,6 +162,23 @@ int sxg_poa_batch_execute(sxg_poa_handle *h);
 int sxg_poa_batch_download(sxg_poa_handle *h, sxg_poa_batch_out *out);
 void sxg_poa_batch_free(sxg_poa_batch_out *out);
 
+/* Zero-copy view of the executed batch's results in HBM (valid until the next upload on this
+ * handle): what a caller hands to RCCL to reassemble the per-block graphs across GPUs before
+ * lacing (src/main.cpp:599+) without a host round trip.  Node/edge arrays use the worst-case
+ * layout: block b's entries start at index seq_off[blk_off[b]].                              */
+typedef struct sxg_poa_device_view {
+    int32_t n_blocks;
+    int64_t n_seqs, n_bases;
+    const int32_t *status, *n_nodes, *n_edges;           /* [n_blocks] */
+    const uint8_t *node_code;                            /* [n_bases] worst-case layout */
+    const int32_t *node_rank, *node_group;               /* [n_bases] */
+    const int32_t *edge_tail, *edge_head;                /* [n_bases] */
+    const uint32_t *edge_weight;                         /* [n_bases] */
+    const int32_t *seq_path_nodes;                       /* [n_bases] dense */
+    const int32_t *score;                                /* [n_seqs] */
+} sxg_poa_device_view;
+int sxg_poa_batch_device_view(sxg_poa_handle *h, sxg_poa_device_view *out);
+
 int sxg_poa_align_batch(sxg_poa_handle *h, const sxg_poa_align_in *in, sxg_poa_align_out *out);
 void sxg_poa_align_free(sxg_poa_align_out *out);
 

@@ -176,6 +176,7 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
     norm_params_t P = normalise(pp);
     if (score) *score = 0;
     if (N == 0 || L == 0) return 0;
+    for (int i = 1; i <= N; ++i) if (off[i] - off[i - 1] > 65535) { fprintf(stderr, "poa_oracle: in-degree > 65535\n"); abort(); }
     const size_t W = (size_t)L + 1;
     /* rows of H,F,O kept until their last reader is done */
     int32_t **Hm = (int32_t **)calloc((size_t)N + 1, sizeof(int32_t *));
@@ -195,7 +196,7 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
     int32_t *mp_index = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
     size_t n_mp = 0;
     for (int i = 1; i <= N; ++i) mp_index[i] = (off[i] - off[i - 1] > 1) ? (int32_t)n_mp++ : -1;
-    int32_t *tbx = (int32_t *)malloc(sizeof(int32_t) * 3 * (n_mp ? n_mp : 1) * W);
+    uint16_t *tbx = (uint16_t *)malloc(sizeof(uint16_t) * 3 * (n_mp ? n_mp : 1) * W); /* ordinals < 65536 */
 
     /* row 0 */
     Hm[0] = (int32_t *)malloc(sizeof(int32_t) * 3 * W);
@@ -219,7 +220,7 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
         int32_t *H = (int32_t *)malloc(sizeof(int32_t) * 3 * W), *F = H + W, *O = F + W;
         Hm[i] = H;
         uint8_t *t = tb + (size_t)i * W;
-        int32_t *tx = mp_index[i] >= 0 ? tbx + 3 * (size_t)mp_index[i] * W : NULL;
+        uint16_t *tx = mp_index[i] >= 0 ? tbx + 3 * (size_t)mp_index[i] * W : NULL;
         const int code = codes[i - 1];
         int E = NEG, Q = NEG;
         for (int j = 0; j <= L; ++j) {
@@ -251,7 +252,7 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
             H[j] = h; F[j] = f; O[j] = o;
             t[j] = (uint8_t)(src | (fx ? TB_FEXT : 0) | (ox ? TB_OEXT : 0) | (ex ? TB_EEXT : 0) |
                              (qx ? TB_QEXT : 0));
-            if (tx) { tx[3 * (size_t)j] = dd; tx[3 * (size_t)j + 1] = fo; tx[3 * (size_t)j + 2] = oo; }
+            if (tx) { tx[3 * (size_t)j] = (uint16_t)dd; tx[3 * (size_t)j + 1] = (uint16_t)fo; tx[3 * (size_t)j + 2] = (uint16_t)oo; }
             if (P.sw && h > best) { best = h; best_i = i; best_j = j; }
         }
         if (!P.sw && sink[i - 1] && (best_i < 0 || H[L] > best)) { best = H[L]; best_i = i; best_j = L; }
@@ -272,7 +273,7 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
                 continue;
             }
             const uint8_t t = tb[(size_t)i * W + j];
-            const int32_t *tx = mp_index[i] >= 0 ? tbx + 3 * ((size_t)mp_index[i] * W + j) : NULL;
+            const uint16_t *tx = mp_index[i] >= 0 ? tbx + 3 * ((size_t)mp_index[i] * W + j) : NULL;
             const int32_t *pl = pred + off[i - 1];
             const int has = off[i] - off[i - 1];
             if (st == SRC_STOP) {

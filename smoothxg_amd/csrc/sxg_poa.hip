@@ -824,6 +824,19 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
     return SXG_OK;
 }
 
+extern "C" int sxg_poa_batch_device_view(sxg_poa_handle* h, sxg_poa_device_view* v) {
+    if (!h || !v) return fail(SXG_E_INVALID, "NULL argument");
+    memset(v, 0, sizeof(*v));
+    if (!h->have_batch || !h->executed) return fail(SXG_E_INVALID, "no executed batch");
+    v->n_blocks = h->n_blocks; v->n_seqs = h->n_seqs; v->n_bases = h->n_bases;
+    v->status = h->d_status.as<int32_t>(); v->n_nodes = h->d_nn.as<int32_t>(); v->n_edges = h->d_ne.as<int32_t>();
+    v->node_code = h->d_node_code.as<uint8_t>(); v->node_rank = h->d_node_rank.as<int32_t>();
+    v->node_group = h->d_node_group.as<int32_t>(); v->edge_tail = h->d_edge_tail.as<int32_t>();
+    v->edge_head = h->d_edge_head.as<int32_t>(); v->edge_weight = h->d_edge_w.as<uint32_t>();
+    v->seq_path_nodes = h->d_paths.as<int32_t>(); v->score = h->d_score.as<int32_t>();
+    return SXG_OK;
+}
+
 extern "C" void sxg_poa_batch_free(sxg_poa_batch_out* out) {
     if (!out) return;
     delete (OutOwner*)out->_owner;

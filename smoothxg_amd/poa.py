@@ -63,7 +63,15 @@ class Stats(C.Structure):
                 ("device_bytes", C.c_uint64)]
 
 
-EXPORTS = ["sxg_poa_abi_version", "sxg_poa_device_count", "sxg_poa_last_error", "sxg_poa_create",
+class DeviceView(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("n_seqs", C.c_int64), ("n_bases", C.c_int64),
+                ("status", C.c_void_p), ("n_nodes", C.c_void_p), ("n_edges", C.c_void_p),
+                ("node_code", C.c_void_p), ("node_rank", C.c_void_p), ("node_group", C.c_void_p),
+                ("edge_tail", C.c_void_p), ("edge_head", C.c_void_p), ("edge_weight", C.c_void_p),
+                ("seq_path_nodes", C.c_void_p), ("score", C.c_void_p)]
+
+
+EXPORTS = ["sxg_poa_batch_device_view", "sxg_poa_abi_version", "sxg_poa_device_count", "sxg_poa_last_error", "sxg_poa_create",
            "sxg_poa_destroy", "sxg_poa_batch_run", "sxg_poa_batch_upload", "sxg_poa_batch_execute",
            "sxg_poa_batch_download", "sxg_poa_batch_free", "sxg_poa_align_batch", "sxg_poa_align_free",
            "sxg_poa_get_stats", "sxg_poa_set_memory_budget", "sxg_xxh64"]
@@ -91,6 +99,7 @@ def load_library(build_if_missing=True):
     L.sxg_poa_batch_execute.argtypes = [vp]
     L.sxg_poa_batch_download.argtypes = [vp, C.POINTER(BatchOut)]
     L.sxg_poa_batch_free.argtypes = [C.POINTER(BatchOut)]
+    L.sxg_poa_batch_device_view.argtypes = [vp, C.POINTER(DeviceView)]
     L.sxg_poa_align_batch.argtypes = [vp, C.POINTER(AlignIn), C.POINTER(AlignOut)]
     L.sxg_poa_align_free.argtypes = [C.POINTER(AlignOut)]
     L.sxg_poa_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -189,6 +198,13 @@ class PoaEngine:
         s = Stats()
         self.lib.sxg_poa_get_stats(self.h, C.byref(s))
         return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def device_view(self):
+        """Raw HBM pointers of the executed batch's results (see sxg_poa_device_view)."""
+        v = DeviceView()
+        if self.lib.sxg_poa_batch_device_view(self.h, C.byref(v)):
+            raise self._err("sxg_poa_batch_device_view")
+        return v
 
     def download(self):
         out = BatchOut()
