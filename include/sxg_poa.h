@@ -51,7 +51,7 @@ extern "C" {
 #define SXG_ST_NODES_OVERFLOW 4
 #define SXG_ST_TOO_LONG 5 /* a sequence exceeds SXG_POA_MAX_SEQ_LEN */
 
-#define SXG_POA_MAX_SEQ_LEN 24575
+#define SXG_POA_MAX_SEQ_LEN 16383
 
 /* The six scores + alignment type that smooth_spoa hands to
  * spoa::AlignmentEngine::Create (src/smooth.cpp:752-755).                                */
@@ -143,7 +143,11 @@ typedef struct sxg_poa_stats {
     uint64_t algo_bytes;  /* algorithmic bytes (2*n_cross*sizeof(score)+1 per cell) */
     int32_t n_slots;      /* resident workgroups used */
     int32_t retries;      /* blocks re-run with a larger arena */
-    uint64_t device_bytes;/* device memory held by the handle */
+    uint64_t device_bytes;/* device memory of the block arenas */
+    /* the dominant launch (most cells) of the last execute: what bench.py's roofline quotes */
+    double dom_kernel_ms;
+    uint64_t dom_cells, dom_algo_bytes;
+    int32_t dom_threads, dom_cols_per_lane; /* kernel variant <T, W> */
 } sxg_poa_stats;
 
 int sxg_poa_abi_version(void);

@@ -106,10 +106,12 @@ template <> struct RowWord<false> {
 
 struct DpBuffers {
     uint8_t* tb;       // [(rows_cap+1) * Lpad] traceback bytes, row-major, row 0 unused
-    uint16_t* tbx16;   // [tbx16_cap * Lpad] ordinals d|f<<5|o<<10 for rows with 2..32 preds
-    uint32_t* tbx32;   // [tbx32_cap * Lpad] ordinals d|f<<10|o<<20 for rows with >32 preds
+    uint32_t* steps;   // [step_cap * 3 * T] fold-step masks of multi-pred rows: for step s (=
+                       //   "predecessor #x folded in") and lane t, words {D,F,O}[t] hold one bit per
+                       //   column of the lane's strip: 1 = predecessor #x took over that state
     void* pool;        // [pool_slots * Lpad] packed rows
     void* row0;        // [Lpad] packed virtual source row
+    void* park;        // [Lpad] parked previous row when it cannot live in LDS
 };
 
 struct DpResult {
@@ -117,26 +119,59 @@ struct DpResult {
 };
 
 // ---------------------------------------------------------------------------------------
-template <int T, int W, bool CVX, bool H16>
-__device__ void dp_fill(const Scoring& S, const RowsView& R, const int N,
+// LDS carve-up of one workgroup (dynamic shared memory):
+//   [0, 1 KiB)                 control words: scans, exchanges, work ticket
+//   [1 KiB, 1 KiB + 8 KiB)     row descriptors (RowMeta) of the current 256-row chunk
+//   [9 KiB, 9 KiB + Lpad*word) packed image of the previous row (multi-pred rows only)
+constexpr int LDS_CTL_BYTES = 1024;
+constexpr int META_CHUNK = 256;
+constexpr int LDS_META_BYTES = META_CHUNK * 32;
+__host__ __device__ constexpr int dp_lds_bytes(int Lpad, int word_bytes) {
+    return LDS_CTL_BYTES + LDS_META_BYTES + Lpad * word_bytes;
+}
+// LDS to request at launch: the parked row only if it leaves room for >= 2 workgroups per CU
+// (or is small); otherwise it goes to the slot's HBM scratch.
+__host__ __device__ constexpr bool dp_park_in_lds(int Lpad, int word_bytes) {
+    return Lpad * word_bytes <= 64 * 1024;
+}
+__host__ __device__ constexpr int dp_lds_launch_bytes(int Lpad, int word_bytes) {
+    return dp_park_in_lds(Lpad, word_bytes) ? dp_lds_bytes(Lpad, word_bytes) : LDS_CTL_BYTES + LDS_META_BYTES;
+}
+
+// Register discipline: every per-column result is pinned with an empty asm right where it is
+// produced and column pairs are fenced with sched_barrier.  Without this hipcc keeps the raw
+// candidates of every column alive to derive the traceback bits later (measured: ~17 VGPRs per
+// column instead of ~6) and the kernel drops to one wave per SIMD or spills.
+#define SXG_PIN(...) asm volatile("" : __VA_ARGS__)
+#define SXG_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// T (= blockDim.x, a multiple of 64) is a run-time value: one compiled kernel serves every
+// strip count, the host picks T = 64 * ceil((L+1) / (64*W)).
+template <int W, bool CVX, bool H16, bool SW>
+__device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, const int N,
                         const uint8_t* __restrict__ seq, const int L, const DpBuffers& B,
-                        int* lds, DpResult& res) {
-    static_assert(W % 4 == 0, "W must be a multiple of 4");
-    constexpr int NW = T / 64;
-    constexpr int Lpad = T * W;
+                        char* smem, const bool park_in_lds, DpResult& res) {
+    static_assert(W % 4 == 0 && W <= 24, "W must be a multiple of 4, at most 24");
+    const int T = (int)blockDim.x;
+    const int NW = T >> 6;
+    const int Lpad = T * W;
+    constexpr unsigned ALL = (1u << W) - 1u;
     using RWt = RowWord<H16>;
     using Word = typename RWt::type;
+    int* lds = (int*)smem;
+    const int4* lmeta = (const int4*)(smem + LDS_CTL_BYTES);
+    // the parked previous row (rows with >= 3 predecessors) lives in LDS unless it cannot fit
+    Word* lrow = park_in_lds ? (Word*)(smem + LDS_CTL_BYTES + LDS_META_BYTES) : (Word*)B.park;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int j0 = t * W;
     const int g = S.g, e = S.e, q = S.q, c = S.c, mm = S.m, mn = S.n;
-    const int lowclamp = S.sw ? 0 : NEG * 2;
     const int We = W * e, Wc = W * c;
-    int* tot_a = lds;            // [NW]
-    int* tot_b = lds + NW;       // [NW]
-    int* xch_h = lds + 2 * NW;   // [NW]
-    int* xch_b = lds + 3 * NW;   // [NW]
+    int* tot_a = lds;        // [16]
+    int* tot_b = lds + 16;   // [16]
+    int* xch_h = lds + 32;   // [16]
+    int* xch_b = lds + 48;   // [16]
 
-    // query letters of my columns: column j pairs with seq[j-1]
+    // query letters of my columns, 4 per VGPR: column j pairs with seq[j-1]; 255 = no letter
     unsigned qcw[W / 4];
 #pragma unroll
     for (int k4 = 0; k4 < W / 4; ++k4) {
@@ -156,13 +191,13 @@ __device__ void dp_fill(const Scoring& S, const RowsView& R, const int N,
     for (int k = 0; k < W; ++k) {
         const int j = j0 + k;
         int h = 0;
-        if (!S.sw && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = a > b ? a : b; }
+        if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = a > b ? a : b; }
         Hp[k] = h; Fp[k] = NEG; Op[k] = NEG;
     }
     {
         const int j = j0 - 1;
         int h = 0;
-        if (!S.sw && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = a > b ? a : b; }
+        if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = a > b ? a : b; }
         Hleft = j < 0 ? NEG : h;
     }
     {
@@ -170,97 +205,180 @@ __device__ void dp_fill(const Scoring& S, const RowsView& R, const int N,
 #pragma unroll
         for (int k = 0; k < W; ++k) r0[k] = RWt::pack(Hp[k], Fp[k], Op[k]);
     }
-    int best = 0, bi = -1, bj = -1;
-    __syncthreads();
+    // end-cell tracking.  Local: key = H<<5 | (31-k) so that one max per column finds the
+    // greatest H and, among equals, the smallest column; rows are compared on H only (strictly).
+    int best = SW ? 0 : NEG * 2, bi = -1, bj = -1;  // bj: column index INSIDE my strip
+    const int kL = L - j0;                          // strip-local index of the end column L
 
     for (int i = 1; i <= N; ++i) {
         const int r = i - 1;
-        const int pb = __builtin_amdgcn_readfirstlane(R.pred_off[r]);
-        const int pe = __builtin_amdgcn_readfirstlane(R.pred_off[r + 1]);
-        const int np = pe - pb;
-        const int code = __builtin_amdgcn_readfirstlane((int)R.code[r]);
-        const int flags = __builtin_amdgcn_readfirstlane((int)R.flags[r]);
+        if ((r & (META_CHUNK - 1)) == 0) {
+            // stage the descriptors of the next 256 rows (all waves are past row r-1 here)
+            __syncthreads();
+            const int4* gm = (const int4*)(R.meta + 8 * (size_t)r);
+            int4* lm = (int4*)(smem + LDS_CTL_BYTES);
+            const int nrow = min(META_CHUNK, N - r);
+            for (int x = t; x < 2 * nrow; x += T) lm[x] = gm[x];
+            __syncthreads();
+        }
+        const int4 m0 = lmeta[2 * (r & (META_CHUNK - 1))], m1 = lmeta[2 * (r & (META_CHUNK - 1)) + 1];
+        const int pb = __builtin_amdgcn_readfirstlane(m0.x);
+        const int info = __builtin_amdgcn_readfirstlane(m0.y);
+        const int p0 = __builtin_amdgcn_readfirstlane(m0.z);
+        const int s0 = __builtin_amdgcn_readfirstlane(m0.w);
+        const int p1 = __builtin_amdgcn_readfirstlane(m1.x);
+        const int s1 = __builtin_amdgcn_readfirstlane(m1.y);
+        const int myslot = __builtin_amdgcn_readfirstlane(m1.z);
+        const int tx = __builtin_amdgcn_readfirstlane(m1.w);
+        const int np = info & 0xffff, code = (info >> 16) & 0xff, flags = (info >> 24) & 0xff;
+#pragma unroll
+        for (int k4 = 0; k4 < W / 4; ++k4) SXG_PIN("+v"(qcw[k4]));  // stay packed: no per-column hoisting
 
-        int Dm[W], F[W], O[W];
-        unsigned tag[W];  // d | f<<10 | o<<20 | fx<<30 | ox<<31
+        int Hc[W];                  // first the best diagonal source, later the final H of this row
+        unsigned fxm = 0, oxm = 0;  // "came from EXTEND" bit of F / O, one bit per column
 
-        const int p0 = np ? __builtin_amdgcn_readfirstlane(R.preds[pb]) : 0;
+// first source of a row: F/O/diag straight from (hs, fs, os, hprev)
+#define SXG_INIT(k, hs, fs, os, hprev)                                              \
+    do {                                                                            \
+        const int c1_ = (hs) + g, c2_ = (fs) + e;                                   \
+        const bool x1_ = c2_ > c1_;                                                 \
+        const int d1_ = (hs) + q, d2_ = (os) + c;                                   \
+        const bool x2_ = CVX && d2_ > d1_;                                          \
+        Hc[k] = (hprev);                                                            \
+        Fp[k] = x1_ ? c2_ : c1_;                                                    \
+        fxm |= (unsigned)x1_ << (k);                                                \
+        if (CVX) { Op[k] = x2_ ? d2_ : d1_; oxm |= (unsigned)x2_ << (k); }          \
+        SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm));       \
+    } while (0)
+
         if (np <= 1 && p0 == i - 1) {
-            // ---- fast path: single predecessor held in registers
+            // ---- the single predecessor is the row in registers: update F and O in place
 #pragma unroll
             for (int k = 0; k < W; ++k) {
-                const int c1 = Hp[k] + g, c2 = Fp[k] + e;
-                unsigned tg = 0;
-                F[k] = c1; if (c2 > c1) { F[k] = c2; tg |= 1u << 30; }
-                if (CVX) {
-                    const int d1 = Hp[k] + q, d2 = Op[k] + c;
-                    O[k] = d1; if (d2 > d1) { O[k] = d2; tg |= 1u << 31; }
-                } else O[k] = NEG;
-                Dm[k] = k ? Hp[k - 1] : Hleft;
-                tag[k] = tg;
+                SXG_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
+                if ((k & 1) == 1) SXG_FENCE();
             }
         } else {
-            for (int x = 0; x < (np ? np : 1); ++x) {
-                const int p = np ? __builtin_amdgcn_readfirstlane(R.preds[pb + x]) : 0;
-                if (p == i - 1) {
+            // ---- general row.  Sources are folded one at a time: the first one initialises the
+            // accumulators, each further one takes a state over where it is better.  List-order
+            // tie-breaks (S3): a later predecessor must be STRICTLY better.  With two
+            // predecessors of which #1 is the register row, #1 is folded first (in place, no
+            // parking) and #0 second with "better or equal" (ge = 1).  Three or more: the
+            // register row is parked in LDS (own columns only, so no barrier) and everything is
+            // folded in list order.
+            const bool reg0 = (p0 == i - 1), reg1 = (np == 2 && p1 == i - 1);
+            const bool park = np >= 3;
+            if (park) {
 #pragma unroll
-                    for (int k = 0; k < W; ++k) {
-                        const int hs = Hp[k], fs = Fp[k], os = Op[k];
-                        const int hl = k ? Hp[k - 1] : Hleft;
-                        unsigned tg = x ? tag[k] : 0u;
-                        int c1 = hs + g, c2 = fs + e;
-                        if (x == 0 || c1 > F[k]) { F[k] = c1; tg = (tg & ~((1023u << 10) | (1u << 30))) | ((unsigned)x << 10); }
-                        if (c2 > F[k]) { F[k] = c2; tg = (tg & ~(1023u << 10)) | ((unsigned)x << 10) | (1u << 30); }
-                        if (CVX) {
-                            c1 = hs + q; c2 = os + c;
-                            if (x == 0 || c1 > O[k]) { O[k] = c1; tg = (tg & ~((1023u << 20) | (1u << 31))) | ((unsigned)x << 20); }
-                            if (c2 > O[k]) { O[k] = c2; tg = (tg & ~(1023u << 20)) | ((unsigned)x << 20) | (1u << 31); }
-                        } else O[k] = NEG;
-                        if (x == 0 || hl > Dm[k]) { Dm[k] = hl; tg = (tg & ~1023u) | (unsigned)x; }
-                        tag[k] = tg;
-                    }
+                for (int k = 0; k < W; ++k) lrow[j0 + k] = RWt::pack(Hp[k], Fp[k], Op[k]);
+            }
+            const int ge = reg1 ? 1 : 0;
+            // ---- first source
+            if ((reg0 || reg1) && !park) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    SXG_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
+                    if ((k & 1) == 1) SXG_FENCE();
+                }
+            } else {
+                Word wr[W];
+                int hl = Hleft;
+                if (reg0) {  // parked copy of the register row
+#pragma unroll
+                    for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
                 } else {
-                    const Word* src = (p == 0) ? (const Word*)B.row0
-                                               : (const Word*)B.pool + (size_t)__builtin_amdgcn_readfirstlane(R.slot[p - 1]) * Lpad;
-                    int hl = NEG;
-                    if (j0 > 0) hl = RWt::h_of(src[j0 - 1]);
+                    const Word* sp = ((p0 == 0) ? (const Word*)B.row0 : (const Word*)B.pool + (size_t)s0 * Lpad) + j0;
 #pragma unroll
-                    for (int k = 0; k < W; ++k) {
-                        int hs, fs, os;
-                        RWt::unpack(src[j0 + k], hs, fs, os);
-                        unsigned tg = x ? tag[k] : 0u;
-                        int c1 = hs + g, c2 = fs + e;
-                        if (x == 0 || c1 > F[k]) { F[k] = c1; tg = (tg & ~((1023u << 10) | (1u << 30))) | ((unsigned)x << 10); }
-                        if (c2 > F[k]) { F[k] = c2; tg = (tg & ~(1023u << 10)) | ((unsigned)x << 10) | (1u << 30); }
-                        if (CVX) {
-                            c1 = hs + q; c2 = os + c;
-                            if (x == 0 || c1 > O[k]) { O[k] = c1; tg = (tg & ~((1023u << 20) | (1u << 31))) | ((unsigned)x << 20); }
-                            if (c2 > O[k]) { O[k] = c2; tg = (tg & ~(1023u << 20)) | ((unsigned)x << 20) | (1u << 31); }
-                        } else O[k] = NEG;
-                        if (x == 0 || hl > Dm[k]) { Dm[k] = hl; tg = (tg & ~1023u) | (unsigned)x; }
-                        tag[k] = tg;
-                        hl = hs;
-                    }
+                    for (int k = 0; k < W; ++k) wr[k] = sp[k];
+                    hl = j0 > 0 ? RWt::h_of(sp[-1]) : NEG;
+                }
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    int hs, fs, os;
+                    RWt::unpack(wr[k], hs, fs, os);
+                    SXG_INIT(k, hs, fs, os, hl);
+                    hl = hs;
+                    SXG_PIN("+v"(hl));
+                    if ((k & 1) == 1) SXG_FENCE();
                 }
             }
+            // ---- further sources, one fold step each
+            for (int x = 1; x < np; ++x) {
+                int p, sl;
+                if (x == 1) { p = reg1 ? p0 : p1; sl = reg1 ? s0 : s1; }
+                else {
+                    p = __builtin_amdgcn_readfirstlane(R.preds[pb + x]);
+                    sl = (p >= 1 && p != i - 1) ? __builtin_amdgcn_readfirstlane(R.slot[p - 1]) : -1;
+                }
+                Word wr[W];
+                int hl = Hleft;
+                if (p == i - 1) {  // only with three or more predecessors: the parked copy
+#pragma unroll
+                    for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
+                } else {
+                    const Word* sp = ((p == 0) ? (const Word*)B.row0 : (const Word*)B.pool + (size_t)sl * Lpad) + j0;
+#pragma unroll
+                    for (int k = 0; k < W; ++k) wr[k] = sp[k];
+                    hl = j0 > 0 ? RWt::h_of(sp[-1]) : NEG;
+                }
+                // fold: "cand + ge > cur" is (cand > cur) for ge = 0 and (cand >= cur) for ge = 1;
+                // the masks start at 0 (ge = 0: set on take-over) or ALL (ge = 1: cleared on
+                // take-over), both expressed as one xor
+                unsigned dm = ge ? ALL : 0u, fmk = dm, omk = CVX ? dm : 0u;
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    int hs, fs, os;
+                    RWt::unpack(wr[k], hs, fs, os);
+                    const int c1 = hs + g, c2 = fs + e;
+                    const bool x1 = c2 > c1;
+                    const int cb = x1 ? c2 : c1;
+                    const bool rf = cb + ge > Fp[k];
+                    Fp[k] = rf ? cb : Fp[k];
+                    fxm = (fxm & ~((unsigned)rf << k)) | ((unsigned)(rf && x1) << k);
+                    fmk ^= (unsigned)rf << k;
+                    if (CVX) {
+                        const int d1 = hs + q, d2 = os + c;
+                        const bool x2 = d2 > d1;
+                        const int db = x2 ? d2 : d1;
+                        const bool ro = db + ge > Op[k];
+                        Op[k] = ro ? db : Op[k];
+                        oxm = (oxm & ~((unsigned)ro << k)) | ((unsigned)(ro && x2) << k);
+                        omk ^= (unsigned)ro << k;
+                    }
+                    const bool rd = hl + ge > Hc[k];
+                    Hc[k] = rd ? hl : Hc[k];
+                    dm ^= (unsigned)rd << k;
+                    hl = hs;
+                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm), "+v"(dm), "+v"(fmk), "+v"(omk), "+v"(hl));
+                    if ((k & 1) == 1) SXG_FENCE();
+                }
+                uint32_t* st = B.steps + ((size_t)(tx + x - 1) * 3) * T + t;
+                st[0] = dm; st[T] = fmk; st[2 * T] = omk;
+            }
+        }
+#undef SXG_INIT
+        if (!CVX) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) Op[k] = NEG;
         }
 
         // ---- H before the in-row gaps, strip-local carries (pass 1)
-        int Hc[W];
-        unsigned srcv[W];
+        unsigned fm = 0, om = 0;  // H came from F / from O
         int a = NEG, b = NEG;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const unsigned qb = (qcw[k >> 2] >> (8 * (k & 3))) & 255u;
-            int h = Dm[k] + ((int)qb == code ? mm : mn);
-            unsigned src = SRC_D;
-            if (F[k] > h) { h = F[k]; src = SRC_F; }
-            if (CVX && O[k] > h) { h = O[k]; src = SRC_O; }
-            Hc[k] = h; srcv[k] = src;
-            const int hc = max(h, lowclamp);
+            int h = Hc[k] + ((int)qb == code ? mm : mn);
+            if (Fp[k] > h) { h = Fp[k]; fm |= 1u << k; }
+            if (CVX && Op[k] > h) { h = Op[k]; om |= 1u << k; }
+            Hc[k] = h;
+            const int hc = SW ? max(h, 0) : h;
             a = max(a + e, hc + g);
             if (CVX) b = max(b + c, hc + q);
+            SXG_PIN("+v"(Hc[k]), "+v"(fm), "+v"(om), "+v"(a), "+v"(b));
+            if ((k & 1) == 1) SXG_FENCE();
         }
+        fm &= ~om;
         // carries: Ein(t) = max_{s<t} (a_s + (t-1-s)*W*e)
         int ya = a - t * We, yb = CVX ? b - t * Wc : NEG;
 #pragma unroll
@@ -286,23 +404,34 @@ __device__ void dp_fill(const Scoring& S, const RowsView& R, const int N,
         // ---- pass 2: final H, traceback bytes
         unsigned tbw[W / 4];
         unsigned ebit = 0, qbit = 0;  // ext flags of the CURRENT column (column 0 patched later)
+        int rowkey = 0;               // SW: max over my columns of H<<5 | (31-k)
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             int h = Hc[k];
-            unsigned src = srcv[k];
+            unsigned src = SRC_D + ((fm >> k) & 1u) + 2u * ((om >> k) & 1u);
             if (E > h) { h = E; src = SRC_E; }
             if (CVX && Q > h) { h = Q; src = SRC_Q; }
-            if (S.sw && h <= 0) { h = 0; src = SRC_STOP; }
+            if (SW && h <= 0) { h = 0; src = SRC_STOP; }
             Hc[k] = h;
-            const unsigned byte = src | ((tag[k] >> 30) & 1u) * TB_FEXT | ((tag[k] >> 31) & 1u) * TB_OEXT |
+            const unsigned byte = src | ((fxm >> k) & 1u) * TB_FEXT | ((oxm >> k) & 1u) * TB_OEXT |
                                   ebit * TB_EEXT | qbit * TB_QEXT;
             if ((k & 3) == 0) tbw[k >> 2] = byte; else tbw[k >> 2] |= byte << (8 * (k & 3));
-            const int j = j0 + k;
-            if (S.sw && j <= L && h > best) { best = h; bi = i; bj = j; }
-            if (!S.sw && j == L && (flags & ROW_SINK) && (bi < 0 || h > best)) { best = h; bi = i; bj = j; }
+            // pad columns (j > L) can never strictly beat a real cell and lose every tie (their
+            // letter never matches), so the local-mode maximum needs no column test
+            if (SW) rowkey = max(rowkey, (h << 5) | (31 - k));
             const int c1 = h + g, c2 = E + e;
             ebit = c2 > c1; E = ebit ? c2 : c1;
             if (CVX) { const int d1 = h + q, d2 = Q + c; qbit = d2 > d1; Q = qbit ? d2 : d1; }
+            SXG_PIN("+v"(Hc[k]), "+v"(tbw[k >> 2]), "+v"(E), "+v"(Q), "+v"(ebit), "+v"(qbit), "+v"(rowkey));
+            if ((k & 1) == 1) SXG_FENCE();
+        }
+        if (SW) {
+            if ((rowkey >> 5) > best) { best = rowkey >> 5; bi = i; bj = 31 - (rowkey & 31); }
+        } else if (flags & ROW_SINK) {  // global: H[i][L] of sink rows, owned by one lane
+            int hL = NEG * 2;
+#pragma unroll
+            for (int k = 0; k < W; ++k) hL = (k == kL) ? Hc[k] : hL;
+            if (kL >= 0 && kL < W && (bi < 0 || hL > best)) { best = hL; bi = i; bj = kL; }
         }
         // hand H of my last column and the ext flags of the next column to the right neighbour
         int xh = Hc[W - 1], xb = (int)(ebit | (qbit << 1));
@@ -321,35 +450,20 @@ __device__ void dp_fill(const Scoring& S, const RowsView& R, const int N,
 #pragma unroll
             for (int k4 = 0; k4 < W / 4; ++k4) dst[k4] = tbw[k4];
         }
-        if (np > 1) {
-            const int tx = __builtin_amdgcn_readfirstlane(R.tbx[r]);
-            if (tx >= 0) {
-                uint16_t* dst = B.tbx16 + (size_t)tx * Lpad + j0;
-#pragma unroll
-                for (int k = 0; k < W; k += 2) {
-                    const unsigned lo = (tag[k] & 31u) | (((tag[k] >> 10) & 31u) << 5) | (((tag[k] >> 20) & 31u) << 10);
-                    const unsigned hi = (tag[k + 1] & 31u) | (((tag[k + 1] >> 10) & 31u) << 5) | (((tag[k + 1] >> 20) & 31u) << 10);
-                    *(unsigned*)(dst + k) = lo | (hi << 16);
-                }
-            } else {
-                uint32_t* dst = B.tbx32 + (size_t)(-(tx + 2)) * Lpad + j0;
-#pragma unroll
-                for (int k = 0; k < W; ++k) dst[k] = tag[k] & 0x3fffffffu;
-            }
-        }
         if (flags & ROW_STORE) {
-            Word* dst = (Word*)B.pool + (size_t)__builtin_amdgcn_readfirstlane(R.slot[r]) * Lpad + j0;
+            Word* dst = (Word*)B.pool + (size_t)myslot * Lpad + j0;
 #pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = RWt::pack(Hc[k], F[k], O[k]);
+            for (int k = 0; k < W; ++k) dst[k] = RWt::pack(Hc[k], Fp[k], Op[k]);
         }
 #pragma unroll
-        for (int k = 0; k < W; ++k) { Hp[k] = Hc[k]; Fp[k] = F[k]; Op[k] = O[k]; }
+        for (int k = 0; k < W; ++k) Hp[k] = Hc[k];
         Hleft = lh;
         if (NW == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
 
     // ---- end cell: greatest score, then smallest row, then smallest column
     unsigned long long key = 0;
+    bj += j0;
     if (bi >= 0)
         key = ((unsigned long long)(unsigned)(best + (1 << 27)) << 35) |
               ((unsigned long long)(0xFFFFFu - (unsigned)bi) << 15) | (unsigned long long)(0x7FFFu - (unsigned)bj);
@@ -377,9 +491,25 @@ __device__ void dp_fill(const Scoring& S, const RowsView& R, const int N,
 // Traceback (S5): replay of the recorded choices by one lane.  Emits pairs in REVERSE order
 // into pair_row/pair_pos (row = 1-based row index or 0 for "none", pos or -1) when PAIRS,
 // and/or fills posnode[pos] = node id of the aligned node.  Returns the number of pairs.
+// Which predecessor (list ordinal) owns state `which` (0 = D, 1 = F, 2 = O) of cell (row r,
+// column j): the last fold step that took the state over, else predecessor #0.  For two
+// predecessors the single step's bit IS the ordinal (dp_fill keeps that true when it folds #1
+// first).
+__device__ __forceinline__ int winner_ordinal(const RowsView& R, const DpBuffers& B, const int T, const int W,
+                                              const int r, const int np, const int j, const int which) {
+    const int tx = R.tbx[r];
+    const int lane_t = j / W, k = j - lane_t * W;
+    for (int x = np - 1; x >= 1; --x) {
+        const unsigned m = B.steps[((size_t)(tx + x - 1) * 3 + which) * T + lane_t];
+        if ((m >> k) & 1u) return x;
+    }
+    return 0;
+}
+
 template <bool PAIRS>
-__device__ int traceback(const RowsView& R, const DpBuffers& B, const int Lpad, const int sw, int i, int j,
+__device__ __noinline__ int traceback(const RowsView& R, const DpBuffers& B, const int T, const int W, const int sw, int i, int j,
                          int32_t* posnode, int32_t* pair_row, int32_t* pair_pos) {
+    const int Lpad = T * W;
     int n = 0, st = SRC_STOP;
     for (;;) {
         if (i == 0) {
@@ -391,17 +521,6 @@ __device__ int traceback(const RowsView& R, const DpBuffers& B, const int Lpad, 
         const int r = i - 1;
         const unsigned tbyte = B.tb[(size_t)i * Lpad + j];
         const int pb = R.pred_off[r], np = R.pred_off[r + 1] - pb;
-        int dord = 0, ford = 0, oord = 0;
-        if (np > 1) {
-            const int tx = R.tbx[r];
-            if (tx >= 0) {
-                const unsigned v = B.tbx16[(size_t)tx * Lpad + j];
-                dord = v & 31; ford = (v >> 5) & 31; oord = (v >> 10) & 31;
-            } else {
-                const unsigned v = B.tbx32[(size_t)(-(tx + 2)) * Lpad + j];
-                dord = v & 1023; ford = (v >> 10) & 1023; oord = (v >> 20) & 1023;
-            }
-        }
         if (st == SRC_STOP) {
             const int src = tbyte & 7;
             if (src == SRC_STOP) break;
@@ -409,15 +528,14 @@ __device__ int traceback(const RowsView& R, const DpBuffers& B, const int Lpad, 
                 if (PAIRS) { pair_row[n] = i; pair_pos[n] = j - 1; }
                 if (posnode) posnode[j - 1] = R.row_node[r];
                 ++n;
-                i = np ? R.preds[pb + dord] : 0;
+                i = np ? R.preds[pb + (np > 1 ? winner_ordinal(R, B, T, W, r, np, j, 0) : 0)] : 0;
                 --j;
             } else st = src;
         } else if (st == SRC_F || st == SRC_O) {
             const int ext = st == SRC_F ? (tbyte & TB_FEXT) : (tbyte & TB_OEXT);
-            const int ord = st == SRC_F ? ford : oord;
             if (PAIRS) { pair_row[n] = i; pair_pos[n] = -1; }
             ++n;
-            i = np ? R.preds[pb + ord] : 0;
+            i = np ? R.preds[pb + (np > 1 ? winner_ordinal(R, B, T, W, r, np, j, st == SRC_F ? 1 : 2) : 0)] : 0;
             if (!ext) st = SRC_STOP;
         } else {
             const int ext = st == SRC_E ? (tbyte & TB_EEXT) : (tbyte & TB_QEXT);

@@ -85,7 +85,7 @@ SXG_HD int group_end(const GraphView& G, int leader, int n_old) {
 // path_out[0..len) receives the node id of every base (replaces spoa's per-edge labels /
 // Node::Successor walk used at src/smooth.cpp:2604-2610).
 template <class Ctx>
-SXG_HD void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq, int len,
+SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq, int len,
                           uint32_t weight, int32_t* path_out) {
     const int T = c.nthreads(), t = c.tid();
     const int n_old = *G.n_nodes, e_old = *G.n_edges;
@@ -196,16 +196,15 @@ SXG_HD void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq, int le
 struct RowCaps {
     int rows_cap;   // rows of the traceback plane
     int pool_slots; // row-pool slots
-    int tbx16_cap;  // rows of the u16 ordinal plane (2..32 preds)
-    int tbx32_cap;  // rows of the u32 ordinal plane (>32 preds)
+    int step_cap;   // fold steps of the step-mask plane (sum over multi-pred rows of np-1)
 };
 
 // Second half of row preparation, shared by the block kernel (graph -> rows) and the
 // stand-alone align kernel (caller CSR -> rows).  On entry R.flags holds STORE/SINK bits and
 // R.slot[r] the rank of the last reader of row r.  Assigns ring slots of the row pool and
-// the ordinal-plane index of multi-pred rows.  Returns a status (same on every thread).
+// the step-mask plane offset of multi-pred rows.  Returns a status (same on every thread).
 template <class Ctx>
-SXG_HD int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps) {
+SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps) {
     const int T = c.nthreads(), t = c.tid();
     c.sync();
     const int n_store = array_excl_sum(c, N, [&](int r) { return (R.flags[r] & ROW_STORE) ? 1 : 0; }, R.sseq);
@@ -221,21 +220,29 @@ SXG_HD int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps) {
     }
     worst = c.reduce_max(worst);
     if (worst > caps.pool_slots) return ST_POOL_OVERFLOW;
-    const int n16 = array_excl_sum(c, N, [&](int r) {
+    // multi-pred rows: np-1 fold steps each in the step-mask plane
+    const int n_steps = array_excl_sum(c, N, [&](int r) {
         const int d = R.pred_off[r + 1] - R.pred_off[r];
-        return (d > 1 && d <= 32) ? 1 : 0; }, R.tbx);
-    const int n32 = array_excl_sum(c, N, [&](int r) {
-        return (R.pred_off[r + 1] - R.pred_off[r] > 32) ? 1 : 0; }, R.sseq);
+        return d > 1 ? d - 1 : 0; }, R.tbx);
     c.sync();
-    if (n16 > caps.tbx16_cap || n32 > caps.tbx32_cap) return ST_TBX_OVERFLOW;
-    int toobig = 0;
+    if (n_steps > caps.step_cap) return ST_TBX_OVERFLOW;
+    for (int r = t; r < N; r += T)
+        if (R.pred_off[r + 1] - R.pred_off[r] <= 1) R.tbx[r] = -1;
+    c.sync();
     for (int r = t; r < N; r += T) {
-        const int d = R.pred_off[r + 1] - R.pred_off[r];
-        if (d <= 1) R.tbx[r] = -1;
-        else if (d > 32) R.tbx[r] = -(R.sseq[r] + 2);
-        if (d > 1023) toobig = 1;
+        const int pb = R.pred_off[r], np = R.pred_off[r + 1] - pb;
+        RowMeta m;
+        m.pb = pb;
+        m.info = np | ((int)R.code[r] << 16) | ((int)R.flags[r] << 24);
+        m.p0 = np >= 1 ? R.preds[pb] : 0;
+        m.s0 = (m.p0 >= 1 && m.p0 != r) ? R.slot[m.p0 - 1] : -1;
+        m.p1 = np >= 2 ? R.preds[pb + 1] : 0;
+        m.s1 = (m.p1 >= 1 && m.p1 != r) ? R.slot[m.p1 - 1] : -1;
+        m.slot = R.slot[r];
+        m.tbx = R.tbx[r];
+        int32_t* d = R.meta + 8 * (size_t)r;
+        d[0] = m.pb; d[1] = m.info; d[2] = m.p0; d[3] = m.s0; d[4] = m.p1; d[5] = m.s1; d[6] = m.slot; d[7] = m.tbx;
     }
-    if (c.reduce_max(toobig)) return ST_TBX_OVERFLOW;
     c.sync();
     return ST_OK;
 }
@@ -243,7 +250,7 @@ SXG_HD int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps) {
 // Rank-space CSR + per-row DP metadata of the current graph.  Returns a status code
 // (identical on every thread).
 template <class Ctx>
-SXG_HD int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const RowCaps& caps) {
+SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const RowCaps& caps) {
     const int T = c.nthreads(), t = c.tid();
     c.sync();
     const int N = *G.n_nodes;
@@ -297,7 +304,7 @@ SXG_HD int branch_completion(const GraphView& G, int N, int r, int64_t* sc, int3
 }
 
 // Writes the consensus node ids (forward order) to out; returns the length.  tmp needs N ints.
-SXG_HD int consensus_serial(const GraphView& G, int64_t* sc, int32_t* pr, int32_t* out) {
+SXG_HD_PHASE int consensus_serial(const GraphView& G, int64_t* sc, int32_t* pr, int32_t* out) {
     const int N = *G.n_nodes;
     if (N == 0) return 0;
     for (int v = 0; v < N; ++v) { sc[v] = -1; pr[v] = -1; }

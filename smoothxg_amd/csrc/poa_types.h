@@ -7,8 +7,12 @@
 
 #if defined(__HIPCC__)
 #define SXG_HD __host__ __device__ __forceinline__
+// the graph phases stay OUT of line in the persistent kernel: inlined, their ~50 array
+// descriptors stay live across the DP sweep and push it into scratch spills
+#define SXG_HD_PHASE __host__ __device__ __noinline__
 #else
 #define SXG_HD inline
+#define SXG_HD_PHASE inline
 #endif
 
 namespace sxg {
@@ -60,10 +64,22 @@ struct RowsView {
     int32_t *pred_off;   // [N+1]
     int32_t *preds;      // [E] row indices (rank+1), in-edge insertion order
     int32_t *slot;       // [N] row-pool slot of stored rows
-    int32_t *tbx;        // [N] >=0: row index in the u16 ordinal plane; <=-2: -(idx+2) in the
-                         //      u32 plane; -1: single-pred row
+    int32_t *tbx;        // [N] first fold step of a multi-pred row in the step-mask plane
+                         //      (row with np preds owns np-1 steps); -1: single-pred row
     int32_t *sseq;       // [N+1] exclusive count of stored rows (scratch)
     int32_t *row_node;   // [N] node id at rank
+    int32_t *meta;       // [N*8] per-row DP descriptor, see RowMeta
+};
+
+// What the DP needs to start a row, gathered into 32 bytes so the sweep reads it from an
+// LDS-staged chunk instead of chasing four dependent global loads per row.
+struct RowMeta {
+    int pb;        // offset of the predecessor list in RowsView::preds
+    int info;      // np | code << 16 | flags << 24
+    int p0, s0;    // first predecessor row (0 = virtual source) and its pool slot (-1: none/regs)
+    int p1, s1;    // second predecessor row / slot (np >= 2)
+    int slot;      // own pool slot (-1: row not stored)
+    int tbx;       // first fold step in the step-mask plane, as RowsView::tbx
 };
 
 }  // namespace sxg

@@ -7,6 +7,7 @@
 // processed per launch with no host round trip between the alignments of a block.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,9 +27,9 @@ using namespace sxg;
 struct SlotLayout {  // byte offsets inside one slot arena (all 16-byte aligned)
     size_t hdr, code, rank, order, order_tmp, leader, gmem, in_head, in_tail, out_head, out_tail, in_deg,
         out_deg, e_tail, e_head, e_next_in, e_next_out, e_w, posnode, target, newidx, nexta, preva, slotadd,
-        kind, r_code, r_flags, r_pred_off, r_preds, r_slot, r_tbx, r_sseq, r_row_node, tb, tbx16, tbx32, pool,
-        row0, cons_sc, cons_pr, pair_row, pair_pos, total;
-    int nodes_cap, rows_cap, pool_slots, tbx16_cap, tbx32_cap, scratch_len, Lpad, word_bytes;
+        kind, r_code, r_flags, r_pred_off, r_preds, r_slot, r_tbx, r_sseq, r_row_node, r_meta, tb, steps, pool,
+        row0, park, cons_sc, cons_pr, pair_row, pair_pos, total;
+    int nodes_cap, rows_cap, pool_slots, step_cap, scratch_len, Lpad, word_bytes, threads;
 };
 
 static size_t lay(size_t& cur, size_t bytes) {
@@ -37,16 +38,16 @@ static size_t lay(size_t& cur, size_t bytes) {
     return o;
 }
 
-static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int tbx16_cap, int tbx32_cap, int Lpad,
+static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int step_cap, int threads, int Lpad,
                               int word_bytes, bool pairs) {
     SlotLayout L;
     memset(&L, 0, sizeof(L));
     L.nodes_cap = nodes_cap; L.rows_cap = rows_cap; L.pool_slots = pool_slots;
-    L.tbx16_cap = tbx16_cap; L.tbx32_cap = tbx32_cap; L.Lpad = Lpad; L.word_bytes = word_bytes;
+    L.step_cap = step_cap; L.threads = threads; L.Lpad = Lpad; L.word_bytes = word_bytes;
     const size_t C = (size_t)nodes_cap + 4, S = (size_t)std::max(nodes_cap, Lpad) + 4, Rr = (size_t)rows_cap + 4;
     L.scratch_len = (int)S;
     size_t cur = 0;
-    L.hdr = lay(cur, 64);
+    L.hdr = lay(cur, 256);
     L.code = lay(cur, C);
     L.rank = lay(cur, 4 * C); L.order = lay(cur, 4 * C); L.order_tmp = lay(cur, 4 * C); L.leader = lay(cur, 4 * C);
     L.gmem = lay(cur, 20 * C);
@@ -58,12 +59,12 @@ static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int t
     L.nexta = lay(cur, 4 * S); L.preva = lay(cur, 4 * S); L.slotadd = lay(cur, 4 * S); L.kind = lay(cur, S);
     L.r_code = lay(cur, Rr); L.r_flags = lay(cur, Rr); L.r_pred_off = lay(cur, 4 * Rr);
     L.r_preds = lay(cur, 4 * C); L.r_slot = lay(cur, 4 * Rr); L.r_tbx = lay(cur, 4 * Rr);
-    L.r_sseq = lay(cur, 4 * Rr); L.r_row_node = lay(cur, 4 * Rr);
+    L.r_sseq = lay(cur, 4 * Rr); L.r_row_node = lay(cur, 4 * Rr); L.r_meta = lay(cur, 32 * Rr);
     L.tb = lay(cur, ((size_t)rows_cap + 1) * Lpad);
-    L.tbx16 = lay(cur, (size_t)std::max(tbx16_cap, 1) * Lpad * 2);
-    L.tbx32 = lay(cur, (size_t)std::max(tbx32_cap, 1) * Lpad * 4);
+    L.steps = lay(cur, (size_t)std::max(step_cap, 1) * 3 * threads * 4);
     L.pool = lay(cur, (size_t)pool_slots * Lpad * word_bytes);
     L.row0 = lay(cur, (size_t)Lpad * word_bytes);
+    L.park = lay(cur, (size_t)Lpad * word_bytes);
     L.cons_sc = lay(cur, 8 * C); L.cons_pr = lay(cur, 4 * C);
     if (pairs) { L.pair_row = lay(cur, 4 * (Rr + Lpad)); L.pair_pos = lay(cur, 4 * (Rr + Lpad)); }
     L.total = cur;
@@ -94,9 +95,9 @@ __device__ static SlotViews slot_views(uint8_t* base, const SlotLayout& L) {
     V.G.preva = P32(preva); V.G.slotadd = P32(slotadd); V.G.kind = (int8_t*)(base + L.kind);
     V.R.code = base + L.r_code; V.R.flags = base + L.r_flags; V.R.pred_off = P32(r_pred_off);
     V.R.preds = P32(r_preds); V.R.slot = P32(r_slot); V.R.tbx = P32(r_tbx); V.R.sseq = P32(r_sseq);
-    V.R.row_node = P32(r_row_node);
-    V.B.tb = base + L.tb; V.B.tbx16 = (uint16_t*)(base + L.tbx16); V.B.tbx32 = (uint32_t*)(base + L.tbx32);
-    V.B.pool = base + L.pool; V.B.row0 = base + L.row0;
+    V.R.row_node = P32(r_row_node); V.R.meta = P32(r_meta);
+    V.B.tb = base + L.tb; V.B.steps = (uint32_t*)(base + L.steps);
+    V.B.pool = base + L.pool; V.B.row0 = base + L.row0; V.B.park = base + L.park;
     V.cons_sc = (int64_t*)(base + L.cons_sc); V.cons_pr = P32(cons_pr);
     V.pair_row = P32(pair_row); V.pair_pos = P32(pair_pos);
 #undef P32
@@ -128,16 +129,25 @@ struct BlockArgs {
     int32_t* edge_tail; int32_t* edge_head; uint32_t* edge_weight;
     int32_t* paths; int32_t* score; unsigned long long* cells; int32_t* cons_nodes;
     int want_consensus;
+    int park_in_lds;
 };
 
-template <int T, int W, bool CVX, bool H16>
-__global__ __launch_bounds__(T) void poa_block_kernel(const BlockArgs A) {
-    __shared__ __attribute__((aligned(16))) int lds[160];
-    __shared__ int s_work;
+// Kernel classes <TMAX, W>: TMAX bounds blockDim.x (the actual T = 64 * strips is a run-time
+// value), W = columns per lane.  The second launch-bound is the number of waves per SIMD the
+// register allocator must leave room for: 8 columns/lane need ~100 VGPRs (4 waves), 16 need
+// ~165 (3 waves); a 1024-thread workgroup is 4 waves per SIMD by itself.
+__host__ __device__ constexpr int sxg_min_waves(int TMAX, int W) { return (TMAX > 512 || W <= 8) ? 4 : 3; }
+
+template <int TMAX, int W, bool CVX, bool H16, bool SW>
+__global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_block_kernel(const BlockArgs A) {
+    const int T = (int)blockDim.x;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* lds = (int*)smem;
+    int& s_work = lds[200];
     WgCtx ctx{lds + 128};
     const int t = threadIdx.x;
     SlotViews V = slot_views(A.arena + (size_t)blockIdx.x * A.lay.total, A.lay);
-    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.tbx16_cap, A.lay.tbx32_cap};
+    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap};
     for (;;) {
         __syncthreads();
         if (t == 0) s_work = atomicAdd(A.queue, 1);
@@ -151,6 +161,9 @@ __global__ __launch_bounds__(T) void poa_block_kernel(const BlockArgs A) {
         if (t == 0) { *V.G.n_nodes = 0; *V.G.n_edges = 0; }
         __syncthreads();
         int status = ST_OK;
+        unsigned long long* prof = (unsigned long long*)(A.arena + (size_t)blockIdx.x * A.lay.total + A.lay.hdr + 64);
+        unsigned long long tc0 = clock64(), tc1;
+#define PROF(k) do { if (t == 0) { tc1 = clock64(); prof[k] += tc1 - tc0; tc0 = tc1; } } while (0)
         for (int s = s0; s < s1 && status == ST_OK; ++s) {
             const int64_t so = A.seq_off[s];
             const int len = (int)(A.seq_off[s + 1] - so);
@@ -162,19 +175,25 @@ __global__ __launch_bounds__(T) void poa_block_kernel(const BlockArgs A) {
             if (len + 1 > T * W) { status = ST_TOO_LONG; break; }
             if (N + len > A.lay.nodes_cap) { status = ST_NODES_OVERFLOW; break; }
             if (N > 0 && len > 0) {
+                PROF(0);
                 status = prep_rows(ctx, V.G, V.R, caps);
                 if (status != ST_OK) break;
+                PROF(1);
                 DpResult res;
-                dp_fill<T, W, CVX, H16>(S, V.R, N, seq, len, V.B, lds, res);
+                dp_fill<W, CVX, H16, SW>(S, V.R, N, seq, len, V.B, smem, A.park_in_lds != 0, res);
                 __syncthreads();
+                PROF(2);
                 if (t == 0 && res.bi >= 0)
-                    traceback<false>(V.R, V.B, T * W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
+                    traceback<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
                 score = res.bi >= 0 ? res.best : 0;
                 __syncthreads();
+                PROF(3);
             }
             if (t == 0) { A.score[s] = score; A.cells[s] = (unsigned long long)N * (unsigned long long)len; }
             add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
+            PROF(4);
         }
+        PROF(0);
         __syncthreads();
         // results of the block
         const int N = *V.G.n_nodes, E = *V.G.n_edges;
@@ -194,6 +213,8 @@ __global__ __launch_bounds__(T) void poa_block_kernel(const BlockArgs A) {
             if (t == 0) { A.n_nodes[b] = N; A.n_edges[b] = E; A.n_cons[b] = nc; }
         } else if (t == 0) { A.n_nodes[b] = 0; A.n_edges[b] = 0; A.n_cons[b] = 0; }
         if (t == 0) A.status[b] = status;
+        PROF(5);
+#undef PROF
     }
 }
 
@@ -206,16 +227,19 @@ struct AlignArgs {
     uint8_t* arena; SlotLayout lay;
     int32_t* status; int32_t* score; int32_t* n_pairs;
     int32_t* pair_row; int32_t* pair_pos;  // worst-case layout: problem p at row_off[p] + seq_off[p]
+    int park_in_lds;
 };
 
-template <int T, int W, bool CVX, bool H16>
-__global__ __launch_bounds__(T) void poa_align_kernel(const AlignArgs A) {
-    __shared__ __attribute__((aligned(16))) int lds[160];
-    __shared__ int s_work;
+template <int TMAX, int W, bool CVX, bool H16, bool SW>
+__global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_align_kernel(const AlignArgs A) {
+    const int T = (int)blockDim.x;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* lds = (int*)smem;
+    int& s_work = lds[200];
     WgCtx ctx{lds + 128};
     const int t = threadIdx.x;
     SlotViews V = slot_views(A.arena + (size_t)blockIdx.x * A.lay.total, A.lay);
-    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.tbx16_cap, A.lay.tbx32_cap};
+    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap};
     for (;;) {
         __syncthreads();
         if (t == 0) s_work = atomicAdd(A.queue, 1);
@@ -230,7 +254,6 @@ __global__ __launch_bounds__(T) void poa_align_kernel(const AlignArgs A) {
         const Scoring S = normalise(A.params[A.per_problem_params ? p : 0]);
         const int64_t e0 = A.pred_off[r0];
         int status = ST_OK, score = 0, npairs = 0;
-        const int64_t out0 = r0 + so;
         if (len + 1 > T * W) status = ST_TOO_LONG;
         else if (N > A.lay.rows_cap) status = ST_ROWS_OVERFLOW;
         else if (N > 0 && len > 0) {
@@ -257,11 +280,12 @@ __global__ __launch_bounds__(T) void poa_align_kernel(const AlignArgs A) {
             status = finish_rows(ctx, N, V.R, caps);
             if (status == ST_OK) {
                 DpResult res;
-                dp_fill<T, W, CVX, H16>(S, V.R, N, A.bases + so, len, V.B, lds, res);
+                dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, res);
                 __syncthreads();
                 if (t == 0 && res.bi >= 0) {
-                    npairs = traceback<true>(V.R, V.B, T * W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
+                    npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
                     score = res.best;
+                    const int64_t out0 = A.row_off[p] + A.seq_off[p];
                     for (int k = 0; k < npairs; ++k) {  // reverse into the output
                         A.pair_row[out0 + k] = V.pair_row[npairs - 1 - k] - 1;
                         A.pair_pos[out0 + k] = V.pair_pos[npairs - 1 - k];
@@ -297,54 +321,57 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
                         std::string(#x) + ": " + hipGetErrorString(_e));                       \
     } while (0)
 
-struct Variant { int T, W; };
-// smallest first; Lpad = T*W must exceed the longest sequence of a block
-static const Variant kVariants[] = {{64, 8}, {64, 16}, {128, 16}, {256, 12}, {256, 16}, {256, 20},
-                                    {256, 24}, {512, 16}, {512, 24}, {1024, 24}};
-static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+// A launch geometry: W columns per lane, NW waves (T = 64*NW), kernel class TMAX.
+struct Variant { int W, NW, TMAX; int T() const { return 64 * NW; } int Lpad() const { return 64 * NW * W; } };
+
+// Prefer 16 columns per lane (less per-row overhead) while the workgroup stays <= 512 threads;
+// beyond that 8 columns per lane keep the 1024-thread class inside 128 VGPRs.
+static bool variant_for_len(int maxlen, Variant* v) {
+    const int need = maxlen + 1;
+    const int nw16 = (need + 64 * 16 - 1) / (64 * 16), nw8 = (need + 64 * 8 - 1) / (64 * 8);
+    if (nw16 <= 8) { *v = Variant{16, std::max(nw16, 1), nw16 <= 4 ? 256 : 512}; return true; }
+    if (nw8 <= 16) { *v = Variant{8, nw8, 1024}; return true; }
+    if (nw16 <= 16) { *v = Variant{16, nw16, 1024}; return true; }
+    return false;
+}
 
 template <class Args> using KernelFn = void (*)(const Args);
 
-template <int T, int W> static KernelFn<BlockArgs> pick_block(bool cvx, bool h16) {
-    if (cvx) return h16 ? poa_block_kernel<T, W, true, true> : poa_block_kernel<T, W, true, false>;
-    return h16 ? poa_block_kernel<T, W, false, true> : poa_block_kernel<T, W, false, false>;
-}
-template <int T, int W> static KernelFn<AlignArgs> pick_align(bool cvx, bool h16) {
-    if (cvx) return h16 ? poa_align_kernel<T, W, true, true> : poa_align_kernel<T, W, true, false>;
-    return h16 ? poa_align_kernel<T, W, false, true> : poa_align_kernel<T, W, false, false>;
-}
-static KernelFn<BlockArgs> block_kernel(int v, bool cvx, bool h16) {
-    switch (v) {
-        case 0: return pick_block<64, 8>(cvx, h16);
-        case 1: return pick_block<64, 16>(cvx, h16);
-        case 2: return pick_block<128, 16>(cvx, h16);
-        case 3: return pick_block<256, 12>(cvx, h16);
-        case 4: return pick_block<256, 16>(cvx, h16);
-        case 5: return pick_block<256, 20>(cvx, h16);
-        case 6: return pick_block<256, 24>(cvx, h16);
-        case 7: return pick_block<512, 16>(cvx, h16);
-        case 8: return pick_block<512, 24>(cvx, h16);
-        default: return pick_block<1024, 24>(cvx, h16);
+template <int TMAX, int W> static KernelFn<BlockArgs> pick_block(bool cvx, bool h16, bool sw) {
+    if (cvx) {
+        if (h16) return sw ? poa_block_kernel<TMAX, W, true, true, true> : poa_block_kernel<TMAX, W, true, true, false>;
+        return sw ? poa_block_kernel<TMAX, W, true, false, true> : poa_block_kernel<TMAX, W, true, false, false>;
     }
+    if (h16) return sw ? poa_block_kernel<TMAX, W, false, true, true> : poa_block_kernel<TMAX, W, false, true, false>;
+    return sw ? poa_block_kernel<TMAX, W, false, false, true> : poa_block_kernel<TMAX, W, false, false, false>;
 }
-static KernelFn<AlignArgs> align_kernel(int v, bool cvx, bool h16) {
-    switch (v) {
-        case 0: return pick_align<64, 8>(cvx, h16);
-        case 1: return pick_align<64, 16>(cvx, h16);
-        case 2: return pick_align<128, 16>(cvx, h16);
-        case 3: return pick_align<256, 12>(cvx, h16);
-        case 4: return pick_align<256, 16>(cvx, h16);
-        case 5: return pick_align<256, 20>(cvx, h16);
-        case 6: return pick_align<256, 24>(cvx, h16);
-        case 7: return pick_align<512, 16>(cvx, h16);
-        case 8: return pick_align<512, 24>(cvx, h16);
-        default: return pick_align<1024, 24>(cvx, h16);
+template <int TMAX, int W> static KernelFn<AlignArgs> pick_align(bool cvx, bool h16, bool sw) {
+    if (cvx) {
+        if (h16) return sw ? poa_align_kernel<TMAX, W, true, true, true> : poa_align_kernel<TMAX, W, true, true, false>;
+        return sw ? poa_align_kernel<TMAX, W, true, false, true> : poa_align_kernel<TMAX, W, true, false, false>;
     }
+    if (h16) return sw ? poa_align_kernel<TMAX, W, false, true, true> : poa_align_kernel<TMAX, W, false, true, false>;
+    return sw ? poa_align_kernel<TMAX, W, false, false, true> : poa_align_kernel<TMAX, W, false, false, false>;
 }
-static int variant_for_len(int maxlen) {
-    for (int v = 0; v < kNumVariants; ++v)
-        if (kVariants[v].T * kVariants[v].W >= maxlen + 1) return v;
-    return -1;
+static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool h16, bool sw) {
+    if (v.W == 8) {
+        if (v.TMAX == 256) return pick_block<256, 8>(cvx, h16, sw);
+        if (v.TMAX == 512) return pick_block<512, 8>(cvx, h16, sw);
+        return pick_block<1024, 8>(cvx, h16, sw);
+    }
+    if (v.TMAX == 256) return pick_block<256, 16>(cvx, h16, sw);
+    if (v.TMAX == 512) return pick_block<512, 16>(cvx, h16, sw);
+    return pick_block<1024, 16>(cvx, h16, sw);
+}
+static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool h16, bool sw) {
+    if (v.W == 8) {
+        if (v.TMAX == 256) return pick_align<256, 8>(cvx, h16, sw);
+        if (v.TMAX == 512) return pick_align<512, 8>(cvx, h16, sw);
+        return pick_align<1024, 8>(cvx, h16, sw);
+    }
+    if (v.TMAX == 256) return pick_align<256, 16>(cvx, h16, sw);
+    if (v.TMAX == 512) return pick_align<512, 16>(cvx, h16, sw);
+    return pick_align<1024, 16>(cvx, h16, sw);
 }
 
 // Is an int16 H safe for the packed row words?  |H| bound: SW 0..m*L; NW additionally the
@@ -380,14 +407,21 @@ struct DevBuf {
 };
 
 struct BlockMeta {
-    int maxlen = 0, nseq = 0, variant = -1;
+    int maxlen = 0, nseq = 0; bool fits = false; Variant variant{16, 1, 256};
     int64_t sumlen = 0;
     double cost = 0;
     bool cvx = false, sw = true;
     Scoring S;
 };
 
+struct PlanRes {
+    DevBuf arena, work, queue;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
 struct sxg_poa_handle {
+    std::vector<PlanRes*> planres;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -449,6 +483,13 @@ extern "C" void sxg_poa_destroy(sxg_poa_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     release_all(h);
+    for (PlanRes* r : h->planres) {
+        r->arena.release(); r->work.release(); r->queue.release();
+        if (r->e0) (void)hipEventDestroy(r->e0);
+        if (r->e1) (void)hipEventDestroy(r->e1);
+        if (r->stream) (void)hipStreamDestroy(r->stream);
+        delete r;
+    }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -470,7 +511,8 @@ extern "C" int sxg_poa_get_stats(sxg_poa_handle* h, sxg_poa_stats* out) {
 static uint64_t arena_budget(sxg_poa_handle* h) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 8ull << 30;
-    uint64_t avail = (uint64_t)fr + h->d_arena.cap;  // the arena we already hold can be reused
+    uint64_t avail = (uint64_t)fr + h->d_arena.cap;  // the arenas we already hold can be reused
+    for (PlanRes* r : h->planres) avail += r->arena.cap;
     uint64_t b = avail / 4 * 3;
     if (h->mem_budget && h->mem_budget < b) b = h->mem_budget;
     return b;
@@ -521,7 +563,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
             if (s > in->blk_off[b]) m.cost += (double)len * (l1 + 0.05 * prev);
             prev += (double)len;
         }
-        m.variant = variant_for_len(m.maxlen);
+        m.fits = variant_for_len(m.maxlen, &m.variant);
     }
     // sanitise letters while copying to a staging buffer
     std::vector<uint8_t> stage((size_t)std::max<int64_t>(nbases, 1));
@@ -555,53 +597,61 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
 }
 
 struct LaunchPlan {
-    int variant; bool cvx, h16;
+    Variant variant; bool cvx, h16, sw;
     std::vector<int32_t> work;  // block ids, largest cost first
+    // filled by prepare_plan
+    SlotLayout lay; KernelFn<BlockArgs> kern = nullptr; int per_cu = 1; int64_t want_slots = 0, n_slots = 0;
+    int smem = 0; bool park_lds = true; uint64_t cells = 0, bytes = 0; float ms = 0;
 };
 
-static int run_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt, float* ms_total) {
-    const Variant V = kVariants[P.variant];
-    const int Lpad = V.T * V.W;
+static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
+    const Variant V = P.variant;
+    const int Lpad = V.Lpad();
     int nodes_cap = 0, maxlen = 0;
     for (int b : P.work) {
         nodes_cap = (int)std::max<int64_t>(nodes_cap, h->meta[b].sumlen);
         maxlen = std::max(maxlen, h->meta[b].maxlen);
     }
     nodes_cap += 8;
-    int rows_cap, pool_slots, tbx16_cap, tbx32_cap;
+    int rows_cap, pool_slots, step_cap;
     if (attempt == 0) {
         rows_cap = std::min(nodes_cap, 2 * maxlen + 1024);
         pool_slots = std::min(rows_cap + 1, 768);
-        tbx16_cap = rows_cap / 2 + 64;
-        tbx32_cap = 16;
+        step_cap = rows_cap;
     } else if (attempt == 1) {
         rows_cap = std::min(nodes_cap, 6 * maxlen + 4096);
         pool_slots = std::min(rows_cap + 1, 8192);
-        tbx16_cap = rows_cap;
-        tbx32_cap = 256;
+        step_cap = 4 * rows_cap;
     } else {
-        rows_cap = nodes_cap; pool_slots = rows_cap + 1; tbx16_cap = rows_cap; tbx32_cap = rows_cap;
+        rows_cap = nodes_cap; pool_slots = rows_cap + 1; step_cap = nodes_cap;  // edges <= nodes_cap
     }
     if (rows_cap >= (1 << 20)) rows_cap = (1 << 20) - 1;
-    const SlotLayout lay = make_layout(nodes_cap, rows_cap, pool_slots, tbx16_cap, tbx32_cap, Lpad, P.h16 ? 4 : 8, false);
-    auto kern = block_kernel(P.variant, P.cvx, P.h16);
-    int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, V.T, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    const uint64_t budget = arena_budget(h);
-    int64_t n_slots = std::min<int64_t>((int64_t)P.work.size(), (int64_t)h->num_cu * per_cu);
-    n_slots = std::min<int64_t>(n_slots, (int64_t)(budget / lay.total));
-    if (n_slots < 1) return fail(SXG_E_NOMEM, "memory budget too small for a single block arena (" + std::to_string(lay.total) + " bytes)");
+    const int wb = P.h16 ? 4 : 8;
+    P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false);
+    P.kern = block_kernel(P.variant, P.cvx, P.h16, P.sw);
+    P.smem = dp_lds_launch_bytes(Lpad, wb);
+    P.park_lds = dp_park_in_lds(Lpad, wb);
+    if (P.smem > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)P.kern, hipFuncAttributeMaxDynamicSharedMemorySize, P.smem);
+    P.per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&P.per_cu, (const void*)P.kern, V.T(), (size_t)P.smem) != hipSuccess || P.per_cu < 1)
+        P.per_cu = 1;
+    P.want_slots = std::min<int64_t>((int64_t)P.work.size(), (int64_t)h->num_cu * P.per_cu);
+}
+
+static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
+    const Variant V = P.variant;
     int rc;
-    if ((rc = h->d_arena.ensure((size_t)n_slots * lay.total))) return rc;
-    if ((rc = h->d_work.ensure(4 * P.work.size()))) return rc;
-    HIPCHK(hipMemcpyAsync(h->d_work.p, P.work.data(), 4 * P.work.size(), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->d_queue.p, 0, 4, h->stream));
+    if ((rc = R.arena.ensure((size_t)P.n_slots * P.lay.total))) return rc;
+    if ((rc = R.work.ensure(4 * P.work.size())) || (rc = R.queue.ensure(256))) return rc;
+    HIPCHK(hipMemcpyAsync(R.work.p, P.work.data(), 4 * P.work.size(), hipMemcpyHostToDevice, R.stream));
+    HIPCHK(hipMemsetAsync(R.queue.p, 0, 4, R.stream));
     BlockArgs A;
     A.blk_off = h->d_blk_off.as<int32_t>(); A.seq_off = h->d_seq_off.as<int64_t>(); A.bases = h->d_bases.as<uint8_t>();
     A.weights = h->has_weights ? h->d_weights.as<uint32_t>() : nullptr;
     A.params = h->d_params.as<sxg_poa_params>(); A.per_block_params = h->per_block_params;
-    A.work = h->d_work.as<int32_t>(); A.n_work = (int)P.work.size(); A.queue = h->d_queue.as<int32_t>();
-    A.arena = h->d_arena.as<uint8_t>(); A.lay = lay;
+    A.work = R.work.as<int32_t>(); A.n_work = (int)P.work.size(); A.queue = R.queue.as<int32_t>();
+    A.arena = R.arena.as<uint8_t>(); A.lay = P.lay;
     A.status = h->d_status.as<int32_t>(); A.n_nodes = h->d_nn.as<int32_t>(); A.n_edges = h->d_ne.as<int32_t>();
     A.n_cons = h->d_nc.as<int32_t>(); A.node_code = h->d_node_code.as<uint8_t>();
     A.node_rank = h->d_node_rank.as<int32_t>(); A.node_group = h->d_node_group.as<int32_t>();
@@ -609,17 +659,36 @@ static int run_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt, float* ms_tot
     A.edge_weight = h->d_edge_w.as<uint32_t>(); A.paths = h->d_paths.as<int32_t>(); A.score = h->d_score.as<int32_t>();
     A.cells = h->d_cells.as<unsigned long long>(); A.cons_nodes = h->d_cons.as<int32_t>();
     A.want_consensus = h->want_consensus;
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_slots), dim3(V.T), 0, h->stream, A);
+    A.park_in_lds = P.park_lds ? 1 : 0;
+    const bool dbg = getenv("SXG_POA_DEBUG") != nullptr;
+    if (dbg)
+        for (int64_t sl = 0; sl < P.n_slots; ++sl)
+            HIPCHK(hipMemsetAsync(R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr, 0, 256, R.stream));
+    HIPCHK(hipStreamWaitEvent(R.stream, h->ev0, 0));
+    HIPCHK(hipEventRecord(R.e0, R.stream));
+    hipLaunchKernelGGL(P.kern, dim3((unsigned)P.n_slots), dim3(V.T()), (size_t)P.smem, R.stream, A);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    *ms_total += ms;
-    h->stats.dp_launches += 1;
-    h->stats.n_slots = std::max<int>(h->stats.n_slots, (int)n_slots);
-    h->stats.device_bytes = std::max<uint64_t>(h->stats.device_bytes, (uint64_t)n_slots * lay.total);
+    HIPCHK(hipEventRecord(R.e1, R.stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, R.e1, 0));
+    return SXG_OK;
+}
+
+static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt) {
+    const Variant V = P.variant;
+    unsigned long long acc[8] = {0};
+    for (int64_t sl = 0; sl < P.n_slots; ++sl) {
+        unsigned long long one[8];
+        HIPCHK(hipMemcpy(one, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64, 64, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; ++k) acc[k] += one[k];
+    }
+    double tot = 1e-9;
+    for (int k = 0; k < 6; ++k) tot += (double)acc[k];
+    size_t fr = 0, tt = 0;
+    (void)hipMemGetInfo(&fr, &tt);
+    fprintf(stderr, "[sxg] variant T=%d W=%d cvx=%d h16=%d attempt=%d work=%zu slots=%lld per_cu=%d smem=%d slot_bytes=%zu free=%zu ms=%.2f\n",
+            V.T(), V.W, (int)P.cvx, (int)P.h16, attempt, P.work.size(), (long long)P.n_slots, P.per_cu, P.smem, P.lay.total, fr, P.ms);
+    fprintf(stderr, "[sxg]   slot time: other %.1f%% prep_rows %.1f%% dp_fill %.1f%% traceback %.1f%% add_alignment %.1f%% output %.1f%%\n",
+            100 * acc[0] / tot, 100 * acc[1] / tot, 100 * acc[2] / tot, 100 * acc[3] / tot, 100 * acc[4] / tot, 100 * acc[5] / tot);
     return SXG_OK;
 }
 
@@ -628,13 +697,21 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
     if (!h->have_batch) return fail(SXG_E_INVALID, "no batch uploaded");
     HIPCHK(hipSetDevice(h->device));
     h->stats = sxg_poa_stats{};
+    const bool dbg = getenv("SXG_POA_DEBUG") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        auto T1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sxg] host %-18s %.3f ms\n", what, std::chrono::duration<double, std::milli>(T1 - T0).count());
+        T0 = T1;
+    };
     const int nb = h->n_blocks;
     std::vector<int32_t> status(std::max(nb, 1), 0);
     float ms_total = 0;
     // blocks whose longest sequence exceeds the largest variant fail up front
     std::vector<int32_t> pending;
     for (int b = 0; b < nb; ++b) {
-        if (h->meta[b].variant < 0) status[b] = ST_TOO_LONG; else pending.push_back(b);
+        if (!h->meta[b].fits) status[b] = ST_TOO_LONG; else pending.push_back(b);
     }
     if (nb) HIPCHK(hipMemcpyAsync(h->d_status.p, status.data(), 4 * (size_t)nb, hipMemcpyHostToDevice, h->stream));
     if (nb) {
@@ -642,8 +719,10 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         HIPCHK(hipMemsetAsync(h->d_ne.p, 0, 4 * (size_t)nb, h->stream));
         HIPCHK(hipMemsetAsync(h->d_nc.p, 0, 4 * (size_t)nb, h->stream));
     }
+    lap("setup");
+    std::vector<LaunchPlan> all_plans;
     for (int attempt = 0; attempt < 3 && !pending.empty(); ++attempt) {
-        // group by (variant, convex, h16)
+        // group by (variant, convex, h16): one launch per group, all groups concurrently
         std::vector<LaunchPlan> plans;
         for (int b : pending) {
             const BlockMeta& m = h->meta[b];
@@ -651,28 +730,64 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             const bool h16 = h16_safe(m.S, m.maxlen, rows_max);
             LaunchPlan* pl = nullptr;
             for (auto& q : plans)
-                if (q.variant == m.variant && q.cvx == m.cvx && q.h16 == h16) { pl = &q; break; }
-            if (!pl) { plans.push_back(LaunchPlan{m.variant, m.cvx, h16, {}}); pl = &plans.back(); }
+                if (q.variant.W == m.variant.W && q.variant.NW == m.variant.NW && q.cvx == m.cvx && q.h16 == h16 && q.sw == m.sw) { pl = &q; break; }
+            if (!pl) { plans.emplace_back(); pl = &plans.back(); pl->variant = m.variant; pl->cvx = m.cvx; pl->h16 = h16; pl->sw = m.sw; }
             pl->work.push_back(b);
         }
-        std::sort(plans.begin(), plans.end(), [](const LaunchPlan& a, const LaunchPlan& b) { return a.variant > b.variant; });
+        std::sort(plans.begin(), plans.end(), [](const LaunchPlan& a, const LaunchPlan& b) { return a.variant.Lpad() > b.variant.Lpad(); });
+        const uint64_t budget = arena_budget(h);
+        uint64_t want_bytes = 0;
         for (auto& pl : plans) {
-            std::stable_sort(pl.work.begin(), pl.work.end(),
-                             [&](int a, int b) { return h->meta[a].cost > h->meta[b].cost; });
-            int rc = run_plan(h, pl, attempt, &ms_total);
+            std::stable_sort(pl.work.begin(), pl.work.end(), [&](int a, int b) { return h->meta[a].cost > h->meta[b].cost; });
+            prepare_plan(h, pl, attempt);
+            want_bytes += (uint64_t)pl.want_slots * pl.lay.total;
+        }
+        const double scale = want_bytes > budget ? (double)budget / (double)want_bytes : 1.0;
+        while (h->planres.size() < plans.size()) {
+            PlanRes* r = new PlanRes();
+            HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreate(&r->e0));
+            HIPCHK(hipEventCreate(&r->e1));
+            h->planres.push_back(r);
+        }
+        for (auto& pl : plans) {
+            pl.n_slots = std::max<int64_t>(1, (int64_t)(pl.want_slots * scale));
+            if ((uint64_t)pl.lay.total > budget)
+                return fail(SXG_E_NOMEM, "memory budget too small for a single block arena (" + std::to_string(pl.lay.total) + " bytes)");
+        }
+        lap("plan");
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        for (size_t i = 0; i < plans.size(); ++i) {
+            int rc = launch_plan(h, plans[i], *h->planres[i]);
             if (rc) return rc;
         }
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        ms_total += ms;
+        for (size_t i = 0; i < plans.size(); ++i) {
+            HIPCHK(hipEventElapsedTime(&plans[i].ms, h->planres[i]->e0, h->planres[i]->e1));
+            h->stats.dp_launches += 1;
+            h->stats.n_slots += (int)plans[i].n_slots;
+            h->stats.device_bytes += (uint64_t)plans[i].n_slots * plans[i].lay.total;
+            if (dbg) debug_plan(h, plans[i], *h->planres[i], attempt);
+        }
+        lap("launches");
         HIPCHK(hipMemcpy(status.data(), h->d_status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
         std::vector<int32_t> again;
         for (int b : pending)
             if (status[b] == ST_ROWS_OVERFLOW || status[b] == ST_POOL_OVERFLOW || status[b] == ST_TBX_OVERFLOW) again.push_back(b);
         if (attempt < 2) h->stats.retries += (int)again.size();
         pending.swap(again);
+        for (auto& pl : plans) all_plans.push_back(std::move(pl));
     }
+    lap("status");
     // accounting
     std::vector<unsigned long long> cells((size_t)std::max<int64_t>(h->n_seqs, 1));
     if (h->n_seqs) HIPCHK(hipMemcpy(cells.data(), h->d_cells.p, 8 * (size_t)h->n_seqs, hipMemcpyDeviceToHost));
     uint64_t total = 0, bytes = 0;
+    std::vector<uint64_t> blk_cells(std::max(nb, 1), 0), blk_bytes(std::max(nb, 1), 0);
     for (int b = 0; b < nb; ++b) {
         if (status[b] != ST_OK) continue;
         uint64_t cb = 0;
@@ -681,9 +796,19 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         const int ncross = m.S.convex ? 3 : (m.S.g == m.S.e ? 1 : 2);
         const int rows_max = (int)std::min<int64_t>(m.sumlen + 8, (1 << 20) - 1);
         const int sz = h16_safe(m.S, m.maxlen, rows_max) ? 2 : 4;
+        blk_cells[b] = cb; blk_bytes[b] = cb * (uint64_t)(2 * ncross * sz + 1);
         total += cb;
-        bytes += cb * (uint64_t)(2 * ncross * sz + 1);
+        bytes += blk_bytes[b];
     }
+    // dominant launch = the one that evaluated the most cells
+    for (auto& pl : all_plans) {
+        for (int b : pl.work) if (status[b] == ST_OK) { pl.cells += blk_cells[b]; pl.bytes += blk_bytes[b]; }
+        if (pl.cells >= h->stats.dom_cells) {
+            h->stats.dom_cells = pl.cells; h->stats.dom_algo_bytes = pl.bytes; h->stats.dom_kernel_ms = pl.ms;
+            h->stats.dom_threads = pl.variant.T(); h->stats.dom_cols_per_lane = pl.variant.W;
+        }
+    }
+    lap("accounting");
     h->stats.kernel_ms = ms_total;
     h->stats.cells = total;
     h->stats.algo_bytes = bytes;
@@ -921,36 +1046,38 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         if (ne) HCK(hipMemcpy(d_preds.p, in->preds, 4 * (size_t)ne, hipMemcpyHostToDevice));
         if (nbases) HCK(hipMemcpy(d_bases.p, stage.data(), (size_t)nbases, hipMemcpyHostToDevice));
         HCK(hipMemset(d_status.p, 0, 4 * (size_t)n)); HCK(hipMemset(d_score.p, 0, 4 * (size_t)n)); HCK(hipMemset(d_np.p, 0, 4 * (size_t)n));
+        HCK(hipMemset(d_pr.p, 0xEE, 4 * outcap)); HCK(hipMemset(d_pp.p, 0xEE, 4 * outcap));
     }
     // plans
-    struct APlan { int variant; bool cvx, h16; std::vector<int32_t> work; int rows_cap = 0; };
+    struct APlan { Variant variant; bool cvx, h16, sw; std::vector<int32_t> work; int rows_cap = 0; };
     std::vector<APlan> plans;
     for (int p = 0; p < n; ++p) {
         const Scoring S = normalise(in->params[in->per_problem_params ? p : 0]);
         const int len = (int)(in->seq_off[p + 1] - in->seq_off[p]), N = (int)(in->row_off[p + 1] - in->row_off[p]);
-        const int v = variant_for_len(len);
-        if (v < 0) { o->status[p] = ST_TOO_LONG; continue; }
+        Variant v;
+        if (!variant_for_len(len, &v)) { o->status[p] = ST_TOO_LONG; continue; }
         const bool h16 = h16_safe(S, len, N);
         APlan* pl = nullptr;
-        for (auto& q : plans) if (q.variant == v && q.cvx == (bool)S.convex && q.h16 == h16) { pl = &q; break; }
-        if (!pl) { plans.push_back(APlan{v, (bool)S.convex, h16, {}, 0}); pl = &plans.back(); }
+        for (auto& q : plans)
+            if (q.variant.W == v.W && q.variant.NW == v.NW && q.cvx == (bool)S.convex && q.h16 == h16 && q.sw == (bool)S.sw) { pl = &q; break; }
+        if (!pl) { plans.push_back(APlan{v, (bool)S.convex, h16, (bool)S.sw, {}, 0}); pl = &plans.back(); }
         pl->work.push_back(p);
         pl->rows_cap = std::max(pl->rows_cap, N);
     }
     if (n) HCK(hipMemcpy(d_status.p, o->status.data(), 4 * (size_t)n, hipMemcpyHostToDevice));
     for (auto& pl : plans) {
-        const Variant V = kVariants[pl.variant];
+        const Variant V = pl.variant;
         const int rows_cap = pl.rows_cap + 1;
-        const SlotLayout lay = make_layout(8, rows_cap, rows_cap + 1, rows_cap, rows_cap, V.T * V.W, pl.h16 ? 4 : 8, true);
-        SlotLayout lay2 = lay;
-        // r_preds is sized by nodes_cap in make_layout; the align path needs the edge count instead
         int64_t maxe = 0;
         for (int p : pl.work) maxe = std::max<int64_t>(maxe, in->pred_off[in->row_off[p + 1]] - in->pred_off[in->row_off[p]]);
-        lay2 = make_layout((int)std::max<int64_t>(maxe + 8, rows_cap + 8), rows_cap, rows_cap + 1, rows_cap, rows_cap, V.T * V.W,
-                           pl.h16 ? 4 : 8, true);
-        auto kern = align_kernel(pl.variant, pl.cvx, pl.h16);
+        // r_preds is sized by nodes_cap in make_layout: give it the edge count
+        const SlotLayout lay2 = make_layout((int)std::max<int64_t>(maxe + 8, rows_cap + 8), rows_cap, rows_cap + 1,
+                                            (int)maxe + 8, V.T(), V.Lpad(), pl.h16 ? 4 : 8, true);
+        auto kern = align_kernel(pl.variant, pl.cvx, pl.h16, pl.sw);
         int per_cu = 1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, V.T, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        const int smem = dp_lds_launch_bytes(V.Lpad(), pl.h16 ? 4 : 8);
+        if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, V.T(), (size_t)smem) != hipSuccess || per_cu < 1) per_cu = 1;
         const uint64_t budget = arena_budget(h);
         int64_t n_slots = std::min<int64_t>((int64_t)pl.work.size(), (int64_t)h->num_cu * per_cu);
         n_slots = std::min<int64_t>(n_slots, (int64_t)(budget / lay2.total));
@@ -966,7 +1093,8 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         A.arena = d_arena.as<uint8_t>(); A.lay = lay2;
         A.status = d_status.as<int32_t>(); A.score = d_score.as<int32_t>(); A.n_pairs = d_np.as<int32_t>();
         A.pair_row = d_pr.as<int32_t>(); A.pair_pos = d_pp.as<int32_t>();
-        hipLaunchKernelGGL(kern, dim3((unsigned)n_slots), dim3(V.T), 0, h->stream, A);
+        A.park_in_lds = dp_park_in_lds(V.Lpad(), pl.h16 ? 4 : 8) ? 1 : 0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_slots), dim3(V.T()), (size_t)smem, h->stream, A);
         HCK(hipGetLastError());
         HCK(hipStreamSynchronize(h->stream));
     }
@@ -977,6 +1105,19 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         HCK(hipMemcpy(npairs.data(), d_np.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
         HCK(hipMemcpy(pr.data(), d_pr.p, 4 * outcap, hipMemcpyDeviceToHost));
         HCK(hipMemcpy(pp.data(), d_pp.p, 4 * outcap, hipMemcpyDeviceToHost));
+    }
+    if (getenv("SXG_POA_DEBUG")) {
+        for (int p = 0; p < n; ++p)
+            fprintf(stderr, "[sxg] align p=%d s0=%lld npairs=%d N=%lld L=%lld\n", p, (long long)(in->row_off[p] + in->seq_off[p]), npairs[p],
+                    (long long)(in->row_off[p + 1] - in->row_off[p]), (long long)(in->seq_off[p + 1] - in->seq_off[p]));
+        size_t i = 0;
+        while (i < outcap) {
+            if ((unsigned)pr[i] == 0xEEEEEEEEu) { ++i; continue; }
+            size_t j = i;
+            while (j < outcap && (unsigned)pr[j] != 0xEEEEEEEEu) ++j;
+            fprintf(stderr, "[sxg] written range [%zu, %zu) first=(%d,%d)\n", i, j, pr[i], pp[i]);
+            i = j;
+        }
     }
     for (int p = 0; p < n; ++p) o->pair_off[p + 1] = o->pair_off[p] + npairs[p];
     o->pair_row.resize((size_t)std::max<int64_t>(o->pair_off[n], 1)); o->pair_pos.resize(o->pair_row.size());

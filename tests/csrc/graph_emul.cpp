@@ -41,10 +41,10 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
                 eni.data(), eno.data(), ew.data(), posn.data(), tgt.data(), nidx.data(), nxa.data(),
                 pva.data(), sla.data(), kd.data()};
     std::vector<uint8_t> rcode(C), rflags(C), sink(C);
-    std::vector<int32_t> poff(C + 1), preds(C), slot(C), tbx(C), sseq(C + 1), rnode(C);
+    std::vector<int32_t> poff(C + 1), preds(C), slot(C), tbx(C), sseq(C + 1), rnode(C), meta(8 * C);
     RowsView R{rcode.data(), rflags.data(), poff.data(), preds.data(), slot.data(), tbx.data(), sseq.data(),
-               rnode.data()};
-    RowCaps caps{(int)C, pool_slots, (int)C, (int)C};
+               rnode.data(), meta.data()};
+    RowCaps caps{(int)C, pool_slots, (int)C};
     SerialCtx c;
     std::vector<int32_t> an(2 * C), ap(2 * C);
     for (int s = 0; s < n_seqs; ++s) {
