@@ -51,7 +51,7 @@ extern "C" {
 #define SXG_ST_NODES_OVERFLOW 4
 #define SXG_ST_TOO_LONG 5 /* a sequence exceeds SXG_POA_MAX_SEQ_LEN */
 
-#define SXG_POA_MAX_SEQ_LEN 16383
+#define SXG_POA_MAX_SEQ_LEN 12287
 
 /* The six scores + alignment type that smooth_spoa hands to
  * spoa::AlignmentEngine::Create (src/smooth.cpp:752-755).                                */

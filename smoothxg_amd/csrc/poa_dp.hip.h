@@ -143,7 +143,20 @@ __host__ __device__ constexpr int dp_lds_launch_bytes(int Lpad, int word_bytes) 
 // candidates of every column alive to derive the traceback bits later (measured: ~17 VGPRs per
 // column instead of ~6) and the kernel drops to one wave per SIMD or spills.
 #define SXG_PIN(...) asm volatile("" : __VA_ARGS__)
-#define SXG_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define SXG_FENCE() do {} while (0)
+// columns are pinned in groups of SXG_G (a multiple of the unroll step that divides W): inside a
+// group the scheduler may interleave the columns' dependent chains, across groups it may not
+#ifndef SXG_G
+#define SXG_G 4
+#endif
+#if SXG_G == 1
+#define SXG_COLS(a, k) "+v"(a[k])
+#elif SXG_G == 2
+#define SXG_COLS(a, k) "+v"(a[(k) - 1]), "+v"(a[k])
+#else
+#define SXG_COLS(a, k) "+v"(a[(k) - 3]), "+v"(a[(k) - 2]), "+v"(a[(k) - 1]), "+v"(a[k])
+#endif
+#define SXG_GROUP_END(k) (((k) % SXG_G) == SXG_G - 1)
 
 // T (= blockDim.x, a multiple of 64) is a run-time value: one compiled kernel serves every
 // strip count, the host picks T = 64 * ceil((L+1) / (64*W)).
@@ -248,15 +261,16 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
         Fp[k] = x1_ ? c2_ : c1_;                                                    \
         fxm |= (unsigned)x1_ << (k);                                                \
         if (CVX) { Op[k] = x2_ ? d2_ : d1_; oxm |= (unsigned)x2_ << (k); }          \
-        SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm));       \
     } while (0)
+#define SXG_PIN_INIT(k) \
+    if (SXG_GROUP_END(k)) SXG_PIN(SXG_COLS(Hc, k), SXG_COLS(Fp, k), SXG_COLS(Op, k), "+v"(fxm), "+v"(oxm))
 
         if (np <= 1 && p0 == i - 1) {
             // ---- the single predecessor is the row in registers: update F and O in place
 #pragma unroll
             for (int k = 0; k < W; ++k) {
                 SXG_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
-                if ((k & 1) == 1) SXG_FENCE();
+                SXG_PIN_INIT(k);
             }
         } else {
             // ---- general row.  Sources are folded one at a time: the first one initialises the
@@ -278,7 +292,7 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     SXG_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
-                    if ((k & 1) == 1) SXG_FENCE();
+                    SXG_PIN_INIT(k);
                 }
             } else {
                 Word wr[W];
@@ -298,8 +312,7 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
                     RWt::unpack(wr[k], hs, fs, os);
                     SXG_INIT(k, hs, fs, os, hl);
                     hl = hs;
-                    SXG_PIN("+v"(hl));
-                    if ((k & 1) == 1) SXG_FENCE();
+                    SXG_PIN_INIT(k);
                 }
             }
             // ---- further sources, one fold step each
@@ -349,14 +362,15 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
                     Hc[k] = rd ? hl : Hc[k];
                     dm ^= (unsigned)rd << k;
                     hl = hs;
-                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm), "+v"(dm), "+v"(fmk), "+v"(omk), "+v"(hl));
-                    if ((k & 1) == 1) SXG_FENCE();
+                    if (SXG_GROUP_END(k))
+                        SXG_PIN(SXG_COLS(Hc, k), SXG_COLS(Fp, k), SXG_COLS(Op, k), "+v"(fxm), "+v"(oxm), "+v"(dm), "+v"(fmk), "+v"(omk), "+v"(hl));
                 }
                 uint32_t* st = B.steps + ((size_t)(tx + x - 1) * 3) * T + t;
                 st[0] = dm; st[T] = fmk; st[2 * T] = omk;
             }
         }
 #undef SXG_INIT
+#undef SXG_PIN_INIT
         if (!CVX) {
 #pragma unroll
             for (int k = 0; k < W; ++k) Op[k] = NEG;
@@ -375,8 +389,7 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
             const int hc = SW ? max(h, 0) : h;
             a = max(a + e, hc + g);
             if (CVX) b = max(b + c, hc + q);
-            SXG_PIN("+v"(Hc[k]), "+v"(fm), "+v"(om), "+v"(a), "+v"(b));
-            if ((k & 1) == 1) SXG_FENCE();
+            if (SXG_GROUP_END(k)) SXG_PIN(SXG_COLS(Hc, k), "+v"(fm), "+v"(om), "+v"(a), "+v"(b));
         }
         fm &= ~om;
         // carries: Ein(t) = max_{s<t} (a_s + (t-1-s)*W*e)
@@ -422,8 +435,7 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
             const int c1 = h + g, c2 = E + e;
             ebit = c2 > c1; E = ebit ? c2 : c1;
             if (CVX) { const int d1 = h + q, d2 = Q + c; qbit = d2 > d1; Q = qbit ? d2 : d1; }
-            SXG_PIN("+v"(Hc[k]), "+v"(tbw[k >> 2]), "+v"(E), "+v"(Q), "+v"(ebit), "+v"(qbit), "+v"(rowkey));
-            if ((k & 1) == 1) SXG_FENCE();
+            if (SXG_GROUP_END(k)) SXG_PIN(SXG_COLS(Hc, k), "+v"(tbw[k >> 2]), "+v"(E), "+v"(Q), "+v"(ebit), "+v"(qbit), "+v"(rowkey));
         }
         if (SW) {
             if ((rowkey >> 5) > best) { best = rowkey >> 5; bi = i; bj = 31 - (rowkey & 31); }

@@ -136,7 +136,7 @@ struct BlockArgs {
 // value), W = columns per lane.  The second launch-bound is the number of waves per SIMD the
 // register allocator must leave room for: 8 columns/lane need ~100 VGPRs (4 waves), 16 need
 // ~165 (3 waves); a 1024-thread workgroup is 4 waves per SIMD by itself.
-__host__ __device__ constexpr int sxg_min_waves(int TMAX, int W) { return (TMAX > 512 || W <= 8) ? 4 : 3; }
+__host__ __device__ constexpr int sxg_min_waves(int TMAX, int W) { return (TMAX > 512 || W <= 12) ? 4 : 3; }
 
 template <int TMAX, int W, bool CVX, bool H16, bool SW>
 __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_block_kernel(const BlockArgs A) {
@@ -324,15 +324,28 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 // A launch geometry: W columns per lane, NW waves (T = 64*NW), kernel class TMAX.
 struct Variant { int W, NW, TMAX; int T() const { return 64 * NW; } int Lpad() const { return 64 * NW * W; } };
 
-// Prefer 16 columns per lane (less per-row overhead) while the workgroup stays <= 512 threads;
-// beyond that 8 columns per lane keep the 1024-thread class inside 128 VGPRs.
+// Geometry choice.  Inside a workgroup all waves meet at two barriers per row, so the wave
+// count should load the four SIMDs of a CU evenly: 1, 2, 3, 4, 8, 12 or 16 waves.  Among the
+// (W, NW) pairs that cover the sequence pick the one with the fewest padded columns, then the
+// wider strip (less per-row overhead).  12 columns per lane is the widest strip that still fits
+// 128 VGPRs, i.e. four waves per SIMD (two 512-thread or four 256-thread workgroups per CU).
 static bool variant_for_len(int maxlen, Variant* v) {
+    static const int kNW[] = {1, 2, 3, 4, 8, 12, 16};
+    static const int kW[] = {16, 12, 8};
     const int need = maxlen + 1;
-    const int nw16 = (need + 64 * 16 - 1) / (64 * 16), nw8 = (need + 64 * 8 - 1) / (64 * 8);
-    if (nw16 <= 8) { *v = Variant{16, std::max(nw16, 1), nw16 <= 4 ? 256 : 512}; return true; }
-    if (nw8 <= 16) { *v = Variant{8, nw8, 1024}; return true; }
-    if (nw16 <= 16) { *v = Variant{16, nw16, 1024}; return true; }
-    return false;
+    long best_cols = -1;
+    for (int W : kW)
+        for (int NW : kNW) {
+            const long cols = 64L * NW * W;
+            if (cols < need) continue;
+            if (W == 16 && NW > 8) continue;  // 16 columns/lane needs ~165 VGPRs: not in a 1024-thread group
+            if (best_cols < 0 || cols < best_cols) {
+                best_cols = cols;
+                *v = Variant{W, NW, NW <= 4 ? 256 : (NW <= 8 ? 512 : 1024)};
+            }
+            break;  // larger NW for this W only adds padding
+        }
+    return best_cols >= 0;
 }
 
 template <class Args> using KernelFn = void (*)(const Args);
@@ -354,6 +367,11 @@ template <int TMAX, int W> static KernelFn<AlignArgs> pick_align(bool cvx, bool 
     return sw ? poa_align_kernel<TMAX, W, false, false, true> : poa_align_kernel<TMAX, W, false, false, false>;
 }
 static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool h16, bool sw) {
+    if (v.W == 12) {
+        if (v.TMAX == 256) return pick_block<256, 12>(cvx, h16, sw);
+        if (v.TMAX == 512) return pick_block<512, 12>(cvx, h16, sw);
+        return pick_block<1024, 12>(cvx, h16, sw);
+    }
     if (v.W == 8) {
         if (v.TMAX == 256) return pick_block<256, 8>(cvx, h16, sw);
         if (v.TMAX == 512) return pick_block<512, 8>(cvx, h16, sw);
@@ -361,9 +379,14 @@ static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool h16, bo
     }
     if (v.TMAX == 256) return pick_block<256, 16>(cvx, h16, sw);
     if (v.TMAX == 512) return pick_block<512, 16>(cvx, h16, sw);
-    return pick_block<1024, 16>(cvx, h16, sw);
+    return pick_block<512, 16>(cvx, h16, sw);
 }
 static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool h16, bool sw) {
+    if (v.W == 12) {
+        if (v.TMAX == 256) return pick_align<256, 12>(cvx, h16, sw);
+        if (v.TMAX == 512) return pick_align<512, 12>(cvx, h16, sw);
+        return pick_align<1024, 12>(cvx, h16, sw);
+    }
     if (v.W == 8) {
         if (v.TMAX == 256) return pick_align<256, 8>(cvx, h16, sw);
         if (v.TMAX == 512) return pick_align<512, 8>(cvx, h16, sw);
@@ -371,7 +394,7 @@ static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool h16, bo
     }
     if (v.TMAX == 256) return pick_align<256, 16>(cvx, h16, sw);
     if (v.TMAX == 512) return pick_align<512, 16>(cvx, h16, sw);
-    return pick_align<1024, 16>(cvx, h16, sw);
+    return pick_align<512, 16>(cvx, h16, sw);
 }
 
 // Is an int16 H safe for the packed row words?  |H| bound: SW 0..m*L; NW additionally the

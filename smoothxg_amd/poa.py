@@ -85,7 +85,7 @@ def load_library(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    so = _build.SO
+    so = os.environ.get("SXG_POA_LIB", _build.SO)  # override: A/B builds of the same source
     if not os.path.exists(so):
         if not build_if_missing:
             raise RuntimeError("libsxgpoa.so is missing: run `python -m smoothxg_amd.build`")
