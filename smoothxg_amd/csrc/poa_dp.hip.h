@@ -18,6 +18,8 @@
 
 namespace sxg {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------------------
 // workgroup context for poa_graph_dev.h
 struct WgCtx {
@@ -137,17 +139,24 @@ __host__ __device__ constexpr bool dp_park_in_lds(int Lpad, int word_bytes) {
 __host__ __device__ constexpr int dp_lds_launch_bytes(int Lpad, int word_bytes) {
     return dp_park_in_lds(Lpad, word_bytes) ? dp_lds_bytes(Lpad, word_bytes) : LDS_CTL_BYTES + LDS_META_BYTES;
 }
+// prefetch area: the packed words of one row + one 4-byte left value per lane; only when the
+// whole carve-up stays <= 64 KiB (two or more workgroups per CU)
+__host__ __device__ constexpr int dp_pf_bytes(int Lpad, int word_bytes, int threads) { return Lpad * word_bytes + threads * 4; }
+__host__ __device__ constexpr int dp_pf_offset(int Lpad, int word_bytes, int threads) {
+    return dp_lds_launch_bytes(Lpad, word_bytes) + dp_pf_bytes(Lpad, word_bytes, threads) <= 64 * 1024
+               ? dp_lds_launch_bytes(Lpad, word_bytes) : -1;
+}
 
 // Register discipline: every per-column result is pinned with an empty asm right where it is
 // produced and column pairs are fenced with sched_barrier.  Without this hipcc keeps the raw
 // candidates of every column alive to derive the traceback bits later (measured: ~17 VGPRs per
 // column instead of ~6) and the kernel drops to one wave per SIMD or spills.
+#define SXG_ROW_BARRIER() __syncthreads()
 #define SXG_PIN(...) asm volatile("" : __VA_ARGS__)
-#define SXG_FENCE() do {} while (0)
 // columns are pinned in groups of SXG_G (a multiple of the unroll step that divides W): inside a
 // group the scheduler may interleave the columns' dependent chains, across groups it may not
 #ifndef SXG_G
-#define SXG_G 4
+#define SXG_G 1  // measured on MI355X: 1, 2 and 4 run within 1 %; 1 never spills
 #endif
 #if SXG_G == 1
 #define SXG_COLS(a, k) "+v"(a[k])
@@ -163,7 +172,7 @@ __host__ __device__ constexpr int dp_lds_launch_bytes(int Lpad, int word_bytes) 
 template <int W, bool CVX, bool H16, bool SW>
 __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, const int N,
                         const uint8_t* __restrict__ seq, const int L, const DpBuffers& B,
-                        char* smem, const bool park_in_lds, DpResult& res) {
+                        char* smem, const bool park_in_lds, const int pf_off, DpResult& res) {
     static_assert(W % 4 == 0 && W <= 24, "W must be a multiple of 4, at most 24");
     const int T = (int)blockDim.x;
     const int NW = T >> 6;
@@ -177,6 +186,15 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
     Word* lrow = park_in_lds ? (Word*)(smem + LDS_CTL_BYTES + LDS_META_BYTES) : (Word*)B.park;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int j0 = t * W;
+    // LDS-DMA prefetch area (pf_off < 0: disabled): the stored row the NEXT graph row will fold
+    // first is fetched with global_load_lds while the current row computes, so its HBM/L2
+    // latency hides behind ~10k cycles of work.  Piece c of lane t lives at c*T*16 + t*16.
+    constexpr int PF_PIECES = W * (int)sizeof(Word) / 16;
+    // addressed as raw LDS offsets (address space 3): dynamic LDS starts right after the static
+    // LDS of the kernel, no generic-pointer casts involved
+    const unsigned lds_pf = (unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)(pf_off >= 0 ? pf_off : 0);
+    const unsigned lds_pfl = lds_pf + (unsigned)PF_PIECES * (unsigned)T * 16u;  // [T] 4-byte H left of each strip
+    int pf_row = -1;                                                            // row whose words are (being) fetched
     const int g = S.g, e = S.e, q = S.q, c = S.c, mm = S.m, mn = S.n;
     const int We = W * e, Wc = W * c;
     int* tot_a = lds;        // [16]
@@ -250,6 +268,24 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
         int Hc[W];                  // first the best diagonal source, later the final H of this row
         unsigned fxm = 0, oxm = 0;  // "came from EXTEND" bit of F / O, one bit per column
 
+// my words of the prefetched row (each lane reads back only what its own DMA wrote, so the
+// wave's vmcnt is the only ordering needed)
+#define SXG_READ_PF(wr, hl)                                                                    \
+    do {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+        _Pragma("unroll") for (int c_ = 0; c_ < PF_PIECES; ++c_) {                             \
+            const u32x4 v_ = *(const __attribute__((address_space(3))) u32x4*)(size_t)(lds_pf + (unsigned)c_ * (unsigned)T * 16u + (unsigned)t * 16u); \
+            if (H16) {                                                                         \
+                *(unsigned*)&wr[4 * c_] = v_.x; *(unsigned*)&wr[4 * c_ + 1] = v_.y;            \
+                *(unsigned*)&wr[4 * c_ + 2] = v_.z; *(unsigned*)&wr[4 * c_ + 3] = v_.w;        \
+            } else {                                                                           \
+                *(uint2*)&wr[2 * c_] = make_uint2(v_.x, v_.y);                                 \
+                *(uint2*)&wr[2 * c_ + 1] = make_uint2(v_.z, v_.w);                             \
+            }                                                                                  \
+        }                                                                                      \
+        const unsigned l_ = *(const __attribute__((address_space(3))) unsigned*)(size_t)(lds_pfl + (unsigned)t * 4u); \
+        hl = j0 > 0 ? (H16 ? (int)(short)(l_ & 0xffffu) : (int)l_) : NEG;                      \
+    } while (0)
 // first source of a row: F/O/diag straight from (hs, fs, os, hprev)
 #define SXG_INIT(k, hs, fs, os, hprev)                                              \
     do {                                                                            \
@@ -300,6 +336,8 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
                 if (reg0) {  // parked copy of the register row
 #pragma unroll
                     for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
+                } else if (p0 == pf_row) {
+                    SXG_READ_PF(wr, hl);
                 } else {
                     const Word* sp = ((p0 == 0) ? (const Word*)B.row0 : (const Word*)B.pool + (size_t)s0 * Lpad) + j0;
 #pragma unroll
@@ -328,6 +366,8 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
                 if (p == i - 1) {  // only with three or more predecessors: the parked copy
 #pragma unroll
                     for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
+                } else if (p == pf_row) {
+                    SXG_READ_PF(wr, hl);
                 } else {
                     const Word* sp = ((p == 0) ? (const Word*)B.row0 : (const Word*)B.pool + (size_t)sl * Lpad) + j0;
 #pragma unroll
@@ -371,9 +411,38 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
         }
 #undef SXG_INIT
 #undef SXG_PIN_INIT
+#undef SXG_READ_PF
         if (!CVX) {
 #pragma unroll
             for (int k = 0; k < W; ++k) Op[k] = NEG;
+        }
+
+        // ---- start fetching what the NEXT row folds first (see pf_area above)
+        pf_row = -1;
+        if (pf_off >= 0 && i < N && (i & (META_CHUNK - 1)) != 0) {
+            const int4 n0 = lmeta[2 * (i & (META_CHUNK - 1))], n1 = lmeta[2 * (i & (META_CHUNK - 1)) + 1];
+            const int np1 = __builtin_amdgcn_readfirstlane(n0.y) & 0xffff;
+            const int q0 = __builtin_amdgcn_readfirstlane(n0.z), t0 = __builtin_amdgcn_readfirstlane(n0.w);
+            const int q1 = __builtin_amdgcn_readfirstlane(n1.x), t1 = __builtin_amdgcn_readfirstlane(n1.y);
+            const bool r0n = (q0 == i), r1n = (np1 == 2 && q1 == i);
+            int tp = -1, ts = -1;
+            if (np1 >= 3 || !(r0n || r1n)) { tp = q0; ts = t0; }               // first source lives in memory
+            else if (np1 == 2) { tp = r1n ? q0 : q1; ts = r1n ? t0 : t1; }     // register row first, then this one
+            if (tp == i) tp = -1;                                              // (parked copy of the register row)
+            if (tp >= 0) {
+                const char* src = (const char*)((tp == 0) ? (const Word*)B.row0 : (const Word*)B.pool + (size_t)ts * Lpad);
+                const char* mine = src + (size_t)j0 * sizeof(Word);
+                // the LDS side of the DMA is a wave-uniform base (M0) + lane * size
+                const unsigned wave0 = (unsigned)__builtin_amdgcn_readfirstlane(wv) * 64u;
+#pragma unroll
+                for (int c_ = 0; c_ < PF_PIECES; ++c_)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(mine + c_ * 16),
+                                                     (void __attribute__((address_space(3)))*)(size_t)(lds_pf + (unsigned)c_ * (unsigned)T * 16u + wave0 * 16u),
+                                                     16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(j0 > 0 ? mine - sizeof(Word) : mine),
+                                                 (void __attribute__((address_space(3)))*)(size_t)(lds_pfl + wave0 * 4u), 4, 0, 0);
+                pf_row = tp;
+            }
         }
 
         // ---- H before the in-row gaps, strip-local carries (pass 1)
@@ -401,7 +470,7 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
         }
         if (NW > 1) {
             if (lane == 63) { tot_a[wv] = ya; tot_b[wv] = yb; }
-            __syncthreads();  // B1
+            SXG_ROW_BARRIER();  // B1
             int ba = NEG * 2, bb = NEG * 2;
             for (int x = 0; x < wv; ++x) { ba = max(ba, tot_a[x]); bb = max(bb, tot_b[x]); }
             ya = max(ya, ba); yb = max(yb, bb);
@@ -450,7 +519,7 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
         int lh = __shfl_up(xh, 1), lb = __shfl_up(xb, 1);
         if (NW > 1) {
             if (lane == 63) { xch_h[wv] = xh; xch_b[wv] = xb; }
-            __syncthreads();  // B2
+            SXG_ROW_BARRIER();  // B2
             if (lane == 0 && wv > 0) { lh = xch_h[wv - 1]; lb = xch_b[wv - 1]; }
         }
         if (t == 0) { lh = NEG; lb = 0; }

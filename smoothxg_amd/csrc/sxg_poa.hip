@@ -130,6 +130,7 @@ struct BlockArgs {
     int32_t* paths; int32_t* score; unsigned long long* cells; int32_t* cons_nodes;
     int want_consensus;
     int park_in_lds;
+    int pf_off;  // byte offset of the LDS prefetch area, -1 = off
 };
 
 // Kernel classes <TMAX, W>: TMAX bounds blockDim.x (the actual T = 64 * strips is a run-time
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_block_kernel
                 if (status != ST_OK) break;
                 PROF(1);
                 DpResult res;
-                dp_fill<W, CVX, H16, SW>(S, V.R, N, seq, len, V.B, smem, A.park_in_lds != 0, res);
+                dp_fill<W, CVX, H16, SW>(S, V.R, N, seq, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 PROF(2);
                 if (t == 0 && res.bi >= 0)
@@ -228,6 +229,7 @@ struct AlignArgs {
     int32_t* status; int32_t* score; int32_t* n_pairs;
     int32_t* pair_row; int32_t* pair_pos;  // worst-case layout: problem p at row_off[p] + seq_off[p]
     int park_in_lds;
+    int pf_off;
 };
 
 template <int TMAX, int W, bool CVX, bool H16, bool SW>
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_align_kernel
             status = finish_rows(ctx, N, V.R, caps);
             if (status == ST_OK) {
                 DpResult res;
-                dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, res);
+                dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 if (t == 0 && res.bi >= 0) {
                     npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
@@ -624,7 +626,7 @@ struct LaunchPlan {
     std::vector<int32_t> work;  // block ids, largest cost first
     // filled by prepare_plan
     SlotLayout lay; KernelFn<BlockArgs> kern = nullptr; int per_cu = 1; int64_t want_slots = 0, n_slots = 0;
-    int smem = 0; bool park_lds = true; uint64_t cells = 0, bytes = 0; float ms = 0;
+    int smem = 0, pf_off = -1; bool park_lds = true; uint64_t cells = 0, bytes = 0; float ms = 0;
 };
 
 static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
@@ -654,6 +656,8 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     P.kern = block_kernel(P.variant, P.cvx, P.h16, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
+    P.pf_off = getenv("SXG_POA_PREFETCH") ? dp_pf_offset(Lpad, wb, V.T()) : -1;
+    if (P.pf_off >= 0) P.smem += dp_pf_bytes(Lpad, wb, V.T());
     if (P.smem > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)P.kern, hipFuncAttributeMaxDynamicSharedMemorySize, P.smem);
     P.per_cu = 1;
@@ -683,6 +687,7 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
     A.cells = h->d_cells.as<unsigned long long>(); A.cons_nodes = h->d_cons.as<int32_t>();
     A.want_consensus = h->want_consensus;
     A.park_in_lds = P.park_lds ? 1 : 0;
+    A.pf_off = P.pf_off;
     const bool dbg = getenv("SXG_POA_DEBUG") != nullptr;
     if (dbg)
         for (int64_t sl = 0; sl < P.n_slots; ++sl)
@@ -1069,7 +1074,7 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         if (ne) HCK(hipMemcpy(d_preds.p, in->preds, 4 * (size_t)ne, hipMemcpyHostToDevice));
         if (nbases) HCK(hipMemcpy(d_bases.p, stage.data(), (size_t)nbases, hipMemcpyHostToDevice));
         HCK(hipMemset(d_status.p, 0, 4 * (size_t)n)); HCK(hipMemset(d_score.p, 0, 4 * (size_t)n)); HCK(hipMemset(d_np.p, 0, 4 * (size_t)n));
-        HCK(hipMemset(d_pr.p, 0xEE, 4 * outcap)); HCK(hipMemset(d_pp.p, 0xEE, 4 * outcap));
+
     }
     // plans
     struct APlan { Variant variant; bool cvx, h16, sw; std::vector<int32_t> work; int rows_cap = 0; };
@@ -1098,7 +1103,9 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
                                             (int)maxe + 8, V.T(), V.Lpad(), pl.h16 ? 4 : 8, true);
         auto kern = align_kernel(pl.variant, pl.cvx, pl.h16, pl.sw);
         int per_cu = 1;
-        const int smem = dp_lds_launch_bytes(V.Lpad(), pl.h16 ? 4 : 8);
+        int smem = dp_lds_launch_bytes(V.Lpad(), pl.h16 ? 4 : 8);
+        const int pf_off = getenv("SXG_POA_PREFETCH") ? dp_pf_offset(V.Lpad(), pl.h16 ? 4 : 8, V.T()) : -1;
+        if (pf_off >= 0) smem += dp_pf_bytes(V.Lpad(), pl.h16 ? 4 : 8, V.T());
         if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, V.T(), (size_t)smem) != hipSuccess || per_cu < 1) per_cu = 1;
         const uint64_t budget = arena_budget(h);
@@ -1117,6 +1124,7 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         A.status = d_status.as<int32_t>(); A.score = d_score.as<int32_t>(); A.n_pairs = d_np.as<int32_t>();
         A.pair_row = d_pr.as<int32_t>(); A.pair_pos = d_pp.as<int32_t>();
         A.park_in_lds = dp_park_in_lds(V.Lpad(), pl.h16 ? 4 : 8) ? 1 : 0;
+        A.pf_off = pf_off;
         hipLaunchKernelGGL(kern, dim3((unsigned)n_slots), dim3(V.T()), (size_t)smem, h->stream, A);
         HCK(hipGetLastError());
         HCK(hipStreamSynchronize(h->stream));
@@ -1128,19 +1136,6 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         HCK(hipMemcpy(npairs.data(), d_np.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
         HCK(hipMemcpy(pr.data(), d_pr.p, 4 * outcap, hipMemcpyDeviceToHost));
         HCK(hipMemcpy(pp.data(), d_pp.p, 4 * outcap, hipMemcpyDeviceToHost));
-    }
-    if (getenv("SXG_POA_DEBUG")) {
-        for (int p = 0; p < n; ++p)
-            fprintf(stderr, "[sxg] align p=%d s0=%lld npairs=%d N=%lld L=%lld\n", p, (long long)(in->row_off[p] + in->seq_off[p]), npairs[p],
-                    (long long)(in->row_off[p + 1] - in->row_off[p]), (long long)(in->seq_off[p + 1] - in->seq_off[p]));
-        size_t i = 0;
-        while (i < outcap) {
-            if ((unsigned)pr[i] == 0xEEEEEEEEu) { ++i; continue; }
-            size_t j = i;
-            while (j < outcap && (unsigned)pr[j] != 0xEEEEEEEEu) ++j;
-            fprintf(stderr, "[sxg] written range [%zu, %zu) first=(%d,%d)\n", i, j, pr[i], pp[i]);
-            i = j;
-        }
     }
     for (int p = 0; p < n; ++p) o->pair_off[p + 1] = o->pair_off[p] + npairs[p];
     o->pair_row.resize((size_t)std::max<int64_t>(o->pair_off[n], 1)); o->pair_pos.resize(o->pair_row.size());

@@ -108,3 +108,65 @@ def test_invalid_arguments(engine):
     import smoothxg_amd as S
     with pytest.raises(S.PoaError):
         engine.run_blocks([[np.zeros(4, np.uint8)]], S.Params(1, 4, -6, -2, -26, -1, 0, 0))  # n > 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_long_sequences_every_kernel_class(engine, oracle, mode):
+    """Lengths that select the 256/512/1024-thread classes, all three strip widths and (in
+    global mode beyond ~7 kbp) the 32-bit row words."""
+    rng = np.random.default_rng(17 + mode)
+    blocks = [random_block(rng, 3, L, div=0.02) for L in (1500, 2500, 3500, 7000, 9000, 11500)]
+    res = engine.run_blocks(blocks, gparams("convex_default", mode))
+    for b, seqs in enumerate(blocks):
+        g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", mode))
+        assert_block_equal(res[b], g, sc, cells, label=f"long{len(seqs[0])}/mode{mode}")
+
+
+@pytest.mark.parametrize("pname", ["convex_default", "affine_4param"])
+def test_deep_divergent_block_many_predecessors(engine, oracle, pname):
+    """48 divergent sequences: rows with many predecessors (generic fold + parked register row)."""
+    rng = np.random.default_rng(23)
+    seqs = random_block(rng, 48, 120, div=0.25)
+    for mode in (0, 1):
+        g, sc, cells = oracle.block_run(seqs, None, oparams(pname, mode))
+        codes, off, pred, sink, _ = g.rows()
+        assert np.diff(off).max() >= 4
+        res = engine.run_blocks([seqs], gparams(pname, mode), want_consensus=True)
+        assert_block_equal(res[0], g, sc, cells, label=f"deep/{pname}/{mode}")
+        assert (res[0].consensus == g.consensus()).all()
+
+
+def test_lds_dma_prefetch_path_is_exact(engine, oracle, monkeypatch):
+    """SXG_POA_PREFETCH=1 turns on the global_load_lds prefetch of predecessor rows."""
+    monkeypatch.setenv("SXG_POA_PREFETCH", "1")
+    rng = np.random.default_rng(31)
+    blocks = [random_block(rng, 6, L, div=0.05) for L in (300, 900, 2000)]
+    for mode in (0, 1):
+        res = engine.run_blocks(blocks, gparams("convex_default", mode))
+        for b, seqs in enumerate(blocks):
+            g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", mode))
+            assert_block_equal(res[b], g, sc, cells, label=f"prefetch/{b}/{mode}")
+
+
+def test_north_star_shape_properties(engine, oracle):
+    """One block of the headline shape (64 x 5 kbp): size-independent invariants on the full
+    block, oracle equality on its first 6 sequences."""
+    import smoothxg_amd as S
+    seqs = synth.make_block(4242, 64, 5000)
+    p = gparams("convex_default", 0)
+    res = engine.run_blocks([seqs, seqs[:6]], p)
+    full, head = res
+    assert full.status == 0
+    n = len(full.node_code)
+    for s, q in enumerate(seqs):                       # the reference's own self-check (src/main.cpp:770-803)
+        assert (full.node_code[full.paths[s]] == q).all()
+    assert sorted(full.node_rank.tolist()) == list(range(n))
+    assert (full.node_rank[full.edge_tail] < full.node_rank[full.edge_head]).all()
+    assert int(full.edge_weight.sum()) == sum(2 * (len(q) - 1) for q in seqs)
+    assert (full.scores[1:] > 0).all() and (full.scores <= np.array([len(q) for q in seqs])).all()
+    order = np.argsort(full.node_rank)                  # aligned groups contiguous, distinct letters
+    gs = full.node_group[order]
+    assert 1 + int((gs[1:] != gs[:-1]).sum()) == len(set(full.node_group.tolist()))
+    g, sc, cells = oracle.block_run(seqs[:6], None, oparams("convex_default", 0))
+    assert_block_equal(head, g, sc, cells, label="ns-head")
+    assert (full.scores[:6] == sc).all() and (full.cells[:6] == cells).all()
