@@ -126,7 +126,7 @@ def test_long_sequences_every_kernel_class(engine, oracle, mode):
 def test_deep_divergent_block_many_predecessors(engine, oracle, pname):
     """48 divergent sequences: rows with many predecessors (generic fold + parked register row)."""
     rng = np.random.default_rng(23)
-    seqs = random_block(rng, 48, 120, div=0.25)
+    seqs = random_block(rng, 48, 120, div=0.1)
     for mode in (0, 1):
         g, sc, cells = oracle.block_run(seqs, None, oparams(pname, mode))
         codes, off, pred, sink, _ = g.rows()
