@@ -53,24 +53,30 @@ def cpu_baseline(workload, mode, seconds_hint=20.0):
         cores = max(1, min(cores, int(avail * 0.5 / per_thread)))
     except Exception:
         pass
-    # sample: `cores` blocks (one per thread), each cut to its first `k` sequences so that the
-    # whole sample is ~seconds_hint of scalar work at ~5e7 cells/s/thread
-    k = ns
-    est = lambda kk: 1.2 * ln * ln * kk * (1 + 0.012 * kk) / 2 / 5e7
-    while k > 4 and est(k) > seconds_hint:
-        k //= 2
+    # sample: `cores` blocks of the workload (one per thread), each cut to its first k sequences;
+    # k is sized from a short calibration so the timed sample is ~seconds_hint of CPU work
+    def cut(bases, seq_off, blk_off, k):
+        keep, so, bo = [], [0], [0]
+        for b in range(len(blk_off) - 1):
+            for s in range(blk_off[b], blk_off[b] + k):
+                keep.append(bases[seq_off[s]:seq_off[s + 1]])
+                so.append(so[-1] + int(seq_off[s + 1] - seq_off[s]))
+            bo.append(len(so) - 1)
+        return np.concatenate(keep), np.asarray(so, np.int64), np.asarray(bo, np.int32)
     bases, seq_off, blk_off = synth.make_batch(cores, ns, ln, first_block=10_000_000)
-    # cut every block to k sequences
-    keep_b, so, bo = [], [0], [0]
-    for b in range(cores):
-        for s in range(blk_off[b], blk_off[b] + k):
-            keep_b.append(bases[seq_off[s]:seq_off[s + 1]])
-            so.append(so[-1] + int(seq_off[s + 1] - seq_off[s]))
-        bo.append(len(so) - 1)
-    sb = np.concatenate(keep_b)
     p = O.mkparams(*prm, mode=mode)
+    kc = min(4, ns)
+    cb, cso, cbo = cut(bases, seq_off, blk_off, kc)
     t0 = time.time()
-    _, cells, _, _ = O.blocks_run_omp(sb, np.asarray(so, np.int64), np.asarray(bo, np.int32), None, p, cores)
+    _, ccells, _, _ = O.blocks_run_omp(cb, cso, cbo, None, p, cores)
+    rate = ccells / max(time.time() - t0, 1e-3)            # cells/s of the whole machine
+    k = kc
+    while k < ns and 0.55 * cores * ln * ln * (2 * k) * (2 * k) * (1 + 0.006 * 2 * k) / rate < seconds_hint:
+        k *= 2
+    k = min(k, ns)
+    sb, so, bo = cut(bases, seq_off, blk_off, k)
+    t0 = time.time()
+    _, cells, _, _ = O.blocks_run_omp(sb, so, bo, None, p, cores)
     dt = time.time() - t0
     return {"cells_per_s": cells / dt, "cores": cores, "seconds": dt,
             "sample": "%d blocks of the workload (one per thread), first %d of %d sequences each, "

@@ -175,7 +175,7 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
                       int32_t *score) {
     norm_params_t P = normalise(pp);
     if (score) *score = 0;
-    if (N == 0 || L == 0) return 0;
+    if (N <= 0 || L <= 0) return 0;
     for (int i = 1; i <= N; ++i) if (off[i] - off[i - 1] > 65535) { fprintf(stderr, "poa_oracle: in-degree > 65535\n"); abort(); }
     const size_t W = (size_t)L + 1;
     /* rows of H,F,O kept until their last reader is done */
@@ -191,6 +191,11 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
     for (int i = 0; i <= N + 1; ++i) free_head[i] = -1;
     for (int i = 0; i <= N; ++i) { free_next[i] = free_head[last_use[i]]; free_head[last_use[i]] = i; }
 
+    /* freed row buffers are recycled (a malloc per row serialises 256 OpenMP threads in glibc) */
+    int32_t **spare = (int32_t **)malloc(sizeof(int32_t *) * ((size_t)N + 2));
+    int n_spare = 0;
+#define ROW_ALLOC() (n_spare ? spare[--n_spare] : (int32_t *)malloc(sizeof(int32_t) * 3 * W))
+#define ROW_FREE(p) (spare[n_spare++] = (p))
     uint8_t *tb = (uint8_t *)malloc(((size_t)N + 1) * W);
     /* ordinals of the winning pred for D,F,O on multi-pred rows */
     int32_t *mp_index = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
@@ -199,7 +204,7 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
     uint16_t *tbx = (uint16_t *)malloc(sizeof(uint16_t) * 3 * (n_mp ? n_mp : 1) * W); /* ordinals < 65536 */
 
     /* row 0 */
-    Hm[0] = (int32_t *)malloc(sizeof(int32_t) * 3 * W);
+    Hm[0] = ROW_ALLOC();
     {
         int32_t *H = Hm[0], *F = H + W, *O = F + W;
         for (int j = 0; j <= L; ++j) {
@@ -217,7 +222,7 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
         int np = off[i] - off[i - 1];
         const int32_t *pl = pred + off[i - 1];
         if (np == 0) { np = 1; pl = &zero_pred; }
-        int32_t *H = (int32_t *)malloc(sizeof(int32_t) * 3 * W), *F = H + W, *O = F + W;
+        int32_t *H = ROW_ALLOC(), *F = H + W, *O = F + W;
         Hm[i] = H;
         uint8_t *t = tb + (size_t)i * W;
         uint16_t *tx = mp_index[i] >= 0 ? tbx + 3 * (size_t)mp_index[i] * W : NULL;
@@ -257,9 +262,13 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
         }
         if (!P.sw && sink[i - 1] && (best_i < 0 || H[L] > best)) { best = H[L]; best_i = i; best_j = L; }
         /* release rows nobody will read again */
-        for (int r = free_head[i]; r >= 0; r = free_next[r]) { free(Hm[r]); Hm[r] = NULL; }
+        for (int r = free_head[i]; r >= 0; r = free_next[r]) { ROW_FREE(Hm[r]); Hm[r] = NULL; }
     }
     for (int i = 0; i <= N; ++i) free(Hm[i]);
+    while (n_spare) free(spare[--n_spare]);
+    free(spare);
+#undef ROW_ALLOC
+#undef ROW_FREE
     free(Hm); free(last_use); free(free_head); free(free_next);
 
     int n = 0;
