@@ -147,7 +147,9 @@ typedef struct sxg_poa_stats {
     /* the dominant launch (most cells) of the last execute: what bench.py's roofline quotes */
     double dom_kernel_ms;
     uint64_t dom_cells, dom_algo_bytes;
-    int32_t dom_threads, dom_cols_per_lane; /* kernel variant <T, W> */
+    int32_t dom_threads, dom_cols_per_lane; /* launch geometry */
+    int32_t dom_row_mode;  /* 0/1 = 32-bit sweep (int16 / int32 row words), 2 = packed-int16 sweep */
+    int32_t reserved;
 } sxg_poa_stats;
 
 int sxg_poa_abi_version(void);

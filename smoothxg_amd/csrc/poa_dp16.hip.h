@@ -1,0 +1,495 @@
+// poa_dp16.hip.h -- packed-int16 DP sweep (gfx950 v_pk_add_i16 / v_pk_max_i16 / v_pk_sub_i16).
+//
+// Same semantics (S1-S5) and the same row-uniform structure as poa_dp.hip.h, but every VGPR
+// holds TWO cells: lane t owns strip "lo" = columns [t*W, (t+1)*W) and strip "hi" = columns
+// [T*W + t*W, T*W + (t+1)*W); the low / high 16 bits of a register are the two strips, so every
+// add/max serves two cells.  Measured on MI355X (profiles/ubench/valu_rate.hip): a wave64
+// integer VALU instruction issues every 4 cycles whether it is 32-bit or packed 16-bit, and the
+// 32-bit sweep is bound by exactly that issue rate -- packing is the lever.
+//
+// What changes with packing:
+//  * no packed compare exists, so every "which candidate won" bit is the SIGN of a packed
+//    difference, shifted into bit k (lo strip) / bit 16+k (hi strip) of a per-row mask word;
+//  * the traceback plane stores those mask words (9 per lane per row) instead of one byte per
+//    cell; the 6-way source of H is resolved from "strictly beat the running maximum" bits in
+//    priority order Q > E > O > F > D at traceback time;
+//  * stored rows keep the register format: per lane and column one word of packed H and one of
+//    packed 8-bit H-F / H-O deltas;
+//  * the end cell of a local alignment is found with a packed running maximum per row and a
+//    wave-uniform search of the column only in rows that improve it.
+// Applicability: every reachable score and intermediate fits +-15800 (host check); otherwise the
+// 32-bit sweep runs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "poa_dp.hip.h"
+
+namespace sxg {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NEGP = -16384;  // "minus infinity" of the packed sweep
+constexpr int P16_TB_WORDS = 9;
+// mask words of one lane and row in the packed traceback plane
+enum : int { PM_STOP = 0, PM_GTF = 1, PM_GTO = 2, PM_GTE = 3, PM_GTQ = 4, PM_FX = 5, PM_OX = 6, PM_EX = 7, PM_QX = 8 };
+
+__device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ int pk_sub(int a, int b) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ int pk_minu(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ int pk_mad(int a, int b, int c) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) * __builtin_bit_cast(s16x2, b) + __builtin_bit_cast(s16x2, c))); }
+__device__ __forceinline__ int pk2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+__device__ __forceinline__ int pk_lo(int v) { return (int)(short)(v & 0xffff); }
+__device__ __forceinline__ int pk_hi(int v) { return v >> 16; }
+// bit k (lo) / 16+k (hi) <- sign bits of the packed difference d
+#define SXG_SIGN_TO(mask, d, k) mask |= (((unsigned)(d)) >> (15 - (k))) & (0x00010001u << (k))
+
+constexpr int LDS16_X = 64;  // ints of exchange scratch after the four [16] arrays of dp_fill
+
+// Row words of the packed ring: (Hpk, deltas) per lane and column.
+__device__ __forceinline__ uint2 p16_pack_row(int h, int f, int o) {
+    const int df = pk_minu(pk_sub(h, f), 0x00ff00ff), dq = pk_minu(pk_sub(h, o), 0x00ff00ff);
+    return make_uint2((unsigned)h, (unsigned)(df | (dq << 8)));
+}
+__device__ __forceinline__ void p16_unpack_row(uint2 w, int& h, int& f, int& o) {
+    h = (int)w.x;
+    f = pk_sub(h, (int)(w.y & 0x00ff00ffu));
+    o = pk_sub(h, (int)((w.y >> 8) & 0x00ff00ffu));
+}
+
+template <int W, bool CVX, bool SW>
+__device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R, const int N,
+                                            const uint8_t* __restrict__ seq, const int L, const DpBuffers& B,
+                                            char* smem, DpResult& res) {
+    static_assert(W % 4 == 0 && W <= 16, "W must be a multiple of 4, at most 16");
+    const int T = (int)blockDim.x;
+    const int NW = T >> 6;
+    const int TW = T * W;           // columns of one half
+    constexpr unsigned ALL = ((1u << W) - 1u) * 0x00010001u;
+    int* lds = (int*)smem;
+    const int4* lmeta = (const int4*)(smem + LDS_CTL_BYTES);
+    uint2* lrow = (uint2*)(smem + LDS_CTL_BYTES + LDS_META_BYTES);  // parked register row (>= 3 preds)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int j0 = t * W;           // first column of my lo strip; hi strip starts at TW + j0
+    const int g = S.g, e = S.e, q = S.q, c = S.c;
+    const int G2 = pk2(g, g), E2 = pk2(e, e), Q2 = pk2(q, q), C2 = pk2(c, c);
+    const int MN2 = pk2(S.n - S.m, S.n - S.m), M2 = pk2(S.m, S.m), ONE2 = 0x00010001, NEG2 = pk2(NEGP, NEGP);
+    const int We = W * e, Wc = W * c;
+    int* tot = lds;            // [4][16]: a_lo, a_hi, b_lo, b_hi inclusive totals per wave
+    int* xch = lds + 64;       // [16][2]: (Hc[W-1] packed, ext bits) of every wave's last lane
+
+    // query letters, one byte per (strip, column): register c2 holds (lo_k, hi_k, lo_k+1, hi_k+1)
+    unsigned let[W / 2];
+#pragma unroll
+    for (int k2 = 0; k2 < W / 2; ++k2) {
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = (b & 1 ? TW : 0) + j0 + 2 * k2 + (b >> 1);
+            const unsigned ch = (j >= 1 && j <= L) ? (unsigned)seq[j - 1] : 15u;
+            v |= (ch > 4u && ch != 15u ? 4u : ch) << (8 * b);
+        }
+        let[k2] = v;
+    }
+
+    int Hp[W], Fp[W], Op[W], Hleft;
+    // virtual row 0
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        int h2[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int j = hf * TW + j0 + k;
+            int h = 0;
+            if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = max(a > b ? a : b, NEGP); }
+            h2[hf] = h;
+        }
+        Hp[k] = pk2(h2[0], h2[1]); Fp[k] = NEG2; Op[k] = NEG2;
+    }
+    {
+        int h2[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int j = hf * TW + j0 - 1;
+            int h = 0;
+            if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = max(a > b ? a : b, NEGP); }
+            h2[hf] = j < 0 ? NEGP : h;
+        }
+        Hleft = pk2(h2[0], h2[1]);
+    }
+    {
+        uint2* r0 = (uint2*)B.row0 + j0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) r0[k] = p16_pack_row(Hp[k], Fp[k], Op[k]);
+    }
+    int best_lo = SW ? 0 : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;
+    const int kL_lo = L - j0, kL_hi = L - TW - j0;  // strip-local index of the end column L
+
+    for (int i = 1; i <= N; ++i) {
+        const int r = i - 1;
+        if ((r & (META_CHUNK - 1)) == 0) {
+            __syncthreads();
+            const int4* gm = (const int4*)(R.meta + 8 * (size_t)r);
+            int4* lm = (int4*)(smem + LDS_CTL_BYTES);
+            const int nrow = min(META_CHUNK, N - r);
+            for (int x = t; x < 2 * nrow; x += T) lm[x] = gm[x];
+            __syncthreads();
+        }
+        const int4 m0 = lmeta[2 * (r & (META_CHUNK - 1))], m1 = lmeta[2 * (r & (META_CHUNK - 1)) + 1];
+        const int pb = __builtin_amdgcn_readfirstlane(m0.x);
+        const int info = __builtin_amdgcn_readfirstlane(m0.y);
+        const int p0 = __builtin_amdgcn_readfirstlane(m0.z);
+        const int s0 = __builtin_amdgcn_readfirstlane(m0.w);
+        const int p1 = __builtin_amdgcn_readfirstlane(m1.x);
+        const int s1 = __builtin_amdgcn_readfirstlane(m1.y);
+        const int myslot = __builtin_amdgcn_readfirstlane(m1.z);
+        const int tx = __builtin_amdgcn_readfirstlane(m1.w);
+        const int np = info & 0xffff, code = (info >> 16) & 0xff, flags = (info >> 24) & 0xff;
+        const unsigned CODE4 = (unsigned)code * 0x01010101u;
+#pragma unroll
+        for (int k2 = 0; k2 < W / 2; ++k2) SXG_PIN("+v"(let[k2]));
+
+        int Hc[W];
+        unsigned fxm = 0, oxm = 0;
+
+#define P16_INIT(k, hs, fs, os, hprev)                        \
+    do {                                                      \
+        const int c1_ = pk_add((hs), G2), c2_ = pk_add((fs), E2); \
+        Hc[k] = (hprev);                                      \
+        Fp[k] = pk_max(c1_, c2_);                             \
+        SXG_SIGN_TO(fxm, pk_sub(c1_, c2_), k);                \
+        if (CVX) {                                            \
+            const int d1_ = pk_add((hs), Q2), d2_ = pk_add((os), C2); \
+            Op[k] = pk_max(d1_, d2_);                         \
+            SXG_SIGN_TO(oxm, pk_sub(d1_, d2_), k);            \
+        }                                                     \
+        SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm)); \
+    } while (0)
+// the column left of my strips in a stored row: lane t-1's last column; lane 0: lo = none,
+// hi = last column of the lo half (lane T-1)
+#define P16_LOAD_LEFT(sp_base, hl)                                                    \
+    do {                                                                              \
+        if (t > 0) hl = (int)(sp_base)[(size_t)(j0 - 1)].x;                           \
+        else hl = pk2(NEGP, pk_lo((int)(sp_base)[(size_t)(TW - 1)].x));               \
+    } while (0)
+
+        if (np <= 1 && p0 == i - 1) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) P16_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
+        } else {
+            const bool reg0 = (p0 == i - 1), reg1 = (np == 2 && p1 == i - 1);
+            const bool park = np >= 3;
+            if (park) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) lrow[j0 + k] = p16_pack_row(Hp[k], Fp[k], Op[k]);
+            }
+            const int ge = reg1 ? 1 : 0;
+            const int GE2 = ge ? ONE2 : 0;
+            if ((reg0 || reg1) && !park) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) P16_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
+            } else {
+                uint2 wr[W];
+                int hl = Hleft;
+                if (reg0) {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
+                } else {
+                    const uint2* base = (p0 == 0) ? (const uint2*)B.row0 : (const uint2*)B.pool + (size_t)s0 * TW;
+#pragma unroll
+                    for (int k = 0; k < W; ++k) wr[k] = base[j0 + k];
+                    P16_LOAD_LEFT(base, hl);
+                }
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    int hs, fs, os;
+                    p16_unpack_row(wr[k], hs, fs, os);
+                    P16_INIT(k, hs, fs, os, hl);
+                    hl = hs;
+                    SXG_PIN("+v"(hl));
+                }
+            }
+            for (int x = 1; x < np; ++x) {
+                int p, sl;
+                if (x == 1) { p = reg1 ? p0 : p1; sl = reg1 ? s0 : s1; }
+                else {
+                    p = __builtin_amdgcn_readfirstlane(R.preds[pb + x]);
+                    sl = (p >= 1 && p != i - 1) ? __builtin_amdgcn_readfirstlane(R.slot[p - 1]) : -1;
+                }
+                uint2 wr[W];
+                int hl = Hleft;
+                if (p == i - 1) {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
+                } else {
+                    const uint2* base = (p == 0) ? (const uint2*)B.row0 : (const uint2*)B.pool + (size_t)sl * TW;
+#pragma unroll
+                    for (int k = 0; k < W; ++k) wr[k] = base[j0 + k];
+                    P16_LOAD_LEFT(base, hl);
+                }
+                // take-over test "cand + ge > cur" = sign of (cur - cand - ge); the value is the max
+                // either way (on a tie both are equal); masks: xor as in the 32-bit sweep
+                unsigned dm = ge ? ALL : 0u, fmk = dm, omk = CVX ? dm : 0u;
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    int hs, fs, os;
+                    p16_unpack_row(wr[k], hs, fs, os);
+                    const unsigned bit = 0x00010001u << k;
+                    {
+                        const int c1 = pk_add(hs, G2), c2 = pk_add(fs, E2);
+                        const int cb = pk_max(c1, c2);
+                        const unsigned x1 = (((unsigned)pk_sub(c1, c2)) >> (15 - k)) & bit;
+                        const unsigned rf = (((unsigned)pk_sub(pk_sub(Fp[k], cb), GE2)) >> (15 - k)) & bit;
+                        Fp[k] = pk_max(Fp[k], cb);
+                        fxm = (fxm & ~rf) | (rf & x1);
+                        fmk ^= rf;
+                    }
+                    if (CVX) {
+                        const int d1 = pk_add(hs, Q2), d2 = pk_add(os, C2);
+                        const int db = pk_max(d1, d2);
+                        const unsigned x2 = (((unsigned)pk_sub(d1, d2)) >> (15 - k)) & bit;
+                        const unsigned ro = (((unsigned)pk_sub(pk_sub(Op[k], db), GE2)) >> (15 - k)) & bit;
+                        Op[k] = pk_max(Op[k], db);
+                        oxm = (oxm & ~ro) | (ro & x2);
+                        omk ^= ro;
+                    }
+                    {
+                        const unsigned rd = (((unsigned)pk_sub(pk_sub(Hc[k], hl), GE2)) >> (15 - k)) & bit;
+                        Hc[k] = pk_max(Hc[k], hl);
+                        dm ^= rd;
+                    }
+                    hl = hs;
+                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm), "+v"(dm), "+v"(fmk), "+v"(omk), "+v"(hl));
+                }
+                uint32_t* st = B.steps + ((size_t)(tx + x - 1) * 3) * T + t;
+                st[0] = dm; st[T] = fmk; st[2 * T] = omk;
+            }
+        }
+#undef P16_INIT
+#undef P16_LOAD_LEFT
+        if (!CVX) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) Op[k] = NEG2;
+        }
+
+        // ---- pass 1: H before the in-row gaps, strip-local carries
+        unsigned gtf = 0, gto = 0;  // F / O strictly beat the running maximum
+        int a = NEG2, b = NEG2;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            // letters (lo_k, hi_k) of column k as a packed pair; 0 where they equal the node letter
+            const unsigned x4 = let[k >> 1] ^ CODE4;
+            const int lp = (int)__builtin_amdgcn_perm(0u, x4, (k & 1) ? 0x0c030c02u : 0x0c010c00u);
+            const int nm = pk_minu(lp, ONE2);              // 0 = match, 1 = mismatch
+            int h = pk_add(Hc[k], pk_mad(nm, MN2, M2));    // diagonal + (match ? m : n)
+            SXG_SIGN_TO(gtf, pk_sub(h, Fp[k]), k);
+            h = pk_max(h, Fp[k]);
+            if (CVX) { SXG_SIGN_TO(gto, pk_sub(h, Op[k]), k); h = pk_max(h, Op[k]); }
+            Hc[k] = h;
+            const int hc = SW ? pk_max(h, 0) : h;
+            a = pk_max(pk_add(a, E2), pk_add(hc, G2));
+            if (CVX) b = pk_max(pk_add(b, C2), pk_add(hc, Q2));
+            SXG_PIN("+v"(Hc[k]), "+v"(gtf), "+v"(gto), "+v"(a), "+v"(b));
+        }
+        // ---- carries (32-bit).  Strip order: lo strips of lanes 0..T-1, then hi strips.
+        // y = a - s*W*e with strip index s (lo: t, hi: T + t); E entering strip s = max_{s'<s} y_{s'} + (s-1)*W*e
+        int ya_lo = pk_lo(a) - t * We, ya_hi = pk_hi(a) - (T + t) * We;
+        int yb_lo = CVX ? pk_lo(b) - t * Wc : NEG, yb_hi = CVX ? pk_hi(b) - (T + t) * Wc : NEG;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o0 = __shfl_up(ya_lo, d), o1 = __shfl_up(ya_hi, d), o2 = __shfl_up(yb_lo, d), o3 = __shfl_up(yb_hi, d);
+            if (lane >= d) { ya_lo = max(ya_lo, o0); ya_hi = max(ya_hi, o1); yb_lo = max(yb_lo, o2); yb_hi = max(yb_hi, o3); }
+        }
+        if (lane == 63) { tot[wv] = ya_lo; tot[16 + wv] = ya_hi; tot[32 + wv] = yb_lo; tot[48 + wv] = yb_hi; }
+        SXG_ROW_BARRIER();  // B1
+        {
+            int b0 = NEG * 2, b1 = NEG * 2, b2 = NEG * 2, b3 = NEG * 2, lo_a = NEG * 2, lo_b = NEG * 2;
+            for (int x = 0; x < NW; ++x) {
+                const int v0 = tot[x], v1 = tot[16 + x], v2 = tot[32 + x], v3 = tot[48 + x];
+                lo_a = max(lo_a, v0); lo_b = max(lo_b, v2);
+                if (x < wv) { b0 = max(b0, v0); b1 = max(b1, v1); b2 = max(b2, v2); b3 = max(b3, v3); }
+            }
+            b1 = max(b1, lo_a); b3 = max(b3, lo_b);  // every lo strip precedes every hi strip
+            ya_lo = max(ya_lo, b0); ya_hi = max(ya_hi, b1); yb_lo = max(yb_lo, b2); yb_hi = max(yb_hi, b3);
+            int e0 = __shfl_up(ya_lo, 1), e1 = __shfl_up(ya_hi, 1), e2 = __shfl_up(yb_lo, 1), e3 = __shfl_up(yb_hi, 1);
+            if (lane == 0) { e0 = b0; e1 = b1; e2 = b2; e3 = b3; }
+            ya_lo = e0; ya_hi = e1; yb_lo = e2; yb_hi = e3;
+        }
+        const int Ein_lo = (t == 0) ? NEGP : max(ya_lo + (t - 1) * We, NEGP);
+        const int Ein_hi = max(ya_hi + (T + t - 1) * We, NEGP);
+        const int Qin_lo = (t == 0 || !CVX) ? NEGP : max(yb_lo + (t - 1) * Wc, NEGP);
+        const int Qin_hi = !CVX ? NEGP : max(yb_hi + (T + t - 1) * Wc, NEGP);
+        int E = pk2(Ein_lo, Ein_hi), Q = pk2(Qin_lo, Qin_hi);
+
+        // ---- pass 2: final H and the remaining decision bits
+        unsigned gte = 0, gtq = 0, stp = 0, exm = 0, qxm = 0;  // exm/qxm: EXTEND bit of E/Q of column k
+        int rowmax = SW ? 0 : NEG2;
+        unsigned ebn = 0, qbn = 0;  // ext bits of the NEXT column, at bit positions 0 / 16
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            exm |= ebn << k; if (CVX) qxm |= qbn << k;
+            int h = Hc[k];
+            SXG_SIGN_TO(gte, pk_sub(h, E), k);
+            h = pk_max(h, E);
+            if (CVX) { SXG_SIGN_TO(gtq, pk_sub(h, Q), k); h = pk_max(h, Q); }
+            if (SW) { SXG_SIGN_TO(stp, pk_sub(h, ONE2), k); h = pk_max(h, 0); }
+            Hc[k] = h;
+            rowmax = pk_max(rowmax, h);
+            const int c1 = pk_add(h, G2), c2 = pk_add(E, E2);
+            ebn = (((unsigned)pk_sub(c1, c2)) >> 15) & 0x00010001u;
+            E = pk_max(c1, c2);
+            if (CVX) {
+                const int d1 = pk_add(h, Q2), d2 = pk_add(Q, C2);
+                qbn = (((unsigned)pk_sub(d1, d2)) >> 15) & 0x00010001u;
+                Q = pk_max(d1, d2);
+            }
+            SXG_PIN("+v"(Hc[k]), "+v"(gte), "+v"(gtq), "+v"(stp), "+v"(exm), "+v"(qxm), "+v"(E), "+v"(Q), "+v"(ebn), "+v"(qbn), "+v"(rowmax));
+        }
+        // hand my last column and the ext bits of the next column to the right neighbour; the lo
+        // half's last lane feeds lane 0's hi strip
+        const int xh = Hc[W - 1];
+        const int xb = (int)(ebn | (qbn << 1));  // bits 0,1 (lo strip), 16,17 (hi strip)
+        int lh = __shfl_up(xh, 1), lb = __shfl_up(xb, 1);
+        if (lane == 63) { xch[2 * wv] = xh; xch[2 * wv + 1] = xb; }
+        SXG_ROW_BARRIER();  // B2
+        if (lane == 0) {
+            if (wv > 0) { lh = xch[2 * (wv - 1)]; lb = xch[2 * (wv - 1) + 1]; }
+            else {
+                const int th = xch[2 * (NW - 1)], tb_ = xch[2 * (NW - 1) + 1];  // lane T-1
+                lh = pk2(NEGP, pk_lo(th));
+                lb = (tb_ & 3) << 16;  // its lo-strip bits become my hi-strip bits; my lo strip starts the row
+            }
+        }
+        exm |= ((unsigned)lb & 0x00010001u);
+        if (CVX) qxm |= (((unsigned)lb >> 1) & 0x00010001u);
+
+        // ---- end cell bookkeeping
+        if (SW) {
+            const bool il = pk_lo(rowmax) > best_lo, ih = pk_hi(rowmax) > best_hi;
+            if (__any(il || ih)) {  // wave-uniform: only the waves the best diagonal runs through
+                if (il) { best_lo = pk_lo(rowmax); bi_lo = i; }
+                if (ih) { best_hi = pk_hi(rowmax); bi_hi = i; }
+#pragma unroll
+                for (int k = W - 1; k >= 0; --k) {
+                    if (il && pk_lo(Hc[k]) == best_lo) bk_lo = k;
+                    if (ih && pk_hi(Hc[k]) == best_hi) bk_hi = k;
+                }
+            }
+        } else if (flags & ROW_SINK) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                if (k == kL_lo && (bi_lo < 0 || pk_lo(Hc[k]) > best_lo)) { best_lo = pk_lo(Hc[k]); bi_lo = i; bk_lo = k; }
+                if (k == kL_hi && (bi_hi < 0 || pk_hi(Hc[k]) > best_hi)) { best_hi = pk_hi(Hc[k]); bi_hi = i; bk_hi = k; }
+            }
+        }
+
+        // ---- stores
+        {
+            uint32_t* dst = (uint32_t*)B.tb + ((size_t)i * T + t) * P16_TB_WORDS;
+            dst[PM_STOP] = stp; dst[PM_GTF] = gtf; dst[PM_GTO] = gto; dst[PM_GTE] = gte; dst[PM_GTQ] = gtq;
+            dst[PM_FX] = fxm; dst[PM_OX] = oxm; dst[PM_EX] = exm; dst[PM_QX] = qxm;
+        }
+        if (flags & ROW_STORE) {
+            uint2* dst = (uint2*)B.pool + (size_t)myslot * TW + j0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = p16_pack_row(Hc[k], Fp[k], Op[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) Hp[k] = Hc[k];
+        Hleft = lh;
+    }
+
+    // ---- end cell: greatest score, then smallest row, then smallest column (two candidates per lane)
+    unsigned long long key = 0;
+    if (bi_lo >= 0)
+        key = ((unsigned long long)(unsigned)(best_lo + (1 << 27)) << 35) |
+              ((unsigned long long)(0xFFFFFu - (unsigned)bi_lo) << 15) | (unsigned long long)(0x7FFFu - (unsigned)(j0 + bk_lo));
+    if (bi_hi >= 0) {
+        const unsigned long long k2 = ((unsigned long long)(unsigned)(best_hi + (1 << 27)) << 35) |
+                                      ((unsigned long long)(0xFFFFFu - (unsigned)bi_hi) << 15) |
+                                      (unsigned long long)(0x7FFFu - (unsigned)(TW + j0 + bk_hi));
+        key = k2 > key ? k2 : key;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(key, d);
+        key = o > key ? o : key;
+    }
+    __syncthreads();
+    unsigned long long* kl = (unsigned long long*)lds;
+    if (lane == 0) kl[wv] = key;
+    __syncthreads();
+    key = kl[0];
+    for (int x = 1; x < NW; ++x) key = kl[x] > key ? kl[x] : key;
+    __syncthreads();
+    if (key == 0) { res.best = 0; res.bi = -1; res.bj = -1; }
+    else {
+        res.best = (int)(unsigned)(key >> 35) - (1 << 27);
+        res.bi = (int)(0xFFFFFu - (unsigned)((key >> 15) & 0xFFFFFu));
+        res.bj = (int)(0x7FFFu - (unsigned)(key & 0x7FFFu));
+    }
+}
+
+// Traceback over the packed mask plane (S5).  The source of H is the LAST candidate in the order
+// D, F, O, E, Q that strictly beat the running maximum (first-wins priority D > F > O > E > Q),
+// unless the cell is a STOP.
+__device__ __forceinline__ int p16_winner(const RowsView& R, const DpBuffers& B, const int T, const int r, const int np,
+                                          const int lane_t, const int bit, const int which) {
+    const int tx = R.tbx[r];
+    for (int x = np - 1; x >= 1; --x) {
+        const unsigned m = B.steps[((size_t)(tx + x - 1) * 3 + which) * T + lane_t];
+        if ((m >> bit) & 1u) return x;
+    }
+    return 0;
+}
+
+template <bool PAIRS>
+__device__ __noinline__ int traceback_p16(const RowsView& R, const DpBuffers& B, const int T, const int W, const int sw, int i, int j,
+                                          int32_t* posnode, int32_t* pair_row, int32_t* pair_pos) {
+    const int TW = T * W;
+    int n = 0, st = SRC_STOP;
+    for (;;) {
+        if (i == 0) {
+            if (j == 0 || sw) break;
+            if (PAIRS) { pair_row[n] = 0; pair_pos[n] = j - 1; }
+            ++n; --j;
+            continue;
+        }
+        const int r = i - 1;
+        const int half = j >= TW ? 1 : 0, jj = j - half * TW;
+        const int lt = jj / W, bit = (jj - lt * W) + 16 * half;
+        const uint32_t* mw = (const uint32_t*)B.tb + ((size_t)i * T + lt) * P16_TB_WORDS;
+        const int pb = R.pred_off[r], np = R.pred_off[r + 1] - pb;
+        if (st == SRC_STOP) {
+            int src;
+            if ((mw[PM_STOP] >> bit) & 1u) src = SRC_STOP;
+            else if ((mw[PM_GTQ] >> bit) & 1u) src = SRC_Q;
+            else if ((mw[PM_GTE] >> bit) & 1u) src = SRC_E;
+            else if ((mw[PM_GTO] >> bit) & 1u) src = SRC_O;
+            else if ((mw[PM_GTF] >> bit) & 1u) src = SRC_F;
+            else src = SRC_D;
+            if (src == SRC_STOP) break;
+            if (src == SRC_D) {
+                if (PAIRS) { pair_row[n] = i; pair_pos[n] = j - 1; }
+                if (posnode) posnode[j - 1] = R.row_node[r];
+                ++n;
+                i = np ? R.preds[pb + (np > 1 ? p16_winner(R, B, T, r, np, lt, bit, 0) : 0)] : 0;
+                --j;
+            } else st = src;
+        } else if (st == SRC_F || st == SRC_O) {
+            const unsigned ext = (mw[st == SRC_F ? PM_FX : PM_OX] >> bit) & 1u;
+            if (PAIRS) { pair_row[n] = i; pair_pos[n] = -1; }
+            ++n;
+            i = np ? R.preds[pb + (np > 1 ? p16_winner(R, B, T, r, np, lt, bit, st == SRC_F ? 1 : 2) : 0)] : 0;
+            if (!ext) st = SRC_STOP;
+        } else {
+            const unsigned ext = (mw[st == SRC_E ? PM_EX : PM_QX] >> bit) & 1u;
+            if (PAIRS) { pair_row[n] = 0; pair_pos[n] = j - 1; }
+            ++n; --j;
+            if (!ext) st = SRC_STOP;
+        }
+    }
+    return n;
+}
+
+}  // namespace sxg

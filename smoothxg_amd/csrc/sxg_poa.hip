@@ -16,6 +16,7 @@
 
 #include "../../include/sxg_poa.h"
 #include "poa_dp.hip.h"
+#include "poa_dp16.hip.h"
 #include "poa_graph_dev.h"
 
 using namespace sxg;
@@ -39,7 +40,7 @@ static size_t lay(size_t& cur, size_t bytes) {
 }
 
 static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int step_cap, int threads, int Lpad,
-                              int word_bytes, bool pairs) {
+                              int word_bytes, bool pairs, bool packed = false) {
     SlotLayout L;
     memset(&L, 0, sizeof(L));
     L.nodes_cap = nodes_cap; L.rows_cap = rows_cap; L.pool_slots = pool_slots;
@@ -60,7 +61,8 @@ static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int s
     L.r_code = lay(cur, Rr); L.r_flags = lay(cur, Rr); L.r_pred_off = lay(cur, 4 * Rr);
     L.r_preds = lay(cur, 4 * C); L.r_slot = lay(cur, 4 * Rr); L.r_tbx = lay(cur, 4 * Rr);
     L.r_sseq = lay(cur, 4 * Rr); L.r_row_node = lay(cur, 4 * Rr); L.r_meta = lay(cur, 32 * Rr);
-    L.tb = lay(cur, ((size_t)rows_cap + 1) * Lpad);
+    // traceback plane: one byte per cell, or (packed sweep) 9 mask words per lane and row
+    L.tb = lay(cur, ((size_t)rows_cap + 1) * (packed ? (size_t)threads * P16_TB_WORDS * 4 : (size_t)Lpad));
     L.steps = lay(cur, (size_t)std::max(step_cap, 1) * 3 * threads * 4);
     L.pool = lay(cur, (size_t)pool_slots * Lpad * word_bytes);
     L.row0 = lay(cur, (size_t)Lpad * word_bytes);
@@ -137,10 +139,16 @@ struct BlockArgs {
 // value), W = columns per lane.  The second launch-bound is the number of waves per SIMD the
 // register allocator must leave room for: 8 columns/lane need ~100 VGPRs (4 waves), 16 need
 // ~165 (3 waves); a 1024-thread workgroup is 4 waves per SIMD by itself.
-__host__ __device__ constexpr int sxg_min_waves(int TMAX, int W) { return (TMAX > 512 || W <= 12) ? 4 : 3; }
+// RM = row mode: 0 = 32-bit sweep with int16 row words, 1 = 32-bit sweep with int32 row words,
+// 2 = packed-int16 sweep (poa_dp16.hip.h; two strips per lane, W <= 12).
+__host__ __device__ constexpr int sxg_min_waves(int TMAX, int W, int RM) {
+    return TMAX > 512 ? 4 : (RM == 2 ? (W <= 8 ? 4 : 3) : (W <= 12 ? 4 : 3));
+}
 
-template <int TMAX, int W, bool CVX, bool H16, bool SW>
-__global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_block_kernel(const BlockArgs A) {
+template <int TMAX, int W, bool CVX, int RM, bool SW>
+__global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_kernel(const BlockArgs A) {
+    constexpr bool H16 = RM != 1;
+    constexpr int CPL = RM == 2 ? 2 * W : W;  // columns per lane
     const int T = (int)blockDim.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lds = (int*)smem;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_block_kernel
             __syncthreads();
             const int N = *V.G.n_nodes;
             int score = 0;
-            if (len + 1 > T * W) { status = ST_TOO_LONG; break; }
+            if (len + 1 > T * CPL) { status = ST_TOO_LONG; break; }
             if (N + len > A.lay.nodes_cap) { status = ST_NODES_OVERFLOW; break; }
             if (N > 0 && len > 0) {
                 PROF(0);
@@ -181,11 +189,14 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_block_kernel
                 if (status != ST_OK) break;
                 PROF(1);
                 DpResult res;
-                dp_fill<W, CVX, H16, SW>(S, V.R, N, seq, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
+                if constexpr (RM == 2) dp_fill_p16<W, CVX, SW>(S, V.R, N, seq, len, V.B, smem, res);
+                else dp_fill<W, CVX, H16, SW>(S, V.R, N, seq, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 PROF(2);
-                if (t == 0 && res.bi >= 0)
-                    traceback<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
+                if (t == 0 && res.bi >= 0) {
+                    if constexpr (RM == 2) traceback_p16<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
+                    else traceback<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
+                }
                 score = res.bi >= 0 ? res.best : 0;
                 __syncthreads();
                 PROF(3);
@@ -232,8 +243,10 @@ struct AlignArgs {
     int pf_off;
 };
 
-template <int TMAX, int W, bool CVX, bool H16, bool SW>
-__global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_align_kernel(const AlignArgs A) {
+template <int TMAX, int W, bool CVX, int RM, bool SW>
+__global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_kernel(const AlignArgs A) {
+    constexpr bool H16 = RM != 1;
+    constexpr int CPL = RM == 2 ? 2 * W : W;
     const int T = (int)blockDim.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lds = (int*)smem;
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_align_kernel
         const Scoring S = normalise(A.params[A.per_problem_params ? p : 0]);
         const int64_t e0 = A.pred_off[r0];
         int status = ST_OK, score = 0, npairs = 0;
-        if (len + 1 > T * W) status = ST_TOO_LONG;
+        if (len + 1 > T * CPL) status = ST_TOO_LONG;
         else if (N > A.lay.rows_cap) status = ST_ROWS_OVERFLOW;
         else if (N > 0 && len > 0) {
             for (int r = t; r < N; r += T) {
@@ -282,10 +295,12 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W)) void poa_align_kernel
             status = finish_rows(ctx, N, V.R, caps);
             if (status == ST_OK) {
                 DpResult res;
-                dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
+                if constexpr (RM == 2) dp_fill_p16<W, CVX, SW>(S, V.R, N, A.bases + so, len, V.B, smem, res);
+                else dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 if (t == 0 && res.bi >= 0) {
-                    npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
+                    if constexpr (RM == 2) npairs = traceback_p16<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
+                    else npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
                     score = res.best;
                     const int64_t out0 = A.row_off[p] + A.seq_off[p];
                     for (int k = 0; k < npairs; ++k) {  // reverse into the output
@@ -323,27 +338,36 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
                         std::string(#x) + ": " + hipGetErrorString(_e));                       \
     } while (0)
 
-// A launch geometry: W columns per lane, NW waves (T = 64*NW), kernel class TMAX.
-struct Variant { int W, NW, TMAX; int T() const { return 64 * NW; } int Lpad() const { return 64 * NW * W; } };
+// A launch geometry: W columns per strip, NW waves (T = 64*NW), kernel class TMAX, row mode RM
+// (2 = packed sweep: two strips per lane).
+struct Variant {
+    int W, NW, TMAX, RM;
+    int T() const { return 64 * NW; }
+    int Lpad() const { return 64 * NW * W * (RM == 2 ? 2 : 1); }
+};
 
 // Geometry choice.  Inside a workgroup all waves meet at two barriers per row, so the wave
 // count should load the four SIMDs of a CU evenly: 1, 2, 3, 4, 8, 12 or 16 waves.  Among the
 // (W, NW) pairs that cover the sequence pick the one with the fewest padded columns, then the
-// wider strip (less per-row overhead).  12 columns per lane is the widest strip that still fits
-// 128 VGPRs, i.e. four waves per SIMD (two 512-thread or four 256-thread workgroups per CU).
-static bool variant_for_len(int maxlen, Variant* v) {
+// wider strip (less per-row overhead).  Strip widths are bounded by VGPRs: 32-bit sweep 16
+// columns (~165 VGPRs, <= 512 threads) / 12 (128 VGPRs); packed sweep 12 (~152) / 8 (124).
+static bool variant_for_len(int maxlen, int rm, Variant* v) {
     static const int kNW[] = {1, 2, 3, 4, 8, 12, 16};
-    static const int kW[] = {16, 12, 8};
+    static const int kW32[] = {16, 12, 8}, kW16[] = {12, 8};
+    const int* ws = rm == 2 ? kW16 : kW32;
+    const int nws = rm == 2 ? 2 : 3;
     const int need = maxlen + 1;
     long best_cols = -1;
-    for (int W : kW)
+    for (int wi = 0; wi < nws; ++wi)
         for (int NW : kNW) {
-            const long cols = 64L * NW * W;
+            const int W = ws[wi];
+            const long cols = 64L * NW * W * (rm == 2 ? 2 : 1);
             if (cols < need) continue;
-            if (W == 16 && NW > 8) continue;  // 16 columns/lane needs ~165 VGPRs: not in a 1024-thread group
+            const bool wide = rm == 2 ? W > 8 : W > 12;   // needs > 128 VGPRs
+            if (wide && NW > 8) continue;
             if (best_cols < 0 || cols < best_cols) {
                 best_cols = cols;
-                *v = Variant{W, NW, NW <= 4 ? 256 : (NW <= 8 ? 512 : 1024)};
+                *v = Variant{W, NW, NW <= 4 ? 256 : (NW <= 8 ? 512 : 1024), rm};
             }
             break;  // larger NW for this W only adds padding
         }
@@ -352,51 +376,40 @@ static bool variant_for_len(int maxlen, Variant* v) {
 
 template <class Args> using KernelFn = void (*)(const Args);
 
-template <int TMAX, int W> static KernelFn<BlockArgs> pick_block(bool cvx, bool h16, bool sw) {
-    if (cvx) {
-        if (h16) return sw ? poa_block_kernel<TMAX, W, true, true, true> : poa_block_kernel<TMAX, W, true, true, false>;
-        return sw ? poa_block_kernel<TMAX, W, true, false, true> : poa_block_kernel<TMAX, W, true, false, false>;
-    }
-    if (h16) return sw ? poa_block_kernel<TMAX, W, false, true, true> : poa_block_kernel<TMAX, W, false, true, false>;
-    return sw ? poa_block_kernel<TMAX, W, false, false, true> : poa_block_kernel<TMAX, W, false, false, false>;
+template <int TMAX, int W, int RM> static KernelFn<BlockArgs> pick_block(bool cvx, bool sw) {
+    if (cvx) return sw ? poa_block_kernel<TMAX, W, true, RM, true> : poa_block_kernel<TMAX, W, true, RM, false>;
+    return sw ? poa_block_kernel<TMAX, W, false, RM, true> : poa_block_kernel<TMAX, W, false, RM, false>;
 }
-template <int TMAX, int W> static KernelFn<AlignArgs> pick_align(bool cvx, bool h16, bool sw) {
-    if (cvx) {
-        if (h16) return sw ? poa_align_kernel<TMAX, W, true, true, true> : poa_align_kernel<TMAX, W, true, true, false>;
-        return sw ? poa_align_kernel<TMAX, W, true, false, true> : poa_align_kernel<TMAX, W, true, false, false>;
-    }
-    if (h16) return sw ? poa_align_kernel<TMAX, W, false, true, true> : poa_align_kernel<TMAX, W, false, true, false>;
-    return sw ? poa_align_kernel<TMAX, W, false, false, true> : poa_align_kernel<TMAX, W, false, false, false>;
+template <int TMAX, int W, int RM> static KernelFn<AlignArgs> pick_align(bool cvx, bool sw) {
+    if (cvx) return sw ? poa_align_kernel<TMAX, W, true, RM, true> : poa_align_kernel<TMAX, W, true, RM, false>;
+    return sw ? poa_align_kernel<TMAX, W, false, RM, true> : poa_align_kernel<TMAX, W, false, RM, false>;
 }
-static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool h16, bool sw) {
-    if (v.W == 12) {
-        if (v.TMAX == 256) return pick_block<256, 12>(cvx, h16, sw);
-        if (v.TMAX == 512) return pick_block<512, 12>(cvx, h16, sw);
-        return pick_block<1024, 12>(cvx, h16, sw);
-    }
-    if (v.W == 8) {
-        if (v.TMAX == 256) return pick_block<256, 8>(cvx, h16, sw);
-        if (v.TMAX == 512) return pick_block<512, 8>(cvx, h16, sw);
-        return pick_block<1024, 8>(cvx, h16, sw);
-    }
-    if (v.TMAX == 256) return pick_block<256, 16>(cvx, h16, sw);
-    if (v.TMAX == 512) return pick_block<512, 16>(cvx, h16, sw);
-    return pick_block<512, 16>(cvx, h16, sw);
+#define SXG_PICK(FN, TM, Wd)                                             \
+    do {                                                                 \
+        if (v.TMAX == TM && v.W == Wd) {                                 \
+            if (v.RM == 0) return FN<TM, Wd, 0>(cvx, sw);                \
+            if (v.RM == 1) return FN<TM, Wd, 1>(cvx, sw);                \
+        }                                                                \
+    } while (0)
+#define SXG_PICK16(FN, TM, Wd) \
+    do { if (v.TMAX == TM && v.W == Wd && v.RM == 2) return FN<TM, Wd, 2>(cvx, sw); } while (0)
+static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
+    SXG_PICK(pick_block, 256, 8); SXG_PICK(pick_block, 256, 12); SXG_PICK(pick_block, 256, 16);
+    SXG_PICK(pick_block, 512, 8); SXG_PICK(pick_block, 512, 12); SXG_PICK(pick_block, 512, 16);
+    SXG_PICK(pick_block, 1024, 8); SXG_PICK(pick_block, 1024, 12);
+    SXG_PICK16(pick_block, 256, 8); SXG_PICK16(pick_block, 256, 12);
+    SXG_PICK16(pick_block, 512, 8); SXG_PICK16(pick_block, 512, 12);
+    SXG_PICK16(pick_block, 1024, 8);
+    return nullptr;
 }
-static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool h16, bool sw) {
-    if (v.W == 12) {
-        if (v.TMAX == 256) return pick_align<256, 12>(cvx, h16, sw);
-        if (v.TMAX == 512) return pick_align<512, 12>(cvx, h16, sw);
-        return pick_align<1024, 12>(cvx, h16, sw);
-    }
-    if (v.W == 8) {
-        if (v.TMAX == 256) return pick_align<256, 8>(cvx, h16, sw);
-        if (v.TMAX == 512) return pick_align<512, 8>(cvx, h16, sw);
-        return pick_align<1024, 8>(cvx, h16, sw);
-    }
-    if (v.TMAX == 256) return pick_align<256, 16>(cvx, h16, sw);
-    if (v.TMAX == 512) return pick_align<512, 16>(cvx, h16, sw);
-    return pick_align<512, 16>(cvx, h16, sw);
+static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool sw) {
+    SXG_PICK(pick_align, 256, 8); SXG_PICK(pick_align, 256, 12); SXG_PICK(pick_align, 256, 16);
+    SXG_PICK(pick_align, 512, 8); SXG_PICK(pick_align, 512, 12); SXG_PICK(pick_align, 512, 16);
+    SXG_PICK(pick_align, 1024, 8); SXG_PICK(pick_align, 1024, 12);
+    SXG_PICK16(pick_align, 256, 8); SXG_PICK16(pick_align, 256, 12);
+    SXG_PICK16(pick_align, 512, 8); SXG_PICK16(pick_align, 512, 12);
+    SXG_PICK16(pick_align, 1024, 8);
+    return nullptr;
 }
 
 // Is an int16 H safe for the packed row words?  |H| bound: SW 0..m*L; NW additionally the
@@ -409,6 +422,22 @@ static bool h16_safe(const Scoring& S, int maxlen, int rows_max) {
         lo = std::abs(S.g) + std::abs(S.q) + ((long)rows_max + maxlen) * ext + (long)std::abs(S.n) * maxlen;
     }
     return hi < 30000 && lo < 30000;
+}
+
+// Can the packed-int16 sweep run?  Every reachable score and every intermediate (score +- one
+// penalty, difference of two scores) must stay inside int16 with NEGP = -16384 as "-inf".
+static bool p16_safe(const Scoring& S, int maxlen, int rows_max) {
+    if (getenv("SXG_POA_NO_PACKED")) return false;
+    long hi = (long)std::abs(S.m) * maxlen, lo = 0;
+    if (!S.sw) {
+        const long ext = std::max(std::max(std::abs(S.e), std::abs(S.c)), 1);
+        lo = std::abs(S.g) + std::abs(S.q) + ((long)rows_max + maxlen) * ext + (long)std::abs(S.n) * maxlen;
+    }
+    return hi < 15800 && lo < 15800;
+}
+static int row_mode(const Scoring& S, int maxlen, int rows_max) {
+    if (p16_safe(S, maxlen, rows_max)) return 2;
+    return h16_safe(S, maxlen, rows_max) ? 0 : 1;
 }
 
 struct DevBuf {
@@ -432,7 +461,7 @@ struct DevBuf {
 };
 
 struct BlockMeta {
-    int maxlen = 0, nseq = 0; bool fits = false; Variant variant{16, 1, 256};
+    int maxlen = 0, nseq = 0, rm = 0; bool fits = false; Variant variant{16, 1, 256, 0};
     int64_t sumlen = 0;
     double cost = 0;
     bool cvx = false, sw = true;
@@ -588,7 +617,8 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
             if (s > in->blk_off[b]) m.cost += (double)len * (l1 + 0.05 * prev);
             prev += (double)len;
         }
-        m.fits = variant_for_len(m.maxlen, &m.variant);
+        m.rm = row_mode(m.S, m.maxlen, (int)std::min<int64_t>(m.sumlen + 8, (1 << 20) - 1));
+        m.fits = variant_for_len(m.maxlen, m.rm, &m.variant);
     }
     // sanitise letters while copying to a staging buffer
     std::vector<uint8_t> stage((size_t)std::max<int64_t>(nbases, 1));
@@ -622,7 +652,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
 }
 
 struct LaunchPlan {
-    Variant variant; bool cvx, h16, sw;
+    Variant variant; bool cvx, sw;
     std::vector<int32_t> work;  // block ids, largest cost first
     // filled by prepare_plan
     SlotLayout lay; KernelFn<BlockArgs> kern = nullptr; int per_cu = 1; int64_t want_slots = 0, n_slots = 0;
@@ -651,12 +681,13 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
         rows_cap = nodes_cap; pool_slots = rows_cap + 1; step_cap = nodes_cap;  // edges <= nodes_cap
     }
     if (rows_cap >= (1 << 20)) rows_cap = (1 << 20) - 1;
-    const int wb = P.h16 ? 4 : 8;
-    P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false);
-    P.kern = block_kernel(P.variant, P.cvx, P.h16, P.sw);
+    const int wb = V.RM == 1 ? 8 : 4;
+    P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false, V.RM == 2);
+    P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
-    P.pf_off = getenv("SXG_POA_PREFETCH") ? dp_pf_offset(Lpad, wb, V.T()) : -1;
+    if (V.RM == 2) { P.smem = dp_lds_bytes(Lpad, wb); P.park_lds = true; }  // packed sweep parks in LDS only
+    P.pf_off = (V.RM != 2 && getenv("SXG_POA_PREFETCH")) ? dp_pf_offset(Lpad, wb, V.T()) : -1;
     if (P.pf_off >= 0) P.smem += dp_pf_bytes(Lpad, wb, V.T());
     if (P.smem > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)P.kern, hipFuncAttributeMaxDynamicSharedMemorySize, P.smem);
@@ -713,8 +744,8 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
     for (int k = 0; k < 6; ++k) tot += (double)acc[k];
     size_t fr = 0, tt = 0;
     (void)hipMemGetInfo(&fr, &tt);
-    fprintf(stderr, "[sxg] variant T=%d W=%d cvx=%d h16=%d attempt=%d work=%zu slots=%lld per_cu=%d smem=%d slot_bytes=%zu free=%zu ms=%.2f\n",
-            V.T(), V.W, (int)P.cvx, (int)P.h16, attempt, P.work.size(), (long long)P.n_slots, P.per_cu, P.smem, P.lay.total, fr, P.ms);
+    fprintf(stderr, "[sxg] variant T=%d W=%d cvx=%d rowmode=%d attempt=%d work=%zu slots=%lld per_cu=%d smem=%d slot_bytes=%zu free=%zu ms=%.2f\n",
+            V.T(), V.W, (int)P.cvx, V.RM, attempt, P.work.size(), (long long)P.n_slots, P.per_cu, P.smem, P.lay.total, fr, P.ms);
     fprintf(stderr, "[sxg]   slot time: other %.1f%% prep_rows %.1f%% dp_fill %.1f%% traceback %.1f%% add_alignment %.1f%% output %.1f%%\n",
             100 * acc[0] / tot, 100 * acc[1] / tot, 100 * acc[2] / tot, 100 * acc[3] / tot, 100 * acc[4] / tot, 100 * acc[5] / tot);
     return SXG_OK;
@@ -754,12 +785,10 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         std::vector<LaunchPlan> plans;
         for (int b : pending) {
             const BlockMeta& m = h->meta[b];
-            const int rows_max = (int)std::min<int64_t>(m.sumlen + 8, (1 << 20) - 1);
-            const bool h16 = h16_safe(m.S, m.maxlen, rows_max);
             LaunchPlan* pl = nullptr;
             for (auto& q : plans)
-                if (q.variant.W == m.variant.W && q.variant.NW == m.variant.NW && q.cvx == m.cvx && q.h16 == h16 && q.sw == m.sw) { pl = &q; break; }
-            if (!pl) { plans.emplace_back(); pl = &plans.back(); pl->variant = m.variant; pl->cvx = m.cvx; pl->h16 = h16; pl->sw = m.sw; }
+                if (q.variant.W == m.variant.W && q.variant.NW == m.variant.NW && q.variant.RM == m.variant.RM && q.cvx == m.cvx && q.sw == m.sw) { pl = &q; break; }
+            if (!pl) { plans.emplace_back(); pl = &plans.back(); pl->variant = m.variant; pl->cvx = m.cvx; pl->sw = m.sw; }
             pl->work.push_back(b);
         }
         std::sort(plans.begin(), plans.end(), [](const LaunchPlan& a, const LaunchPlan& b) { return a.variant.Lpad() > b.variant.Lpad(); });
@@ -822,8 +851,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         for (int s = h->h_blk_off[b]; s < h->h_blk_off[b + 1]; ++s) cb += cells[s];
         const BlockMeta& m = h->meta[b];
         const int ncross = m.S.convex ? 3 : (m.S.g == m.S.e ? 1 : 2);
-        const int rows_max = (int)std::min<int64_t>(m.sumlen + 8, (1 << 20) - 1);
-        const int sz = h16_safe(m.S, m.maxlen, rows_max) ? 2 : 4;
+        const int sz = m.rm == 1 ? 4 : 2;
         blk_cells[b] = cb; blk_bytes[b] = cb * (uint64_t)(2 * ncross * sz + 1);
         total += cb;
         bytes += blk_bytes[b];
@@ -833,7 +861,8 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         for (int b : pl.work) if (status[b] == ST_OK) { pl.cells += blk_cells[b]; pl.bytes += blk_bytes[b]; }
         if (pl.cells >= h->stats.dom_cells) {
             h->stats.dom_cells = pl.cells; h->stats.dom_algo_bytes = pl.bytes; h->stats.dom_kernel_ms = pl.ms;
-            h->stats.dom_threads = pl.variant.T(); h->stats.dom_cols_per_lane = pl.variant.W;
+            h->stats.dom_threads = pl.variant.T(); h->stats.dom_cols_per_lane = pl.variant.W * (pl.variant.RM == 2 ? 2 : 1);
+            h->stats.dom_row_mode = pl.variant.RM;
         }
     }
     lap("accounting");
@@ -1077,18 +1106,17 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
 
     }
     // plans
-    struct APlan { Variant variant; bool cvx, h16, sw; std::vector<int32_t> work; int rows_cap = 0; };
+    struct APlan { Variant variant; bool cvx, sw; std::vector<int32_t> work; int rows_cap = 0; };
     std::vector<APlan> plans;
     for (int p = 0; p < n; ++p) {
         const Scoring S = normalise(in->params[in->per_problem_params ? p : 0]);
         const int len = (int)(in->seq_off[p + 1] - in->seq_off[p]), N = (int)(in->row_off[p + 1] - in->row_off[p]);
         Variant v;
-        if (!variant_for_len(len, &v)) { o->status[p] = ST_TOO_LONG; continue; }
-        const bool h16 = h16_safe(S, len, N);
+        if (!variant_for_len(len, row_mode(S, len, N), &v)) { o->status[p] = ST_TOO_LONG; continue; }
         APlan* pl = nullptr;
         for (auto& q : plans)
-            if (q.variant.W == v.W && q.variant.NW == v.NW && q.cvx == (bool)S.convex && q.h16 == h16 && q.sw == (bool)S.sw) { pl = &q; break; }
-        if (!pl) { plans.push_back(APlan{v, (bool)S.convex, h16, (bool)S.sw, {}, 0}); pl = &plans.back(); }
+            if (q.variant.W == v.W && q.variant.NW == v.NW && q.variant.RM == v.RM && q.cvx == (bool)S.convex && q.sw == (bool)S.sw) { pl = &q; break; }
+        if (!pl) { plans.push_back(APlan{v, (bool)S.convex, (bool)S.sw, {}, 0}); pl = &plans.back(); }
         pl->work.push_back(p);
         pl->rows_cap = std::max(pl->rows_cap, N);
     }
@@ -1099,13 +1127,14 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         int64_t maxe = 0;
         for (int p : pl.work) maxe = std::max<int64_t>(maxe, in->pred_off[in->row_off[p + 1]] - in->pred_off[in->row_off[p]]);
         // r_preds is sized by nodes_cap in make_layout: give it the edge count
+        const int wb = V.RM == 1 ? 8 : 4;
         const SlotLayout lay2 = make_layout((int)std::max<int64_t>(maxe + 8, rows_cap + 8), rows_cap, rows_cap + 1,
-                                            (int)maxe + 8, V.T(), V.Lpad(), pl.h16 ? 4 : 8, true);
-        auto kern = align_kernel(pl.variant, pl.cvx, pl.h16, pl.sw);
+                                            (int)maxe + 8, V.T(), V.Lpad(), wb, true, V.RM == 2);
+        auto kern = align_kernel(pl.variant, pl.cvx, pl.sw);
         int per_cu = 1;
-        int smem = dp_lds_launch_bytes(V.Lpad(), pl.h16 ? 4 : 8);
-        const int pf_off = getenv("SXG_POA_PREFETCH") ? dp_pf_offset(V.Lpad(), pl.h16 ? 4 : 8, V.T()) : -1;
-        if (pf_off >= 0) smem += dp_pf_bytes(V.Lpad(), pl.h16 ? 4 : 8, V.T());
+        int smem = V.RM == 2 ? dp_lds_bytes(V.Lpad(), wb) : dp_lds_launch_bytes(V.Lpad(), wb);
+        const int pf_off = (V.RM != 2 && getenv("SXG_POA_PREFETCH")) ? dp_pf_offset(V.Lpad(), wb, V.T()) : -1;
+        if (pf_off >= 0) smem += dp_pf_bytes(V.Lpad(), wb, V.T());
         if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, V.T(), (size_t)smem) != hipSuccess || per_cu < 1) per_cu = 1;
         const uint64_t budget = arena_budget(h);
@@ -1123,7 +1152,7 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         A.arena = d_arena.as<uint8_t>(); A.lay = lay2;
         A.status = d_status.as<int32_t>(); A.score = d_score.as<int32_t>(); A.n_pairs = d_np.as<int32_t>();
         A.pair_row = d_pr.as<int32_t>(); A.pair_pos = d_pp.as<int32_t>();
-        A.park_in_lds = dp_park_in_lds(V.Lpad(), pl.h16 ? 4 : 8) ? 1 : 0;
+        A.park_in_lds = (V.RM == 2 || dp_park_in_lds(V.Lpad(), wb)) ? 1 : 0;
         A.pf_off = pf_off;
         hipLaunchKernelGGL(kern, dim3((unsigned)n_slots), dim3(V.T()), (size_t)smem, h->stream, A);
         HCK(hipGetLastError());

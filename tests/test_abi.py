@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     from smoothxg_amd import poa
     assert C.sizeof(poa.Params) == 8
     assert C.sizeof(poa.BatchIn) == 8 + 5 * 8 + 3 * 4 + 4  # n_blocks(+pad), 5 pointers, 3 ints (+pad)
-    assert C.sizeof(poa.Stats) == 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 4 + 4
+    assert C.sizeof(poa.Stats) == 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 4 + 4 + 4 + 4
 
 
 def test_xxh64_product_matches_python_xxhash():
