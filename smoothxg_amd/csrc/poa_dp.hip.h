@@ -600,23 +600,32 @@ __device__ __noinline__ int traceback(const RowsView& R, const DpBuffers& B, con
             continue;
         }
         const int r = i - 1;
+        // one round trip per step: the cell's byte and the row descriptor (first two predecessors)
         const unsigned tbyte = B.tb[(size_t)i * Lpad + j];
-        const int pb = R.pred_off[r], np = R.pred_off[r + 1] - pb;
+        const int4 d0 = *(const int4*)(R.meta + 8 * (size_t)r), d1 = *(const int4*)(R.meta + 8 * (size_t)r + 4);
+        const int node = R.row_node[r];
+        const int pb = d0.x, np = d0.y & 0xffff, q0 = d0.z, q1 = d1.x;
+        auto pred_of = [&](int which) -> int {
+            if (np == 0) return 0;
+            if (np == 1) return q0;
+            const int ord = winner_ordinal(R, B, T, W, r, np, j, which);
+            return ord == 0 ? q0 : (ord == 1 ? q1 : R.preds[pb + ord]);
+        };
         if (st == SRC_STOP) {
             const int src = tbyte & 7;
             if (src == SRC_STOP) break;
             if (src == SRC_D) {
                 if (PAIRS) { pair_row[n] = i; pair_pos[n] = j - 1; }
-                if (posnode) posnode[j - 1] = R.row_node[r];
+                if (posnode) posnode[j - 1] = node;
                 ++n;
-                i = np ? R.preds[pb + (np > 1 ? winner_ordinal(R, B, T, W, r, np, j, 0) : 0)] : 0;
+                i = pred_of(0);
                 --j;
             } else st = src;
         } else if (st == SRC_F || st == SRC_O) {
             const int ext = st == SRC_F ? (tbyte & TB_FEXT) : (tbyte & TB_OEXT);
             if (PAIRS) { pair_row[n] = i; pair_pos[n] = -1; }
             ++n;
-            i = np ? R.preds[pb + (np > 1 ? winner_ordinal(R, B, T, W, r, np, j, st == SRC_F ? 1 : 2) : 0)] : 0;
+            i = pred_of(st == SRC_F ? 1 : 2);
             if (!ext) st = SRC_STOP;
         } else {
             const int ext = st == SRC_E ? (tbyte & TB_EEXT) : (tbyte & TB_QEXT);

@@ -458,32 +458,45 @@ __device__ __noinline__ int traceback_p16(const RowsView& R, const DpBuffers& B,
         const int r = i - 1;
         const int half = j >= TW ? 1 : 0, jj = j - half * TW;
         const int lt = jj / W, bit = (jj - lt * W) + 16 * half;
+        // one round trip per step: the 9 mask words of the cell's lane and the row descriptor
+        // (which carries the first two predecessors) are fetched together
         const uint32_t* mw = (const uint32_t*)B.tb + ((size_t)i * T + lt) * P16_TB_WORDS;
-        const int pb = R.pred_off[r], np = R.pred_off[r + 1] - pb;
+        uint32_t m[P16_TB_WORDS];
+#pragma unroll
+        for (int x = 0; x < P16_TB_WORDS; ++x) m[x] = mw[x];
+        const int4 d0 = *(const int4*)(R.meta + 8 * (size_t)r), d1 = *(const int4*)(R.meta + 8 * (size_t)r + 4);
+        const int node = R.row_node[r];
+        const int pb = d0.x, np = d0.y & 0xffff, q0 = d0.z, q1 = d1.x;
+        auto pred_of = [&](int which) -> int {
+            if (np == 0) return 0;
+            if (np == 1) return q0;
+            const int ord = p16_winner(R, B, T, r, np, lt, bit, which);
+            return ord == 0 ? q0 : (ord == 1 ? q1 : R.preds[pb + ord]);
+        };
         if (st == SRC_STOP) {
             int src;
-            if ((mw[PM_STOP] >> bit) & 1u) src = SRC_STOP;
-            else if ((mw[PM_GTQ] >> bit) & 1u) src = SRC_Q;
-            else if ((mw[PM_GTE] >> bit) & 1u) src = SRC_E;
-            else if ((mw[PM_GTO] >> bit) & 1u) src = SRC_O;
-            else if ((mw[PM_GTF] >> bit) & 1u) src = SRC_F;
+            if ((m[PM_STOP] >> bit) & 1u) src = SRC_STOP;
+            else if ((m[PM_GTQ] >> bit) & 1u) src = SRC_Q;
+            else if ((m[PM_GTE] >> bit) & 1u) src = SRC_E;
+            else if ((m[PM_GTO] >> bit) & 1u) src = SRC_O;
+            else if ((m[PM_GTF] >> bit) & 1u) src = SRC_F;
             else src = SRC_D;
             if (src == SRC_STOP) break;
             if (src == SRC_D) {
                 if (PAIRS) { pair_row[n] = i; pair_pos[n] = j - 1; }
-                if (posnode) posnode[j - 1] = R.row_node[r];
+                if (posnode) posnode[j - 1] = node;
                 ++n;
-                i = np ? R.preds[pb + (np > 1 ? p16_winner(R, B, T, r, np, lt, bit, 0) : 0)] : 0;
+                i = pred_of(0);
                 --j;
             } else st = src;
         } else if (st == SRC_F || st == SRC_O) {
-            const unsigned ext = (mw[st == SRC_F ? PM_FX : PM_OX] >> bit) & 1u;
+            const unsigned ext = (m[st == SRC_F ? PM_FX : PM_OX] >> bit) & 1u;
             if (PAIRS) { pair_row[n] = i; pair_pos[n] = -1; }
             ++n;
-            i = np ? R.preds[pb + (np > 1 ? p16_winner(R, B, T, r, np, lt, bit, st == SRC_F ? 1 : 2) : 0)] : 0;
+            i = pred_of(st == SRC_F ? 1 : 2);
             if (!ext) st = SRC_STOP;
         } else {
-            const unsigned ext = (mw[st == SRC_E ? PM_EX : PM_QX] >> bit) & 1u;
+            const unsigned ext = (m[st == SRC_E ? PM_EX : PM_QX] >> bit) & 1u;
             if (PAIRS) { pair_row[n] = 0; pair_pos[n] = j - 1; }
             ++n; --j;
             if (!ext) st = SRC_STOP;
