@@ -180,13 +180,16 @@ def main():
             "metric": "POA blocks/sec (+ DP cells/sec) on 1000-block synthetic",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16" if st["dom_row_mode"] == 2 else "int32", "data": "synthetic",
             "config": {"workload": desc, "blocks_per_gpu": nb, "mode": a.mode,
                        "cells_per_step_per_gpu": cells / a.steps},
             "cells_per_sec": total_cells / dt,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "poa_block_kernel", "kernel_ms_per_launch": kernel_ms / max(launches, 1),
+                         "kernel": "poa_block_kernel<T=%d, cols/lane=%d, %s>" % (
+                             st["dom_threads"], st["dom_cols_per_lane"],
+                             "packed int16 sweep" if st["dom_row_mode"] == 2 else "32-bit sweep"),
+                         "kernel_ms_per_launch": kernel_ms / max(launches, 1),
                          "algo_bytes_per_launch": algo_bytes / max(launches, 1),
                          "bytes_per_cell": algo_bytes / max(cells, 1)},
             "engine": {"slots": st["n_slots"], "retries": st["retries"], "arena_bytes": st["device_bytes"]},
