@@ -170,3 +170,24 @@ def test_north_star_shape_properties(engine, oracle):
     g, sc, cells = oracle.block_run(seqs[:6], None, oparams("convex_default", 0))
     assert_block_equal(head, g, sc, cells, label="ns-head")
     assert (full.scores[:6] == sc).all() and (full.cells[:6] == cells).all()
+
+
+def test_mixed_depth_and_length_batch_properties(engine, oracle):
+    """BASELINE config 4 in miniature: blocks of 8-128 sequences x 0.5-10 kbp in ONE batch (several
+    launch geometries run concurrently, arenas are sized per geometry).  Invariants on every block,
+    oracle equality on the cheapest one."""
+    bases, seq_off, blk_off = synth.make_batch(10, 0, 0, first_block=900, mixed=True)
+    res = engine.run_flat(bases, seq_off, blk_off, None, gparams("convex_default", 0))
+    costs = []
+    for b, r in enumerate(res):
+        assert r.status == 0
+        seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[b], blk_off[b + 1])]
+        for s, q in enumerate(seqs):
+            assert (r.node_code[r.paths[s]] == q).all()
+        assert (r.node_rank[r.edge_tail] < r.node_rank[r.edge_head]).all()
+        assert int(r.edge_weight.sum()) == sum(2 * (len(q) - 1) for q in seqs)
+        costs.append(int(r.cells.sum()))
+    b = int(np.argmin(costs))
+    seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[b], blk_off[b + 1])]
+    g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
+    assert_block_equal(res[b], g, sc, cells, label="mixed-cheapest")
