@@ -1,0 +1,88 @@
+/*
+ * sxg_smooth.h -- C ABI of the host-side rows around the blocked-POA engine:
+ *
+ *   A2  append_to_sequence (flank padding)            src/smooth.cpp:75-126
+ *   A3  sequence collection, orientation, XXH64 dedup src/smooth.cpp:676-743
+ *   A4  padding size                                  src/smooth.cpp:1946-1970
+ *   A9  build_odgi_SPOA (POA graph -> block graph)    src/smooth.cpp:2576-2654
+ *   A10 unchop + topological order + re-copy          src/smooth.cpp:935-1010
+ *   8f-1 lacing of the block graphs + GFA writer      src/main.cpp:599-1061
+ *   8f-3 minimal GFA reader (S/P lines)               src/xg.cpp:696-741 (what the path needs of it)
+ *
+ * Built by g++ into libsxgsmooth.so (no HIP inside): the POA itself is reached through a callback
+ * with the signature of sxg_poa_batch_run (include/sxg_poa.h), so production passes the GPU engine
+ * and nothing in this library can fall back to a CPU aligner.
+ *
+ * odgi (unchop, topological_order, to_gfa) is absent from the reference snapshot, so those three
+ * are restated by decree: parity with real odgi bytes is unpinned.
+ * All strings returned through char** are malloc'ed; release with sxg_smooth_free().
+ */
+#ifndef SXG_SMOOTH_H
+#define SXG_SMOOTH_H
+#include <stddef.h>
+#include <stdint.h>
+#include "sxg_poa.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sxg_graph sxg_graph;       /* input graph: node sequences + paths (XG's role) */
+typedef struct sxg_blockset sxg_blockset; /* blockset_t: blocks of path ranges, src/blocks.hpp:29-120 */
+
+/* POA provider: exactly sxg_poa_batch_run's contract, ctx is its handle. */
+typedef int (*sxg_poa_run_fn)(void *ctx, const sxg_poa_batch_in *in, sxg_poa_batch_out *out);
+typedef void (*sxg_poa_free_fn)(sxg_poa_batch_out *out);
+
+/* smoothxg's knobs on this path with their defaults (src/main.cpp:291-361,487). */
+typedef struct sxg_smooth_params {
+    int32_t poa_m, poa_n, poa_g, poa_e, poa_q, poa_c; /* CLI convention: positive penalties (1,4,6,2,26,1) */
+    int32_t local_alignment;                          /* 1 = default; 0 = -Z */
+    float poa_padding_fraction;                       /* -O, default 0.001 */
+    uint64_t max_block_depth_for_padding_more;        /* -Y, default 1000 */
+    int32_t add_consensus;                            /* embed Consensus_<block> paths (last iteration) */
+    const char *consensus_base_name;                  /* default "Consensus_" */
+} sxg_smooth_params;
+
+void sxg_smooth_default_params(sxg_smooth_params *p);
+const char *sxg_smooth_last_error(void);
+void sxg_smooth_free(void *p);
+
+/* GFA reader: S and P lines (L lines are implied by the paths for everything on this path).
+ * Letters outside ACGT become N as in XG's 3-bit alphabet (src/xg.cpp:24-53). */
+int sxg_graph_from_gfa(const char *text, size_t len, sxg_graph **out);
+void sxg_graph_free(sxg_graph *g);
+int64_t sxg_graph_node_count(const sxg_graph *g);
+int64_t sxg_graph_path_count(const sxg_graph *g);
+
+/* Test/demo blockset: every path is cut into consecutive windows of >= target_bp and the k-th window
+ * of every path forms block k.  This is NOT the reference's smoothable_blocks()/break_blocks() (block
+ * discovery is out of scope): it only provides a valid partition of all path
+ * steps -- roughly homologous for collinear haplotypes -- so that collection, POA and lacing can be
+ * exercised end to end.  Ranges of a block are ordered longest first (src/blocks.cpp:206-219). */
+int sxg_blockset_by_path_windows(const sxg_graph *g, uint64_t target_bp, sxg_blockset **out);
+void sxg_blockset_free(sxg_blockset *b);
+int64_t sxg_blockset_size(const sxg_blockset *b);
+
+/* A2-A4 for one block, as text (one line per record) for inspection and tests:
+ *   "padding\t<poa_padding>"
+ *   "seq\t<rank>\t<weight>\t<sequence>"                     dedup'd, alignment order
+ *   "dup\t<rank>\t<path_range index>\t<is_rev 0|1>\t<name>"  every original range            */
+int sxg_block_collect_text(const sxg_graph *g, const sxg_blockset *b, int64_t block_id,
+                           const sxg_smooth_params *p, char **out_text);
+
+/* A9+A10 for one block given its POA result: the normalised block graph as GFA text. */
+int sxg_block_graph_gfa(const sxg_graph *g, const sxg_blockset *b, int64_t block_id,
+                        const sxg_smooth_params *p, sxg_poa_run_fn run, sxg_poa_free_fn fre, void *ctx,
+                        char **out_gfa);
+
+/* One smoothing iteration over all blocks: collect -> ONE batched POA call -> block graphs ->
+ * lace -> validate (every path spells its original sequence, src/main.cpp:770-810) -> unchop ->
+ * GFA text.  Returns SXG_OK, or SXG_E_INVALID if validation fails. */
+int sxg_smooth_gfa(const sxg_graph *g, const sxg_blockset *b, const sxg_smooth_params *p,
+                   sxg_poa_run_fn run, sxg_poa_free_fn fre, void *ctx, char **out_gfa);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

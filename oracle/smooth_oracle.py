@@ -1,0 +1,417 @@
+"""smooth_oracle.py -- CPU ORACLE (pure Python, small cases) for the host-side rows around the POA:
+
+    A2  append_to_sequence            /root/reference/src/smooth.cpp:75-126
+    A3  collect / orient / dedup      src/smooth.cpp:676-743
+    A4  padding size                  src/smooth.cpp:1946-1970
+    A9  build_odgi_SPOA               src/smooth.cpp:2576-2654
+    A10 unchop, order, re-copy        src/smooth.cpp:935-1010
+    8f  lacing, validation, GFA       src/main.cpp:599-1061
+
+TEST INFRASTRUCTURE ONLY (tests/ imports it; nothing under smoothxg_amd/ does).
+PARITY UNPINNED for the three odgi pieces: odgi is an empty submodule in the reference snapshot, so
+unchop / topological_order / to_gfa are restated BY DECREE here (same decree as
+smoothxg_amd/csrc/sxg_smooth.cpp).  A2-A4, A9 and the lacing follow in-tree
+reference code and are restated literally (quirks included).  The POA itself comes from
+oracle/poa_oracle.c through oracle_py.
+"""
+import heapq
+import struct
+
+import numpy as np
+import xxhash  # independent XXH64 (the C restatements are pinned against it in tests)
+
+from . import oracle_py as O
+
+COMP = {"A": "T", "T": "A", "C": "G", "G": "C"}
+
+
+def revcomp(s):
+    return "".join(COMP.get(c, "N") for c in reversed(s))
+
+
+def mk(n, rev):
+    return (n << 1) | (1 if rev else 0)
+
+
+class Graph:
+    """S and P lines of a GFA; letters outside ACGT -> N (XG alphabet, src/xg.cpp:24-53)."""
+
+    def __init__(self, text):
+        nodes, plines = [], []
+        for line in text.split("\n"):
+            f = line.rstrip("\r").split("\t")
+            if f[0] == "S" and len(f) >= 3:
+                nodes.append((int(f[1]), "".join(c if c in "ACGT" else "N" for c in f[2].upper())))
+            elif f[0] == "P" and len(f) >= 3:
+                plines.append((f[1], f[2]))
+        nodes.sort(key=lambda x: x[0])
+        self.ids = [n[0] for n in nodes]
+        self.seq = [n[1] for n in nodes]
+        rank = {i: k for k, i in enumerate(self.ids)}
+        self.pname, self.steps, self.pos = [], [], []
+        for name, st in plines:
+            hs, ps, bp = [], [], 0
+            for tok in st.split(","):
+                if not tok:
+                    continue
+                n = rank[int(tok[:-1])]
+                hs.append(mk(n, tok[-1] == "-"))
+                ps.append(bp)
+                bp += len(self.seq[n])
+            ps.append(bp)
+            self.pname.append(name)
+            self.steps.append(hs)
+            self.pos.append(ps)
+
+    def sequence(self, h):
+        s = self.seq[h >> 1]
+        return revcomp(s) if h & 1 else s
+
+    def path_sequence(self, p):
+        return "".join(self.sequence(h) for h in self.steps[p])
+
+
+def blockset_by_path_windows(g, target_bp):
+    """Fixture partition (NOT smoothable_blocks): see include/sxg_smooth.h."""
+    blocks = []
+    for p, st in enumerate(g.steps):
+        s, k = 0, 0
+        while s < len(st):
+            e, bp = s, 0
+            while e < len(st) and bp < target_bp:
+                bp += len(g.seq[st[e] >> 1])
+                e += 1
+            while len(blocks) <= k:
+                blocks.append([])
+            blocks[k].append((p, s, e, bp))
+            s, k = e, k + 1
+    return [sorted(b, key=lambda r: -r[3]) for b in blocks]  # stable, longest first
+
+
+def append_to_sequence(g, path, starting_step, poa_padding, on_the_left):
+    """src/smooth.cpp:75-126 -> (text, fwd_bp, rev_bp)"""
+    step = starting_step
+    final_step = 0 if on_the_left else len(g.steps[path])
+    to_add, tmp, fwd, rev = poa_padding, "", 0, 0
+    while step != final_step and to_add > 0:
+        h = g.steps[path][step]
+        s = g.sequence(h)
+        if len(s) <= to_add:
+            tmp += s
+            added = len(s)
+        else:
+            tmp += s[len(s) - to_add:]
+            added = to_add
+        if h & 1:
+            rev += added
+        else:
+            fwd += added
+        to_add -= added
+        step += -1 if on_the_left else 1
+    return ("N" * to_add + tmp) if on_the_left else (tmp + "N" * to_add), fwd, rev
+
+
+def padding_size(g, ranges, fraction, max_depth):
+    """src/smooth.cpp:1946-1970; the reference accumulates in float32."""
+    pad = 0
+    if fraction > 0:
+        if len(ranges) <= max_depth:
+            pad = 311
+        avg = np.float32(0.0)
+        for (p, b, e, _) in ranges:
+            for s in range(b, e):
+                avg = np.float32(avg + np.float32(len(g.seq[g.steps[p][s] >> 1])))
+        avg = np.float32(avg / np.float32(len(ranges)))
+        pad = max(int(np.float32(avg * np.float32(fraction))), pad)
+    return pad
+
+
+class Collected:
+    pass
+
+
+def collect(g, ranges, fraction=0.001, max_depth=1000):
+    """src/smooth.cpp:676-743"""
+    c = Collected()
+    c.poa_padding, c.seqs, c.weights = 0, [], []
+    c.dup_is_revs, c.dup_seq_names, c.dup_rank, c.all_names = [], [], [], []
+    if not ranges:
+        return c
+    c.poa_padding = padding_size(g, ranges, fraction, max_depth)
+    seq_to_rank = {}
+    for i, (p, b, e, _) in enumerate(ranges):
+        left, f1, r1 = append_to_sequence(g, p, b, c.poa_padding, True)
+        mid, fwd, rev = "", f1, r1
+        for s in range(b, e):
+            h = g.steps[p][s]
+            mid += g.sequence(h)
+            if h & 1:
+                rev += len(g.seq[h >> 1])
+            else:
+                fwd += len(g.seq[h >> 1])
+        right, f2, r2 = append_to_sequence(g, p, e, c.poa_padding, False)
+        fwd, rev = fwd + f2, rev + r2
+        seq = left + mid + right
+        is_rev = rev > fwd
+        if is_rev:
+            seq = revcomp(seq)
+        name = "%s_%d" % (g.pname[p], g.pos[p][b])
+        key = xxhash.xxh64(seq.encode(), seed=0).intdigest()
+        if key not in seq_to_rank:
+            seq_to_rank[key] = len(c.seqs)
+            c.seqs.append(seq)
+            c.weights.append(1)
+            c.dup_is_revs.append([is_rev])
+            c.dup_seq_names.append([name])
+            c.dup_rank.append([i])
+        else:
+            k = seq_to_rank[key]
+            c.weights[k] += 1
+            c.dup_is_revs[k].append(is_rev)
+            c.dup_seq_names[k].append(name)
+            c.dup_rank[k].append(i)
+        c.all_names.append(name)
+    if max(len(s) for s in c.seqs) == 0:
+        pad = c.poa_padding
+        c = Collected()
+        c.poa_padding, c.seqs, c.weights = pad, [], []
+        c.dup_is_revs, c.dup_seq_names, c.dup_rank, c.all_names = [], [], [], []
+    return c
+
+
+def collect_text(c):
+    out = ["padding\t%d" % c.poa_padding]
+    for i, s in enumerate(c.seqs):
+        out.append("seq\t%d\t%d\t%s" % (i, c.weights[i], s))
+    for i in range(len(c.seqs)):
+        for j, nm in enumerate(c.dup_seq_names[i]):
+            out.append("dup\t%d\t%d\t%d\t%s" % (i, c.dup_rank[i][j], 1 if c.dup_is_revs[i][j] else 0, nm))
+    return "\n".join(out) + "\n"
+
+
+CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+def poa(c, m=1, n=4, g=6, e=2, q=26, cc=1, local=True):
+    """The POA of one block through the C oracle -> (node letters, per-seq paths, consensus)."""
+    seqs = [np.array([CODE.get(ch, 4) for ch in s], np.uint8) for s in c.seqs]
+    G, _, _ = O.block_run(seqs, c.weights, O.mkparams(m, -n, -g, -e, -q, -cc, 0 if local else 1))
+    code = G.nodes()[0]
+    return code, [G.seq_path(k) for k in range(len(seqs))], G.consensus()
+
+
+class OGraph:
+    def __init__(self):
+        self.seq, self.edges, self.paths = [], set(), []
+
+    @staticmethod
+    def canon(a, b):
+        x, y = (a, b), (b ^ 1, a ^ 1)
+        return y if y < x else x
+
+    def add_edge(self, a, b):
+        self.edges.add(self.canon(a, b))
+
+
+def unchop(G):
+    """Decree (odgi absent): merge u+ -> v+ when the right side of u has the single edge to v+, the
+    left side of v the single edge from u+, u != v, and no path starts or ends inside the link."""
+    n = len(G.seq)
+    out = [[] for _ in range(2 * n)]
+    for (a, b) in sorted(G.edges):
+        out[a].append(b)
+        out[b ^ 1].append(a ^ 1)
+    start_at, end_at = [0] * (2 * n), [0] * (2 * n)
+    for _, st in G.paths:
+        if st:
+            start_at[st[0]] = 1
+            end_at[st[0] ^ 1] = 1
+            end_at[st[-1]] = 1
+            start_at[st[-1] ^ 1] = 1
+    nxt, prv = [-1] * n, [-1] * n
+    for u in range(n):
+        uf = u << 1
+        if len(out[uf]) != 1:
+            continue
+        vf = out[uf][0]
+        if (vf & 1) or (vf >> 1) == u:
+            continue
+        v = vf >> 1
+        if len(out[vf ^ 1]) != 1 or out[vf ^ 1][0] != (uf ^ 1):
+            continue
+        if end_at[uf] or start_at[vf] or end_at[vf ^ 1] or start_at[uf ^ 1]:
+            continue
+        nxt[u], prv[v] = v, u
+    seen = [0] * n
+    for u in range(n):  # break pure cycles at their smallest member
+        if seen[u] or prv[u] < 0:
+            continue
+        x, walk, cyc = u, [], False
+        while True:
+            seen[x] = 1
+            walk.append(x)
+            if prv[x] < 0:
+                break
+            x = prv[x]
+            if x == u:
+                cyc = True
+                break
+            if seen[x]:
+                break
+        if cyc:
+            m = min(walk)
+            nxt[prv[m]] = -1
+            prv[m] = -1
+    chain_of, first_of, last_of, nseq = [-1] * n, [], [], []
+    for u in range(n):
+        if prv[u] >= 0:
+            continue
+        c, s, x = len(nseq), "", u
+        while True:
+            chain_of[x] = c
+            s += G.seq[x]
+            last = x
+            if nxt[x] < 0:
+                break
+            x = nxt[x]
+        nseq.append(s)
+        first_of.append(u)
+        last_of.append(last)
+    ne = set()
+    for (a, b) in G.edges:
+        if not (a & 1) and not (b & 1) and nxt[a >> 1] == (b >> 1):
+            continue
+        ne.add(OGraph.canon((chain_of[a >> 1] << 1) | (a & 1), (chain_of[b >> 1] << 1) | (b & 1)))
+    for k, (name, st) in enumerate(G.paths):
+        ns = []
+        for h in st:
+            x, c = h >> 1, chain_of[h >> 1]
+            if not (h & 1):
+                if first_of[c] == x:
+                    ns.append(c << 1)
+            elif last_of[c] == x:
+                ns.append((c << 1) | 1)
+        G.paths[k] = (name, ns)
+    G.seq, G.edges = nseq, ne
+
+
+def topo_renumber(G):
+    """Decree: Kahn over forward-forward edges, smallest node first; leftovers in id order."""
+    n = len(G.seq)
+    succ, indeg = [[] for _ in range(n)], [0] * n
+    for (a, b) in sorted(G.edges):
+        if not (a & 1) and not (b & 1) and (a >> 1) != (b >> 1):
+            succ[a >> 1].append(b >> 1)
+            indeg[b >> 1] += 1
+    heap = [u for u in range(n) if not indeg[u]]
+    heapq.heapify(heap)
+    newid, k = [-1] * n, 0
+    while heap:
+        u = heapq.heappop(heap)
+        newid[u] = k
+        k += 1
+        for v in succ[u]:
+            indeg[v] -= 1
+            if indeg[v] == 0:
+                heapq.heappush(heap, v)
+    for u in range(n):
+        if newid[u] < 0:
+            newid[u] = k
+            k += 1
+    nseq = [None] * n
+    for u in range(n):
+        nseq[newid[u]] = G.seq[u]
+    G.edges = {OGraph.canon((newid[a >> 1] << 1) | (a & 1), (newid[b >> 1] << 1) | (b & 1)) for (a, b) in G.edges}
+    G.paths = [(nm, [(newid[h >> 1] << 1) | (h & 1) for h in st]) for nm, st in G.paths]
+    G.seq = nseq
+
+
+def to_gfa(G):
+    o = ["H\tVN:Z:1.0"]
+    for i, s in enumerate(G.seq):
+        o.append("S\t%d\t%s" % (i + 1, s))
+    for (a, b) in sorted(G.edges):
+        o.append("L\t%d\t%s\t%d\t%s\t0M" % ((a >> 1) + 1, "-" if a & 1 else "+", (b >> 1) + 1, "-" if b & 1 else "+"))
+    for nm, st in G.paths:
+        o.append("P\t%s\t%s\t*" % (nm, ",".join("%d%s" % ((h >> 1) + 1, "-" if h & 1 else "+") for h in st)))
+    return "\n".join(o) + "\n"
+
+
+def build_block_graph(c, node_code, seq_paths, cons, consensus_name):
+    """A9 (src/smooth.cpp:2576-2654) + A10 (:935-1010)."""
+    by_name = []
+    for i, s in enumerate(c.seqs):
+        for j, nm in enumerate(c.dup_seq_names[i]):
+            st = [int(v) << 1 for v in seq_paths[i][c.poa_padding:len(s) - c.poa_padding]]
+            if c.dup_is_revs[i][j]:
+                st = [h ^ 1 for h in reversed(st)]
+            by_name.append((nm, st))
+    if consensus_name:
+        by_name.append((consensus_name, [int(v) << 1 for v in cons]))
+    used = sorted({h >> 1 for _, st in by_name for h in st})
+    keep = {v: k for k, v in enumerate(used)}
+    G = OGraph()
+    G.seq = ["ACGTN"[min(int(node_code[v]), 4)] for v in used]
+    by_name = [(nm, [(keep[h >> 1] << 1) | (h & 1) for h in st]) for nm, st in by_name]
+    for _, st in by_name:
+        for a, b in zip(st[:-1], st[1:]):
+            G.add_edge(a, b)
+    idx = {nm: k for k, (nm, _) in enumerate(by_name)}
+    G.paths = [by_name[idx[nm]] for nm in c.all_names]
+    if consensus_name:
+        G.paths.append(by_name[-1])
+    unchop(G)
+    topo_renumber(G)
+    return G
+
+
+def smooth(g, blocks, add_consensus=False, consensus_base="Consensus_", fraction=0.001, max_depth=1000, **scores):
+    """One smoothing iteration (src/main.cpp:599-1061 around the per-block POA) -> GFA text."""
+    cols = [collect(g, b, fraction, max_depth) for b in blocks]
+    graphs, mapping = [], []
+    for k, c in enumerate(cols):
+        if not c.seqs:
+            graphs.append(OGraph())
+            continue
+        code, paths, cons = poa(c, **scores)
+        G = build_block_graph(c, code, paths, cons, (consensus_base + str(k)) if add_consensus else "")
+        graphs.append(G)
+        if not G.seq:
+            continue
+        for t, (p, b, e, _) in enumerate(blocks[k]):
+            mapping.append((p, g.pos[p][b], g.pos[p][e], t, k))
+    mapping.sort(key=lambda f: (f[0], f[1]))
+    S, id_trans = OGraph(), []
+    for G in graphs:
+        off = len(S.seq)
+        id_trans.append(off)
+        S.seq.extend(G.seq)
+        for (a, b) in G.edges:
+            S.add_edge(a + (off << 1), b + (off << 1))
+    a = 0
+    while a < len(mapping):
+        z = a
+        while z < len(mapping) and mapping[z][0] == mapping[a][0]:
+            z += 1
+        steps, last_end = [], 0
+        for (p, start, end, t, k) in mapping[a:z]:
+            assert start == last_end, "path not covered by the blocks"
+            steps.extend(h + (id_trans[k] << 1) for h in graphs[k].paths[t][1])
+            last_end = end
+        assert last_end == g.pos[mapping[a][0]][-1]
+        S.paths.append((g.pname[mapping[a][0]], steps))
+        a = z
+    byname = {nm: k for k, nm in enumerate(g.pname)}
+    assert len(S.paths) == sum(1 for st in g.steps if st)
+    for nm, st in S.paths:  # src/main.cpp:770-803
+        spelled = "".join(revcomp(S.seq[h >> 1]) if h & 1 else S.seq[h >> 1] for h in st)
+        assert spelled == g.path_sequence(byname[nm]), "path %s corrupted" % nm
+    if add_consensus:
+        for k, G in enumerate(graphs):
+            if G.seq:
+                S.paths.append((G.paths[-1][0], [h + (id_trans[k] << 1) for h in G.paths[-1][1]]))
+    for _, st in S.paths:
+        for x, y in zip(st[:-1], st[1:]):
+            S.add_edge(x, y)
+    unchop(S)
+    return to_gfa(S)

@@ -29,5 +29,24 @@ def build(force=False, verbose=False):
     return SO
 
 
+SMOOTH_SO = os.path.join(CSRC, "libsxgsmooth.so")
+SMOOTH_DEPS = ["sxg_smooth.cpp", os.path.join("..", "..", "include", "sxg_smooth.h"),
+               os.path.join("..", "..", "include", "sxg_poa.h")]
+
+
+def build_smooth(force=False, verbose=False):
+    """Host-side rows (collection, block graphs, lacing, GFA): plain g++, no HIP."""
+    if not force and os.path.exists(SMOOTH_SO) and \
+            all(os.path.getmtime(os.path.join(CSRC, d)) <= os.path.getmtime(SMOOTH_SO) for d in SMOOTH_DEPS):
+        return SMOOTH_SO
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SMOOTH_SO,
+           os.path.join(CSRC, "sxg_smooth.cpp")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SMOOTH_SO
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    build_smooth(force=True, verbose=True)

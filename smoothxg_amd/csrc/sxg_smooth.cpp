@@ -1,0 +1,613 @@
+// sxg_smooth.cpp -- host side of the smoothing iteration around the blocked-POA engine
+// (C ABI: include/sxg_smooth.h).  Plain C++17, no HIP: the POA is a callback.
+//
+// Follows, row by row:
+//   A2  append_to_sequence            src/smooth.cpp:75-126
+//   A3  collect / orient / dedup      src/smooth.cpp:676-743
+//   A4  padding size                  src/smooth.cpp:1946-1970
+//   A9  build_odgi_SPOA               src/smooth.cpp:2576-2654
+//   A10 unchop, order, re-copy        src/smooth.cpp:935-1010
+//   8f-1 lacing, validation, writer   src/main.cpp:599-1061
+// odgi's unchop / topological_order / to_gfa are absent from the reference snapshot; they are
+// restated by decree and mirrored line for line by oracle/smooth_oracle.py.
+#include "../../include/sxg_smooth.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <queue>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& m) { g_err = m; return code; }
+
+typedef uint64_t handle_t;  // node index << 1 | is_reverse
+inline handle_t mk(uint64_t n, bool rev) { return (n << 1) | (rev ? 1u : 0u); }
+inline uint64_t nid(handle_t h) { return h >> 1; }
+inline bool rev(handle_t h) { return h & 1; }
+inline handle_t flip(handle_t h) { return h ^ 1; }
+
+char comp(char c) {
+    switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C'; default: return 'N'; }
+}
+std::string revcomp(const std::string& s) {
+    std::string r(s.size(), 'N');
+    for (size_t i = 0; i < s.size(); ++i) r[s.size() - 1 - i] = comp(s[i]);
+    return r;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// input graph (what the path needs of XG: src/xg.hpp:271-370)
+struct sxg_graph {
+    std::vector<int64_t> ids;            // sorted node ids; index = rank
+    std::vector<std::string> seq;        // by rank
+    std::vector<std::string> pname;
+    std::vector<std::vector<handle_t>> steps;
+    std::vector<std::vector<uint64_t>> pos;  // bp offset of every step (+ total length at the end)
+    std::string sequence(handle_t h) const { return rev(h) ? revcomp(seq[nid(h)]) : seq[nid(h)]; }
+    std::string path_sequence(size_t p) const {
+        std::string s;
+        for (handle_t h : steps[p]) s += sequence(h);
+        return s;
+    }
+};
+
+struct path_range_t { uint64_t path, begin, end, length; };  // steps [begin,end), length in bp (src/blocks.hpp:29-33)
+struct sxg_blockset { std::vector<std::vector<path_range_t>> blocks; };
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// A2: src/smooth.cpp:75-126.  Quirks kept: the left walk starts AT the range's first step and
+// stops before step 0; every visited node contributes its LAST characters on both sides.
+void append_to_sequence(const sxg_graph& g, uint64_t path, uint64_t starting_step, std::string& seq,
+                        uint64_t& fwd_bp, uint64_t& rev_bp, int poa_padding, bool on_the_left) {
+    uint64_t step = starting_step;
+    const uint64_t final_step = on_the_left ? 0 : g.steps[path].size();
+    uint64_t to_add = (uint64_t)poa_padding;
+    std::string tmp;
+    while (step != final_step && to_add > 0) {
+        const handle_t h = g.steps[path][step];
+        const std::string s = g.sequence(h);
+        const uint64_t l = s.size();
+        uint64_t added;
+        if (l <= to_add) { tmp.append(s); added = l; }
+        else { tmp.append(s.substr(s.size() - to_add)); added = to_add; }
+        if (rev(h)) rev_bp += added; else fwd_bp += added;
+        to_add -= added;
+        step = on_the_left ? step - 1 : step + 1;
+    }
+    if (on_the_left) { seq.append(to_add, 'N'); seq.append(tmp); }
+    else { seq.append(tmp); seq.append(to_add, 'N'); }
+}
+
+// A4: src/smooth.cpp:1946-1970 (float accumulation as in the reference)
+int padding_size(const sxg_graph& g, const std::vector<path_range_t>& ranges, const sxg_smooth_params& p) {
+    int poa_padding = 0;
+    if (p.poa_padding_fraction > 0) {
+        if (ranges.size() <= p.max_block_depth_for_padding_more) poa_padding = 311;
+        float average_seq_len = 0.0f;
+        for (auto& r : ranges)
+            for (uint64_t s = r.begin; s != r.end; ++s) average_seq_len += (float)g.seq[nid(g.steps[r.path][s])].size();
+        average_seq_len /= (float)ranges.size();
+        poa_padding = std::max((int)(average_seq_len * p.poa_padding_fraction), poa_padding);
+    }
+    return poa_padding;
+}
+
+struct collected_t {
+    int poa_padding = 0;
+    std::vector<std::string> seqs;
+    std::vector<uint32_t> weights;
+    std::vector<std::vector<bool>> dup_is_revs;
+    std::vector<std::vector<std::string>> dup_seq_names;
+    std::vector<std::vector<uint64_t>> dup_rank_in_path_ranges;
+    std::vector<std::string> all_names_in_original_order;
+};
+
+uint64_t xxh64(const void* data, uint64_t len, uint64_t seed);
+
+// A3: src/smooth.cpp:676-743
+collected_t collect(const sxg_graph& g, const std::vector<path_range_t>& ranges, const sxg_smooth_params& p) {
+    collected_t c;
+    if (ranges.empty()) return c;
+    c.poa_padding = padding_size(g, ranges, p);
+    std::unordered_map<uint64_t, uint64_t> seq_to_rank;
+    for (uint64_t i = 0; i < ranges.size(); ++i) {
+        const path_range_t& r = ranges[i];
+        std::string seq;
+        uint64_t fwd_bp = 0, rev_bp = 0;
+        append_to_sequence(g, r.path, r.begin, seq, fwd_bp, rev_bp, c.poa_padding, true);
+        for (uint64_t s = r.begin; s != r.end; ++s) {
+            const handle_t h = g.steps[r.path][s];
+            seq.append(g.sequence(h));
+            if (rev(h)) rev_bp += g.seq[nid(h)].size(); else fwd_bp += g.seq[nid(h)].size();
+        }
+        append_to_sequence(g, r.path, r.end, seq, fwd_bp, rev_bp, c.poa_padding, false);
+        const bool is_rev = rev_bp > fwd_bp;
+        if (is_rev) seq = revcomp(seq);
+        const std::string name = g.pname[r.path] + "_" + std::to_string(g.pos[r.path][r.begin]);
+        const uint64_t hash = xxh64(seq.data(), seq.size(), 0);
+        auto it = seq_to_rank.find(hash);
+        if (it == seq_to_rank.end()) {
+            seq_to_rank[hash] = c.seqs.size();
+            c.seqs.push_back(seq);
+            c.weights.push_back(1);
+            c.dup_is_revs.push_back({is_rev});
+            c.dup_seq_names.push_back({name});
+            c.dup_rank_in_path_ranges.push_back({i});
+        } else {
+            const uint64_t rank = it->second;
+            c.weights[rank] += 1;
+            c.dup_is_revs[rank].push_back(is_rev);
+            c.dup_seq_names[rank].push_back(name);
+            c.dup_rank_in_path_ranges[rank].push_back(i);
+        }
+        c.all_names_in_original_order.push_back(name);
+    }
+    size_t mx = 0;
+    for (auto& s : c.seqs) mx = std::max(mx, s.size());
+    if (mx == 0) { collected_t e; e.poa_padding = c.poa_padding; return e; }  // "the graph would be empty"
+    return c;
+}
+
+// XXH64 (published xxHash specification), the dedup key of src/smooth.cpp:716; same restatement as
+// sxg_xxh64 in sxg_poa.hip, repeated here so that this library does not depend on the HIP one.
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+uint64_t xxh64(const void* data, uint64_t len, uint64_t seed) {
+    const uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL,
+                   P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    auto rd64 = [](const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; };
+    auto rd32 = [](const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; };
+    auto round = [&](uint64_t acc, uint64_t in) { return rotl64(acc + in * P2, 31) * P1; };
+    auto merge = [&](uint64_t hh, uint64_t v) { return (hh ^ round(0, v)) * P1 + P4; };
+    const uint8_t *p = (const uint8_t*)data, *end = p + len;
+    uint64_t hh;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        const uint8_t* lim = end - 32;
+        do { v1 = round(v1, rd64(p)); v2 = round(v2, rd64(p + 8)); v3 = round(v3, rd64(p + 16)); v4 = round(v4, rd64(p + 24)); p += 32; } while (p <= lim);
+        hh = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        hh = merge(hh, v1); hh = merge(hh, v2); hh = merge(hh, v3); hh = merge(hh, v4);
+    } else hh = seed + P5;
+    hh += len;
+    while (p + 8 <= end) { hh ^= round(0, rd64(p)); hh = rotl64(hh, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { hh ^= (uint64_t)rd32(p) * P1; hh = rotl64(hh, 23) * P2 + P3; p += 4; }
+    while (p < end) { hh ^= (*p) * P5; hh = rotl64(hh, 11) * P1; ++p; }
+    hh ^= hh >> 33; hh *= P2; hh ^= hh >> 29; hh *= P3; hh ^= hh >> 32;
+    return hh;
+}
+
+inline uint8_t code_of(char ch) {
+    switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// output-side graph (odgi::graph_t's role): nodes, bidirected edges, named paths
+struct ograph_t {
+    std::vector<std::string> seq;                       // node i has id i+1
+    std::set<std::pair<handle_t, handle_t>> edges;      // canonical form
+    std::vector<std::pair<std::string, std::vector<handle_t>>> paths;
+    static std::pair<handle_t, handle_t> canon(handle_t a, handle_t b) {
+        const std::pair<handle_t, handle_t> x(a, b), y(flip(b), flip(a));
+        return y < x ? y : x;
+    }
+    void add_edge(handle_t a, handle_t b) { edges.insert(canon(a, b)); }
+};
+
+// unchop, by decree (odgi::algorithms::unchop is absent): merge u+ -> v+ when the right side of u
+// has the single edge to v+, the left side of v the single edge from u+, u != v, and no path starts
+// or ends inside the link.  Merged nodes are numbered by their chain head, in head order.
+void unchop(ograph_t& G) {
+    const size_t n = G.seq.size();
+    std::vector<std::vector<handle_t>> out(2 * n);
+    for (auto& e : G.edges) { out[e.first].push_back(e.second); out[flip(e.second)].push_back(flip(e.first)); }
+    std::vector<char> start_at(2 * n, 0), end_at(2 * n, 0);
+    for (auto& p : G.paths) {
+        if (p.second.empty()) continue;
+        start_at[p.second.front()] = 1; end_at[flip(p.second.front())] = 1;
+        end_at[p.second.back()] = 1; start_at[flip(p.second.back())] = 1;
+    }
+    std::vector<int64_t> next(n, -1), prev(n, -1);
+    for (size_t u = 0; u < n; ++u) {
+        const handle_t uf = mk(u, false);
+        if (out[uf].size() != 1) continue;
+        const handle_t vf = out[uf][0];
+        if (rev(vf) || nid(vf) == u) continue;
+        const size_t v = nid(vf);
+        if (out[flip(vf)].size() != 1 || out[flip(vf)][0] != flip(uf)) continue;
+        if (end_at[uf] || start_at[vf] || end_at[flip(vf)] || start_at[flip(uf)]) continue;
+        next[u] = (int64_t)v; prev[v] = (int64_t)u;
+    }
+    // break pure cycles at their smallest member
+    {
+        std::vector<char> seen(n, 0);
+        for (size_t u = 0; u < n; ++u) {
+            if (seen[u] || prev[u] < 0) continue;
+            size_t x = u; bool cyc = false;
+            std::vector<size_t> walk;
+            while (true) { seen[x] = 1; walk.push_back(x); if (prev[x] < 0) break; x = (size_t)prev[x]; if (x == u) { cyc = true; break; } if (seen[x]) break; }
+            if (cyc) { size_t m = *std::min_element(walk.begin(), walk.end()); next[(size_t)prev[m]] = -1; prev[m] = -1; }
+        }
+    }
+    std::vector<int64_t> chain_of(n, -1), first_of, last_of;
+    std::vector<std::string> nseq;
+    for (size_t u = 0; u < n; ++u) {
+        if (prev[u] >= 0) continue;
+        const int64_t c = (int64_t)nseq.size();
+        std::string s;
+        size_t x = u, last = u;
+        while (true) { chain_of[x] = c; s += G.seq[x]; last = x; if (next[x] < 0) break; x = (size_t)next[x]; }
+        nseq.push_back(s); first_of.push_back((int64_t)u); last_of.push_back((int64_t)last);
+    }
+    auto map_handle = [&](handle_t h) { return mk((uint64_t)chain_of[nid(h)], rev(h)); };
+    std::set<std::pair<handle_t, handle_t>> nedges;
+    for (auto& e : G.edges) {
+        const size_t a = nid(e.first), b = nid(e.second);
+        if (!rev(e.first) && !rev(e.second) && next[a] == (int64_t)b) continue;  // interior of a chain
+        nedges.insert(ograph_t::canon(map_handle(e.first), map_handle(e.second)));
+    }
+    for (auto& p : G.paths) {
+        std::vector<handle_t> ns;
+        for (handle_t h : p.second) {
+            const size_t x = nid(h);
+            const int64_t c = chain_of[x];
+            if (!rev(h)) { if (first_of[c] == (int64_t)x) ns.push_back(mk((uint64_t)c, false)); }
+            else { if (last_of[c] == (int64_t)x) ns.push_back(mk((uint64_t)c, true)); }
+        }
+        p.second.swap(ns);
+    }
+    G.seq.swap(nseq);
+    G.edges.swap(nedges);
+}
+
+// topological order, by decree (odgi::algorithms::topological_order is absent): Kahn over the
+// forward-to-forward edges, smallest node first; leftovers (cycles) in id order.  Renumbers.
+void topo_renumber(ograph_t& G) {
+    const size_t n = G.seq.size();
+    std::vector<std::vector<size_t>> succ(n);
+    std::vector<int> indeg(n, 0);
+    for (auto& e : G.edges)
+        if (!rev(e.first) && !rev(e.second) && nid(e.first) != nid(e.second)) { succ[nid(e.first)].push_back(nid(e.second)); indeg[nid(e.second)]++; }
+    std::priority_queue<size_t, std::vector<size_t>, std::greater<size_t>> q;
+    for (size_t u = 0; u < n; ++u) if (!indeg[u]) q.push(u);
+    std::vector<int64_t> newid(n, -1);
+    size_t k = 0;
+    while (!q.empty()) {
+        const size_t u = q.top(); q.pop();
+        newid[u] = (int64_t)k++;
+        for (size_t v : succ[u]) if (--indeg[v] == 0) q.push(v);
+    }
+    for (size_t u = 0; u < n; ++u) if (newid[u] < 0) newid[u] = (int64_t)k++;
+    std::vector<std::string> nseq(n);
+    for (size_t u = 0; u < n; ++u) nseq[(size_t)newid[u]] = G.seq[u];
+    std::set<std::pair<handle_t, handle_t>> ne;
+    for (auto& e : G.edges) ne.insert(ograph_t::canon(mk((uint64_t)newid[nid(e.first)], rev(e.first)), mk((uint64_t)newid[nid(e.second)], rev(e.second))));
+    for (auto& p : G.paths) for (auto& h : p.second) h = mk((uint64_t)newid[nid(h)], rev(h));
+    G.seq.swap(nseq); G.edges.swap(ne);
+}
+
+// GFA1 text in the convention the in-tree XG::to_gfa shows (src/xg.cpp:1532-1580) minus its tags;
+// S by id, L sorted by (from, to), P in path order.  odgi::to_gfa is absent: byte parity unpinned.
+std::string to_gfa(const ograph_t& G) {
+    std::string o = "H\tVN:Z:1.0\n";
+    for (size_t i = 0; i < G.seq.size(); ++i) { o += "S\t" + std::to_string(i + 1) + "\t" + G.seq[i] + "\n"; }
+    for (auto& e : G.edges) {
+        o += "L\t" + std::to_string(nid(e.first) + 1) + "\t" + (rev(e.first) ? "-" : "+") + "\t" + std::to_string(nid(e.second) + 1) + "\t" +
+             (rev(e.second) ? "-" : "+") + "\t0M\n";
+    }
+    for (auto& p : G.paths) {
+        o += "P\t" + p.first + "\t";
+        for (size_t k = 0; k < p.second.size(); ++k) {
+            if (k) o += ",";
+            o += std::to_string(nid(p.second[k]) + 1) + (rev(p.second[k]) ? "-" : "+");
+        }
+        o += "\t*\n";
+    }
+    return o;
+}
+
+// A9 + A10 for one block.  poa_* describe the block's POA graph (include/sxg_poa.h, block-local).
+ograph_t build_block_graph(const collected_t& c, const uint8_t* node_code, int64_t n_nodes,
+                           const std::vector<const int32_t*>& seq_paths, const int32_t* cons, int64_t n_cons,
+                           const std::string& consensus_name) {
+    static const char dec[5] = {'A', 'C', 'G', 'T', 'N'};
+    ograph_t G;
+    // A9 (src/smooth.cpp:2583-2637): one node per POA node; a path per duplicate name, padding steps
+    // trimmed at both ends, reversed and flipped when the range was collected in reverse
+    std::vector<std::pair<std::string, std::vector<handle_t>>> by_name;
+    for (size_t i = 0; i < c.seqs.size(); ++i) {
+        const int64_t len = (int64_t)c.seqs[i].size();
+        for (size_t j = 0; j < c.dup_seq_names[i].size(); ++j) {
+            std::vector<handle_t> st;
+            for (int64_t k = c.poa_padding; k < len - c.poa_padding; ++k) st.push_back(mk((uint64_t)seq_paths[i][k], false));
+            if (c.dup_is_revs[i][j]) { std::reverse(st.begin(), st.end()); for (auto& h : st) h = flip(h); }
+            by_name.emplace_back(c.dup_seq_names[i][j], st);
+        }
+    }
+    if (!consensus_name.empty()) {
+        std::vector<handle_t> st;
+        for (int64_t k = 0; k < n_cons; ++k) st.push_back(mk((uint64_t)cons[k], false));
+        by_name.emplace_back(consensus_name, st);
+    }
+    // :2639-2653 drop nodes no path visits; A10 :980-994 keeps only path-supported edges, so the
+    // edge set IS the set of consecutive step pairs
+    std::vector<int64_t> keep(n_nodes, -1);
+    for (auto& p : by_name) for (handle_t h : p.second) keep[nid(h)] = 0;
+    for (int64_t v = 0, k = 0; v < n_nodes; ++v) if (keep[v] == 0) { keep[v] = k++; G.seq.push_back(std::string(1, dec[node_code[v] > 4 ? 4 : node_code[v]])); }
+    for (auto& p : by_name) {
+        for (auto& h : p.second) h = mk((uint64_t)keep[nid(h)], rev(h));
+        for (size_t k = 1; k < p.second.size(); ++k) G.add_edge(p.second[k - 1], p.second[k]);
+    }
+    // A10 :996-1010 paths in the order of the input block, consensus last
+    std::map<std::string, size_t> idx;
+    for (size_t k = 0; k < by_name.size(); ++k) idx[by_name[k].first] = k;
+    for (auto& nm : c.all_names_in_original_order) G.paths.push_back(by_name[idx[nm]]);
+    if (!consensus_name.empty()) G.paths.push_back(by_name.back());
+    unchop(G);          // :935
+    topo_renumber(G);   // :947
+    return G;
+}
+
+struct batch_t {
+    std::vector<int32_t> blk_off{0};
+    std::vector<int64_t> seq_off{0};
+    std::vector<uint8_t> bases;
+    std::vector<uint32_t> weights;
+};
+void add_to_batch(batch_t& B, const collected_t& c) {
+    for (size_t i = 0; i < c.seqs.size(); ++i) {
+        for (char ch : c.seqs[i]) B.bases.push_back(code_of(ch));
+        B.seq_off.push_back((int64_t)B.bases.size());
+        B.weights.push_back(c.weights[i]);
+    }
+    B.blk_off.push_back((int32_t)(B.seq_off.size() - 1));
+}
+sxg_poa_params poa_params(const sxg_smooth_params& p) {  // src/smooth.cpp:2098-2106
+    sxg_poa_params q;
+    q.m = (int8_t)p.poa_m; q.n = (int8_t)-p.poa_n; q.g = (int8_t)-p.poa_g; q.e = (int8_t)-p.poa_e; q.q = (int8_t)-p.poa_q; q.c = (int8_t)-p.poa_c;
+    q.mode = p.local_alignment ? SXG_MODE_LOCAL : SXG_MODE_GLOBAL; q.reserved = 0;
+    return q;
+}
+std::string cons_name(const sxg_smooth_params& p, int64_t block_id) {
+    if (!p.add_consensus) return "";
+    return std::string(p.consensus_base_name ? p.consensus_base_name : "Consensus_") + std::to_string(block_id);
+}
+ograph_t block_graph_from_out(const collected_t& c, const batch_t& B, const sxg_poa_batch_out& out, int64_t slot, const std::string& cname) {
+    std::vector<const int32_t*> sp;
+    for (int32_t s = B.blk_off[slot]; s < B.blk_off[slot + 1]; ++s) sp.push_back(out.seq_path_nodes + B.seq_off[s]);
+    const int64_t n0 = out.node_off[slot], nn = out.node_off[slot + 1] - n0;
+    const int32_t* cons = out.cons_nodes && out.cons_off ? out.cons_nodes + out.cons_off[slot] : nullptr;
+    const int64_t nc = out.cons_nodes && out.cons_off ? out.cons_off[slot + 1] - out.cons_off[slot] : 0;
+    return build_block_graph(c, out.node_code + n0, nn, sp, cons, nc, cname);
+}
+char* dup_out(const std::string& s) {
+    char* r = (char*)malloc(s.size() + 1);
+    if (r) memcpy(r, s.c_str(), s.size() + 1);
+    return r;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+void sxg_smooth_default_params(sxg_smooth_params* p) {
+    if (!p) return;
+    p->poa_m = 1; p->poa_n = 4; p->poa_g = 6; p->poa_e = 2; p->poa_q = 26; p->poa_c = 1;  // src/main.cpp:322-327
+    p->local_alignment = 1;                                                              // src/main.cpp:487
+    p->poa_padding_fraction = 0.001f; p->max_block_depth_for_padding_more = 1000;         // src/main.cpp:293-295
+    p->add_consensus = 0; p->consensus_base_name = "Consensus_";
+}
+const char* sxg_smooth_last_error(void) { return g_err.c_str(); }
+void sxg_smooth_free(void* p) { free(p); }
+
+int sxg_graph_from_gfa(const char* text, size_t len, sxg_graph** out) {
+    if (!text || !out) return fail(SXG_E_INVALID, "NULL argument");
+    *out = nullptr;
+    std::vector<std::pair<int64_t, std::string>> nodes;
+    std::vector<std::pair<std::string, std::string>> plines;
+    size_t i = 0;
+    while (i < len) {
+        size_t j = i;
+        while (j < len && text[j] != '\n') ++j;
+        if (j > i) {
+            std::vector<std::string> f;
+            size_t a = i;
+            for (size_t k = i; k <= j; ++k)
+                if (k == j || text[k] == '\t') { f.emplace_back(text + a, k - a); a = k + 1; }
+            if (!f.empty() && !f.back().empty() && f.back().back() == '\r') f.back().pop_back();
+            if (f[0] == "S" && f.size() >= 3) {
+                std::string s = f[2];
+                for (auto& ch : s) { ch = (char)toupper(ch); if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ch = 'N'; }
+                nodes.emplace_back(atoll(f[1].c_str()), s);
+            } else if (f[0] == "P" && f.size() >= 3) plines.emplace_back(f[1], f[2]);
+        }
+        i = j + 1;
+    }
+    std::sort(nodes.begin(), nodes.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    sxg_graph* g = new sxg_graph();
+    std::unordered_map<int64_t, uint64_t> rank;
+    for (auto& nd : nodes) {
+        if (rank.count(nd.first)) { delete g; return fail(SXG_E_INVALID, "duplicate node id " + std::to_string(nd.first)); }
+        rank[nd.first] = g->ids.size(); g->ids.push_back(nd.first); g->seq.push_back(nd.second);
+    }
+    for (auto& pl : plines) {
+        g->pname.push_back(pl.first);
+        g->steps.emplace_back(); g->pos.emplace_back();
+        uint64_t bp = 0;
+        const std::string& s = pl.second;
+        size_t a = 0;
+        for (size_t k = 0; k <= s.size(); ++k)
+            if (k == s.size() || s[k] == ',') {
+                if (k > a) {
+                    const char o = s[k - 1];
+                    const int64_t id = atoll(s.substr(a, k - a - 1).c_str());
+                    auto it = rank.find(id);
+                    if ((o != '+' && o != '-') || it == rank.end()) { delete g; return fail(SXG_E_INVALID, "bad step in path " + pl.first); }
+                    g->steps.back().push_back(mk(it->second, o == '-'));
+                    g->pos.back().push_back(bp);
+                    bp += g->seq[it->second].size();
+                }
+                a = k + 1;
+            }
+        g->pos.back().push_back(bp);
+    }
+    *out = g;
+    return SXG_OK;
+}
+void sxg_graph_free(sxg_graph* g) { delete g; }
+int64_t sxg_graph_node_count(const sxg_graph* g) { return g ? (int64_t)g->seq.size() : 0; }
+int64_t sxg_graph_path_count(const sxg_graph* g) { return g ? (int64_t)g->pname.size() : 0; }
+
+int sxg_blockset_by_path_windows(const sxg_graph* g, uint64_t target_bp, sxg_blockset** out) {
+    if (!g || !out || target_bp == 0) return fail(SXG_E_INVALID, "bad argument");
+    sxg_blockset* b = new sxg_blockset();
+    for (size_t p = 0; p < g->steps.size(); ++p) {
+        const auto& st = g->steps[p];
+        size_t s = 0, k = 0;
+        while (s < st.size()) {
+            size_t e = s;
+            uint64_t bp = 0;
+            while (e < st.size() && bp < target_bp) { bp += g->seq[nid(st[e])].size(); ++e; }
+            if (b->blocks.size() <= k) b->blocks.resize(k + 1);
+            b->blocks[k].push_back(path_range_t{p, s, e, bp});
+            s = e; ++k;
+        }
+    }
+    for (auto& blk : b->blocks)  // longest first, as src/blocks.cpp:206-219
+        std::stable_sort(blk.begin(), blk.end(), [](const path_range_t& a, const path_range_t& c) { return a.length > c.length; });
+    *out = b;
+    return SXG_OK;
+}
+void sxg_blockset_free(sxg_blockset* b) { delete b; }
+int64_t sxg_blockset_size(const sxg_blockset* b) { return b ? (int64_t)b->blocks.size() : 0; }
+
+int sxg_block_collect_text(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, const sxg_smooth_params* p, char** out_text) {
+    if (!g || !b || !p || !out_text || block_id < 0 || block_id >= (int64_t)b->blocks.size()) return fail(SXG_E_INVALID, "bad argument");
+    const collected_t c = collect(*g, b->blocks[block_id], *p);
+    std::string o = "padding\t" + std::to_string(c.poa_padding) + "\n";
+    for (size_t i = 0; i < c.seqs.size(); ++i) o += "seq\t" + std::to_string(i) + "\t" + std::to_string(c.weights[i]) + "\t" + c.seqs[i] + "\n";
+    for (size_t i = 0; i < c.seqs.size(); ++i)
+        for (size_t j = 0; j < c.dup_seq_names[i].size(); ++j)
+            o += "dup\t" + std::to_string(i) + "\t" + std::to_string(c.dup_rank_in_path_ranges[i][j]) + "\t" + (c.dup_is_revs[i][j] ? "1" : "0") + "\t" +
+                 c.dup_seq_names[i][j] + "\n";
+    *out_text = dup_out(o);
+    return SXG_OK;
+}
+
+int sxg_block_graph_gfa(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, const sxg_smooth_params* p, sxg_poa_run_fn run,
+                        sxg_poa_free_fn fre, void* ctx, char** out_gfa) {
+    if (!g || !b || !p || !run || !out_gfa || block_id < 0 || block_id >= (int64_t)b->blocks.size()) return fail(SXG_E_INVALID, "bad argument");
+    const collected_t c = collect(*g, b->blocks[block_id], *p);
+    batch_t B;
+    add_to_batch(B, c);
+    const sxg_poa_params pp = poa_params(*p);
+    sxg_poa_batch_in in;
+    memset(&in, 0, sizeof(in));
+    in.n_blocks = 1; in.blk_off = B.blk_off.data(); in.seq_off = B.seq_off.data(); in.bases = B.bases.data();
+    in.weights = B.weights.data(); in.params = &pp; in.want_consensus = p->add_consensus;
+    sxg_poa_batch_out out;
+    memset(&out, 0, sizeof(out));
+    const int rc = run(ctx, &in, &out);
+    if (rc != SXG_OK) return fail(rc, "POA provider failed");
+    const ograph_t G = block_graph_from_out(c, B, out, 0, cons_name(*p, block_id));
+    if (fre) fre(&out);
+    *out_gfa = dup_out(to_gfa(G));
+    return SXG_OK;
+}
+
+int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, sxg_poa_run_fn run, sxg_poa_free_fn fre, void* ctx,
+                   char** out_gfa) {
+    if (!g || !b || !p || !run || !out_gfa) return fail(SXG_E_INVALID, "NULL argument");
+    const int64_t nb = (int64_t)b->blocks.size();
+    // phase 1: A2-A4 for every block (the reference's OpenMP loop up to src/smooth.cpp:743)
+    std::vector<collected_t> col(nb);
+    batch_t B;
+    for (int64_t k = 0; k < nb; ++k) { col[k] = collect(*g, b->blocks[k], *p); add_to_batch(B, col[k]); }
+    // phase 2: ONE batched POA call (replaces src/smooth.cpp:752-786 of every block)
+    const sxg_poa_params pp = poa_params(*p);
+    sxg_poa_batch_in in;
+    memset(&in, 0, sizeof(in));
+    uint8_t dummy = 0;
+    in.n_blocks = (int32_t)nb; in.blk_off = B.blk_off.data(); in.seq_off = B.seq_off.data();
+    in.bases = B.bases.empty() ? &dummy : B.bases.data(); in.weights = B.weights.data(); in.params = &pp;
+    in.want_consensus = p->add_consensus;
+    sxg_poa_batch_out out;
+    memset(&out, 0, sizeof(out));
+    const int rc = run(ctx, &in, &out);
+    if (rc != SXG_OK) return fail(rc, "POA provider failed");
+    // phase 3: A9/A10 per block, path_mapping rows (src/smooth.cpp:2277-2296)
+    struct frag_t { uint64_t path, start, end; int64_t target, block; };
+    std::vector<ograph_t> graphs(nb);
+    std::vector<frag_t> mapping;
+    for (int64_t k = 0; k < nb; ++k) {
+        if (col[k].seqs.empty()) continue;
+        graphs[k] = block_graph_from_out(col[k], B, out, k, cons_name(*p, k));
+        if (graphs[k].seq.empty()) continue;
+        int64_t path_id = 0;
+        for (auto& r : b->blocks[k]) mapping.push_back(frag_t{r.path, g->pos[r.path][r.begin], g->pos[r.path][r.end], path_id++, k});
+    }
+    if (fre) fre(&out);
+    // lacing (src/main.cpp:599-764): fragments by (path, start); blocks concatenated with an id offset
+    std::stable_sort(mapping.begin(), mapping.end(), [](const frag_t& a, const frag_t& c) { return a.path < c.path || (a.path == c.path && a.start < c.start); });
+    ograph_t S;
+    std::vector<uint64_t> id_trans(nb, 0);
+    for (int64_t k = 0; k < nb; ++k) {
+        id_trans[k] = S.seq.size();
+        for (auto& s : graphs[k].seq) S.seq.push_back(s);
+        for (auto& e : graphs[k].edges) S.add_edge(mk(nid(e.first) + id_trans[k], rev(e.first)), mk(nid(e.second) + id_trans[k], rev(e.second)));
+    }
+    for (size_t a = 0; a < mapping.size();) {
+        size_t z = a;
+        while (z < mapping.size() && mapping[z].path == mapping[a].path) ++z;
+        std::vector<handle_t> steps;
+        uint64_t last_end = 0;
+        for (size_t f = a; f < z; ++f) {
+            if (mapping[f].start != last_end) return fail(SXG_E_INVALID, "path " + g->pname[mapping[a].path] + " is not covered by the blocks");
+            const auto& bp = graphs[mapping[f].block].paths[(size_t)mapping[f].target].second;
+            for (handle_t h : bp) steps.push_back(mk(nid(h) + id_trans[mapping[f].block], rev(h)));
+            last_end = mapping[f].end;
+        }
+        if (last_end != g->pos[mapping[a].path].back()) return fail(SXG_E_INVALID, "path " + g->pname[mapping[a].path] + " is not covered to its end");
+        S.paths.emplace_back(g->pname[mapping[a].path], steps);
+        a = z;
+    }
+    // validation (src/main.cpp:770-810)
+    {
+        size_t nonempty = 0;
+        for (auto& st : g->steps) if (!st.empty()) ++nonempty;
+        if (S.paths.size() != nonempty) return fail(SXG_E_INVALID, "path count mismatch between input and smoothed graph");
+        std::unordered_map<std::string, size_t> byname;
+        for (size_t q = 0; q < g->pname.size(); ++q) byname[g->pname[q]] = q;
+        for (auto& sp : S.paths) {
+            std::string s;
+            for (handle_t h : sp.second) s += rev(h) ? revcomp(S.seq[nid(h)]) : S.seq[nid(h)];
+            if (s != g->path_sequence(byname[sp.first])) return fail(SXG_E_INVALID, "path " + sp.first + " was corrupted in the smoothed graph");
+        }
+    }
+    // consensus paths (src/main.cpp:812-870, no merged consensus: -M is out of scope)
+    if (p->add_consensus)
+        for (int64_t k = 0; k < nb; ++k) {
+            if (graphs[k].seq.empty()) continue;
+            std::vector<handle_t> steps;
+            for (handle_t h : graphs[k].paths.back().second) steps.push_back(mk(nid(h) + id_trans[k], rev(h)));
+            S.paths.emplace_back(graphs[k].paths.back().first, steps);
+        }
+    // walk every path and make sure its edges exist (src/main.cpp:1002-1016), then unchop (:1021)
+    for (auto& sp : S.paths) for (size_t k = 1; k < sp.second.size(); ++k) S.add_edge(sp.second[k - 1], sp.second[k]);
+    unchop(S);
+    *out_gfa = dup_out(to_gfa(S));
+    return SXG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""ctypes binding of include/sxg_smooth.h (libsxgsmooth.so): the host-side rows around the POA --
+sequence collection / padding / dedup (A2-A4), block-graph normalisation (A9, A10), lacing and GFA
+I/O.  The POA provider is a C function pointer: `gpu_provider(engine)` hands the
+library `sxg_poa_batch_run` of libsxgpoa.so and the engine handle, so a smoothing iteration runs
+collect -> one batched GPU call -> lace without Python in the loop."""
+import ctypes as C
+import os
+
+from . import build as _build
+from . import poa as _poa
+
+_lib = None
+
+RUN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(_poa.BatchIn), C.POINTER(_poa.BatchOut))
+FREE_FN = C.CFUNCTYPE(None, C.POINTER(_poa.BatchOut))
+
+
+class SmoothParams(C.Structure):
+    _fields_ = [("poa_m", C.c_int32), ("poa_n", C.c_int32), ("poa_g", C.c_int32), ("poa_e", C.c_int32),
+                ("poa_q", C.c_int32), ("poa_c", C.c_int32), ("local_alignment", C.c_int32),
+                ("poa_padding_fraction", C.c_float), ("max_block_depth_for_padding_more", C.c_uint64),
+                ("add_consensus", C.c_int32), ("consensus_base_name", C.c_char_p)]
+
+
+EXPORTS = ["sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_free", "sxg_graph_from_gfa",
+           "sxg_graph_free", "sxg_graph_node_count", "sxg_graph_path_count", "sxg_blockset_by_path_windows",
+           "sxg_blockset_free", "sxg_blockset_size", "sxg_block_collect_text", "sxg_block_graph_gfa",
+           "sxg_smooth_gfa"]
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = _build.SMOOTH_SO
+    if not os.path.exists(so):
+        _build.build_smooth()
+    L = C.CDLL(so)
+    vp = C.c_void_p
+    L.sxg_smooth_last_error.restype = C.c_char_p
+    L.sxg_smooth_free.argtypes = [vp]
+    L.sxg_smooth_default_params.argtypes = [C.POINTER(SmoothParams)]
+    L.sxg_graph_from_gfa.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    L.sxg_graph_free.argtypes = [vp]
+    L.sxg_graph_node_count.restype = C.c_int64
+    L.sxg_graph_node_count.argtypes = [vp]
+    L.sxg_graph_path_count.restype = C.c_int64
+    L.sxg_graph_path_count.argtypes = [vp]
+    L.sxg_blockset_by_path_windows.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.sxg_blockset_free.argtypes = [vp]
+    L.sxg_blockset_size.restype = C.c_int64
+    L.sxg_blockset_size.argtypes = [vp]
+    L.sxg_block_collect_text.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), C.POINTER(vp)]
+    L.sxg_block_graph_gfa.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
+    L.sxg_smooth_gfa.argtypes = [vp, vp, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
+    _lib = L
+    return L
+
+
+class SmoothError(RuntimeError):
+    pass
+
+
+def default_params(**kw):
+    p = SmoothParams()
+    load_library().sxg_smooth_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def gpu_provider(engine):
+    """(run, free, ctx) backed by the GPU engine: raw C entry points of libsxgpoa.so."""
+    L = engine.lib
+    run = C.cast(L.sxg_poa_batch_run, C.c_void_p)
+    fre = C.cast(L.sxg_poa_batch_free, C.c_void_p)
+    return run, fre, engine.h
+
+
+class Smoother:
+    """An input GFA + a blockset; collect / block graph / full iteration through the C ABI."""
+
+    def __init__(self, gfa_text, target_bp):
+        self.L = load_library()
+        data = gfa_text.encode() if isinstance(gfa_text, str) else gfa_text
+        g = C.c_void_p()
+        if self.L.sxg_graph_from_gfa(data, len(data), C.byref(g)):
+            raise SmoothError(self.L.sxg_smooth_last_error().decode())
+        self.g = g
+        b = C.c_void_p()
+        if self.L.sxg_blockset_by_path_windows(g, target_bp, C.byref(b)):
+            raise SmoothError(self.L.sxg_smooth_last_error().decode())
+        self.b = b
+
+    def close(self):
+        if getattr(self, "b", None):
+            self.L.sxg_blockset_free(self.b)
+            self.b = None
+        if getattr(self, "g", None):
+            self.L.sxg_graph_free(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_blocks(self):
+        return self.L.sxg_blockset_size(self.b)
+
+    def _text(self, rc, out):
+        if rc:
+            raise SmoothError(self.L.sxg_smooth_last_error().decode())
+        try:
+            return C.string_at(out).decode()
+        finally:
+            self.L.sxg_smooth_free(out)
+
+    def collect_text(self, block_id, params):
+        out = C.c_void_p()
+        return self._text(self.L.sxg_block_collect_text(self.g, self.b, block_id, C.byref(params), C.byref(out)), out)
+
+    def block_graph_gfa(self, block_id, params, provider):
+        run, fre, ctx = provider
+        out = C.c_void_p()
+        return self._text(self.L.sxg_block_graph_gfa(self.g, self.b, block_id, C.byref(params), run, fre, ctx, C.byref(out)), out)
+
+    def smooth_gfa(self, params, provider):
+        run, fre, ctx = provider
+        out = C.c_void_p()
+        return self._text(self.L.sxg_smooth_gfa(self.g, self.b, C.byref(params), run, fre, ctx, C.byref(out)), out)

@@ -1,0 +1,186 @@
+"""CPU: host-side rows (A2-A4 collection, A9/A10 block graphs, lacing + GFA I/O) of
+smoothxg_amd/csrc/sxg_smooth.cpp against the pure-Python oracle (oracle/smooth_oracle.py), with the
+POA supplied by the C oracle through a callback (no GPU involved)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+from oracle import smooth_oracle as SO
+from smoothxg_amd import poa as P
+from smoothxg_amd import smooth as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DRB1 = os.path.join(HERE, "golden", "DRB1-3123.seqwish.gfa")  # the reference's own test input (test/data/)
+
+
+class OracleProvider:
+    """sxg_poa_batch_run-shaped callback backed by oracle/poa_oracle.c (test infrastructure)."""
+
+    def __init__(self):
+        self.keep = []
+        self.run = S.RUN_FN(self._run)
+        self.free = S.FREE_FN(self._free)
+
+    def provider(self):
+        return C.cast(self.run, C.c_void_p), C.cast(self.free, C.c_void_p), None
+
+    def _run(self, ctx, pin, pout):
+        i, o = pin.contents, pout.contents
+        nb = i.n_blocks
+        blk = np.ctypeslib.as_array(i.blk_off, (nb + 1,)).copy()
+        ns = int(blk[-1])
+        so = np.ctypeslib.as_array(i.seq_off, (ns + 1,)).copy() if ns else np.zeros(1, np.int64)
+        bases = np.ctypeslib.as_array(i.bases, (max(int(so[-1]), 1),)).copy()
+        w = np.ctypeslib.as_array(i.weights, (max(ns, 1),)).copy() if i.weights else np.ones(max(ns, 1), np.uint32)
+        pr = i.params[0]
+        par = O.mkparams(pr.m, pr.n, pr.g, pr.e, pr.q, pr.c, pr.mode)
+        node_off, cons_off, codes, paths, cons = [0], [0], [], [], []
+        for b in range(nb):
+            seqs = [bases[so[s]:so[s + 1]] for s in range(blk[b], blk[b + 1])]
+            if seqs:
+                g, _, _ = O.block_run(seqs, w[blk[b]:blk[b + 1]], par)
+                codes.append(g.nodes()[0])
+                paths += [g.seq_path(k) for k in range(len(seqs))]
+                cons.append(g.consensus())
+            node_off.append(node_off[-1] + (len(codes[-1]) if seqs else 0))
+            cons_off.append(cons_off[-1] + (len(cons[-1]) if seqs else 0))
+        cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs) if xs else np.zeros(1, dt), dt)
+        arrs = dict(node_off=np.asarray(node_off, np.int64), cons_off=np.asarray(cons_off, np.int64),
+                    node_code=cat(codes, np.uint8), paths=cat(paths, np.int32), cons=cat(cons, np.int32),
+                    status=np.zeros(max(nb, 1), np.int32))
+        self.keep.append(arrs)
+        o.n_blocks, o.n_seqs = nb, ns
+        o.status = arrs["status"].ctypes.data_as(C.POINTER(C.c_int32))
+        o.node_off = arrs["node_off"].ctypes.data_as(C.POINTER(C.c_int64))
+        o.node_code = arrs["node_code"].ctypes.data_as(C.POINTER(C.c_uint8))
+        o.seq_path_nodes = arrs["paths"].ctypes.data_as(C.POINTER(C.c_int32))
+        o.cons_off = arrs["cons_off"].ctypes.data_as(C.POINTER(C.c_int64))
+        o.cons_nodes = arrs["cons"].ctypes.data_as(C.POINTER(C.c_int32))
+        return 0
+
+    def _free(self, pout):
+        pass
+
+
+def synthetic_gfa(seed, n_paths=5, n_nodes=60, with_reverse=True):
+    """A small variation graph: a backbone of nodes, paths that skip / substitute / reverse."""
+    rng = np.random.default_rng(seed)
+    lines, seqs = ["H\tVN:Z:1.0"], []
+    for i in range(n_nodes):
+        s = "".join("ACGT"[k] for k in rng.integers(0, 4, int(rng.integers(1, 30))))
+        if i % 17 == 5:
+            s = s[:1] + "N" + s[1:]
+        seqs.append(s)
+        lines.append("S\t%d\t%s" % (i + 1, s))
+    for p in range(n_paths):
+        steps = []
+        for i in range(n_nodes):
+            r = rng.random()
+            if r < 0.1:
+                continue
+            steps.append("%d%s" % (i + 1, "-" if (with_reverse and r > 0.93) else "+"))
+        if with_reverse and p == n_paths - 1:   # one path walks the graph mostly in reverse
+            steps = [s[:-1] + ("-" if s[-1] == "+" else "+") for s in reversed(steps)]
+        lines.append("P\tpath%d\t%s\t*" % (p, ",".join(steps)))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.fixture(scope="module")
+def prov():
+    return OracleProvider()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("target", [40, 150, 100000])
+def test_collect_matches_reference_restatement(seed, target):
+    text = synthetic_gfa(seed)
+    sm = S.Smoother(text, target)
+    g = SO.Graph(text)
+    blocks = SO.blockset_by_path_windows(g, target)
+    assert sm.n_blocks == len(blocks)
+    for frac in (0.001, 0.0, 0.5):
+        p = S.default_params(poa_padding_fraction=frac)
+        for k in range(len(blocks)):
+            assert sm.collect_text(k, p) == SO.collect_text(SO.collect(g, blocks[k], frac, 1000)), (seed, target, frac, k)
+
+
+def test_padding_quirks_of_append_to_sequence():
+    """src/smooth.cpp:75-126: a range starting at step 0 gets all-N on the left; the left walk takes
+    the LAST characters of the range's own first node; N-fill at path ends."""
+    text = "S\t1\tAAAA\nS\t2\tCCCCCC\nS\t3\tGG\nP\tp\t1+,2+,3+\t*\n"
+    g = SO.Graph(text)
+    left, f, r = SO.append_to_sequence(g, 0, 0, 5, True)
+    assert left == "NNNNN"
+    left, f, r = SO.append_to_sequence(g, 0, 1, 5, True)   # walks step 1 (CCCCCC) itself, then stops before step 0
+    assert left == "CCCCC" and f == 5
+    right, f, r = SO.append_to_sequence(g, 0, 2, 5, False)
+    assert right == "GGNNN"
+    sm = S.Smoother(text, 1000)
+    assert "seq\t0\t1\t" in sm.collect_text(0, S.default_params())
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+@pytest.mark.parametrize("cons", [0, 1])
+def test_block_graph_and_full_iteration_match_oracle(prov, seed, cons):
+    text = synthetic_gfa(seed, n_paths=6, n_nodes=80)
+    g = SO.Graph(text)
+    for target in (120, 500):
+        sm = S.Smoother(text, target)
+        blocks = SO.blockset_by_path_windows(g, target)
+        p = S.default_params(add_consensus=cons, poa_padding_fraction=0.001)
+        for k in range(min(len(blocks), 4)):
+            c = SO.collect(g, blocks[k])
+            if not c.seqs:
+                continue
+            code, paths, cn = SO.poa(c)
+            want = SO.to_gfa(SO.build_block_graph(c, code, paths, cn, ("Consensus_%d" % k) if cons else ""))
+            assert sm.block_graph_gfa(k, p, prov.provider()) == want
+        want = SO.smooth(g, blocks, add_consensus=bool(cons))
+        got = sm.smooth_gfa(p, prov.provider())
+        assert got == want
+        # the smoothed graph still spells every input path (src/main.cpp:770-810)
+        out = SO.Graph(got)
+        for q, nm in enumerate(g.pname):
+            assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+def test_drb1_fixture_round_trip(prov):
+    """The reference's own test input (CMakeLists.txt:562-567 runs the CLI on it and checks the exit
+    code): one smoothing iteration must preserve all 12 paths and agree with the oracle."""
+    text = open(DRB1).read()
+    g = SO.Graph(text)
+    assert len(g.pname) == 12 and len(g.seq) == 3585
+    sm = S.Smoother(text, 700)
+    blocks = SO.blockset_by_path_windows(g, 700)
+    got = sm.smooth_gfa(S.default_params(), prov.provider())
+    assert got == SO.smooth(g, blocks)
+    out = SO.Graph(got)
+    assert sorted(out.pname) == sorted(g.pname)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+def test_unchop_and_order_decrees():
+    G = SO.OGraph()
+    G.seq = ["A", "C", "G", "T", "A"]
+    for a, b in [(0, 1), (1, 2), (1, 3), (2, 4), (3, 4)]:
+        G.add_edge(a << 1, b << 1)
+    G.paths = [("x", [0, 2, 4, 8]), ("y", [0, 2, 6, 8])]
+    SO.unchop(G)
+    assert G.seq == ["AC", "G", "T", "A"]
+    SO.topo_renumber(G)
+    assert SO.to_gfa(G).count("\nL\t") == 4
+
+
+def test_host_library_exports_every_declared_symbol():
+    import re
+    src = open(os.path.join(os.path.dirname(HERE), "include", "sxg_smooth.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(sxg_[a-z0-9_]+)\s*\(", src)) - {"sxg_poa_run_fn", "sxg_poa_free_fn"})
+    L = S.load_library()
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(S.EXPORTS) == names
