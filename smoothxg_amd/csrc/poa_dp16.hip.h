@@ -39,6 +39,7 @@ __device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(
 __device__ __forceinline__ int pk_minu(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
 __device__ __forceinline__ int pk_mad(int a, int b, int c) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) * __builtin_bit_cast(s16x2, b) + __builtin_bit_cast(s16x2, c))); }
 __device__ __forceinline__ int pk2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+__device__ __forceinline__ int pk2s(int x) { return (x & 0xffff) | (x << 16); }  // both halves = x
 __device__ __forceinline__ int pk_lo(int v) { return (int)(short)(v & 0xffff); }
 __device__ __forceinline__ int pk_hi(int v) { return v >> 16; }
 // bit k (lo) / 16+k (hi) <- sign bits of the packed difference d
@@ -61,7 +62,7 @@ template <int W, bool CVX, bool SW>
 __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R, const int N,
                                             const uint8_t* __restrict__ seq, const int L, const DpBuffers& B,
                                             char* smem, DpResult& res) {
-    static_assert(W % 4 == 0 && W <= 16, "W must be a multiple of 4, at most 16");
+    static_assert(W >= 4 && W <= 15, "mask words hold W bits per strip plus the hand-over bit");
     const int T = (int)blockDim.x;
     const int NW = T >> 6;
     const int TW = T * W;           // columns of one half
@@ -71,22 +72,27 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     uint2* lrow = (uint2*)(smem + LDS_CTL_BYTES + LDS_META_BYTES);  // parked register row (>= 3 preds)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int j0 = t * W;           // first column of my lo strip; hi strip starts at TW + j0
-    const int g = S.g, e = S.e, q = S.q, c = S.c;
+    // scoring values are block-uniform: keep them (and everything derived) in SGPRs
+    const int g = __builtin_amdgcn_readfirstlane(S.g), e = __builtin_amdgcn_readfirstlane(S.e);
+    const int q = __builtin_amdgcn_readfirstlane(S.q), c = __builtin_amdgcn_readfirstlane(S.c);
     const int G2 = pk2(g, g), E2 = pk2(e, e), Q2 = pk2(q, q), C2 = pk2(c, c);
-    const int MN2 = pk2(S.n - S.m, S.n - S.m), M2 = pk2(S.m, S.m), ONE2 = 0x00010001, NEG2 = pk2(NEGP, NEGP);
+    const int sm = __builtin_amdgcn_readfirstlane(S.m), sn = __builtin_amdgcn_readfirstlane(S.n);
+    const int MN2 = pk2(sn - sm, sn - sm), M2 = pk2(sm, sm), ONE2 = 0x00010001, NEG2 = pk2(NEGP, NEGP);
     const int We = W * e, Wc = W * c;
     int* tot = lds;            // [4][16]: a_lo, a_hi, b_lo, b_hi inclusive totals per wave
     int* xch = lds + 64;       // [16][2]: (Hc[W-1] packed, ext bits) of every wave's last lane
 
     // query letters, one byte per (strip, column): register c2 holds (lo_k, hi_k, lo_k+1, hi_k+1)
-    unsigned let[W / 2];
+    constexpr int NL = (W + 1) / 2;
+    unsigned let[NL];
 #pragma unroll
-    for (int k2 = 0; k2 < W / 2; ++k2) {
+    for (int k2 = 0; k2 < NL; ++k2) {
         unsigned v = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int j = (b & 1 ? TW : 0) + j0 + 2 * k2 + (b >> 1);
-            const unsigned ch = (j >= 1 && j <= L) ? (unsigned)seq[j - 1] : 15u;
+            const int kc = 2 * k2 + (b >> 1);  // strip-local column (W odd: one spare byte)
+            const int j = (b & 1 ? TW : 0) + j0 + kc;
+            const unsigned ch = (kc < W && j >= 1 && j <= L) ? (unsigned)seq[j - 1] : 15u;
             v |= (ch > 4u && ch != 15u ? 4u : ch) << (8 * b);
         }
         let[k2] = v;
@@ -125,6 +131,8 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     int best_lo = SW ? 0 : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;
     const int kL_lo = L - j0, kL_hi = L - TW - j0;  // strip-local index of the end column L
 
+    unsigned fxm = 0, oxm = 0;
+    int prev_p0 = -2;
     for (int i = 1; i <= N; ++i) {
         const int r = i - 1;
         if ((r & (META_CHUNK - 1)) == 0) {
@@ -147,10 +155,14 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         const int np = info & 0xffff, code = (info >> 16) & 0xff, flags = (info >> 24) & 0xff;
         const unsigned CODE4 = (unsigned)code * 0x01010101u;
 #pragma unroll
-        for (int k2 = 0; k2 < W / 2; ++k2) SXG_PIN("+v"(let[k2]));
+        for (int k2 = 0; k2 < NL; ++k2) SXG_PIN("+v"(let[k2]));
 
         int Hc[W];
-        unsigned fxm = 0, oxm = 0;
+        // sibling rows (alternative alleles): the same single predecessor as the row just done, so
+        // F, O and their ext bits carry over unchanged and only the diagonal H is fetched
+        const bool sib = np <= 1 && p0 == prev_p0 && p0 != i - 1;
+        if (!sib) { fxm = 0; oxm = 0; }
+        prev_p0 = np <= 1 ? p0 : -2;
 
 #define P16_INIT(k, hs, fs, os, hprev)                        \
     do {                                                      \
@@ -176,6 +188,13 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         if (np <= 1 && p0 == i - 1) {
 #pragma unroll
             for (int k = 0; k < W; ++k) P16_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
+        } else if (sib) {
+            const uint2* base = (p0 == 0) ? (const uint2*)B.row0 : (const uint2*)B.pool + (size_t)s0 * TW;
+            int hl;
+            P16_LOAD_LEFT(base, hl);
+            Hc[0] = hl;
+#pragma unroll
+            for (int k = 1; k < W; ++k) Hc[k] = (int)base[j0 + k - 1].x;
         } else {
             const bool reg0 = (p0 == i - 1), reg1 = (np == 2 && p1 == i - 1);
             const bool park = np >= 3;
@@ -286,11 +305,13 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             h = pk_max(h, Fp[k]);
             if (CVX) { SXG_SIGN_TO(gto, pk_sub(h, Op[k]), k); h = pk_max(h, Op[k]); }
             Hc[k] = h;
-            const int hc = SW ? pk_max(h, 0) : h;
-            a = pk_max(pk_add(a, E2), pk_add(hc, G2));
-            if (CVX) b = pk_max(pk_add(b, C2), pk_add(hc, Q2));
+            // a = max_k (max(h_k, 0 if SW) + g + (W-1-k) e): the open+extend cost to the strip's end is
+            // a per-column scalar constant, and the clamp contributes only its best term (k = W-1)
+            a = pk_max(a, pk_add(h, pk2s(g + (W - 1 - k) * e)));
+            if (CVX) b = pk_max(b, pk_add(h, pk2s(q + (W - 1 - k) * c)));
             SXG_PIN("+v"(Hc[k]), "+v"(gtf), "+v"(gto), "+v"(a), "+v"(b));
         }
+        if (SW) { a = pk_max(a, G2); if (CVX) b = pk_max(b, Q2); }
         // ---- carries (32-bit).  Strip order: lo strips of lanes 0..T-1, then hi strips.
         // y = a - s*W*e with strip index s (lo: t, hi: T + t); E entering strip s = max_{s'<s} y_{s'} + (s-1)*W*e
         int ya_lo = pk_lo(a) - t * We, ya_hi = pk_hi(a) - (T + t) * We;
@@ -322,12 +343,12 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         int E = pk2(Ein_lo, Ein_hi), Q = pk2(Qin_lo, Qin_hi);
 
         // ---- pass 2: final H and the remaining decision bits
-        unsigned gte = 0, gtq = 0, stp = 0, exm = 0, qxm = 0;  // exm/qxm: EXTEND bit of E/Q of column k
+        // exm/qxm: EXTEND bit of E/Q of column k; the decision made at column k belongs to column
+        // k+1, so it goes straight to bit k+1 (bit W = the hand-over to the next lane)
+        unsigned gte = 0, gtq = 0, stp = 0, exm = 0, qxm = 0;
         int rowmax = SW ? 0 : NEG2;
-        unsigned ebn = 0, qbn = 0;  // ext bits of the NEXT column, at bit positions 0 / 16
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            exm |= ebn << k; if (CVX) qxm |= qbn << k;
             int h = Hc[k];
             SXG_SIGN_TO(gte, pk_sub(h, E), k);
             h = pk_max(h, E);
@@ -336,19 +357,20 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             Hc[k] = h;
             rowmax = pk_max(rowmax, h);
             const int c1 = pk_add(h, G2), c2 = pk_add(E, E2);
-            ebn = (((unsigned)pk_sub(c1, c2)) >> 15) & 0x00010001u;
+            SXG_SIGN_TO(exm, pk_sub(c1, c2), k + 1);
             E = pk_max(c1, c2);
             if (CVX) {
                 const int d1 = pk_add(h, Q2), d2 = pk_add(Q, C2);
-                qbn = (((unsigned)pk_sub(d1, d2)) >> 15) & 0x00010001u;
+                SXG_SIGN_TO(qxm, pk_sub(d1, d2), k + 1);
                 Q = pk_max(d1, d2);
             }
-            SXG_PIN("+v"(Hc[k]), "+v"(gte), "+v"(gtq), "+v"(stp), "+v"(exm), "+v"(qxm), "+v"(E), "+v"(Q), "+v"(ebn), "+v"(qbn), "+v"(rowmax));
+            SXG_PIN("+v"(Hc[k]), "+v"(gte), "+v"(gtq), "+v"(stp), "+v"(exm), "+v"(qxm), "+v"(E), "+v"(Q), "+v"(rowmax));
         }
         // hand my last column and the ext bits of the next column to the right neighbour; the lo
         // half's last lane feeds lane 0's hi strip
         const int xh = Hc[W - 1];
-        const int xb = (int)(ebn | (qbn << 1));  // bits 0,1 (lo strip), 16,17 (hi strip)
+        const int xb = (int)(((exm >> W) & 0x00010001u) | (((qxm >> W) & 0x00010001u) << 1));  // bits 0,1 (lo strip), 16,17 (hi strip)
+        exm &= ALL; qxm &= ALL;
         int lh = __shfl_up(xh, 1), lb = __shfl_up(xb, 1);
         if (lane == 63) { xch[2 * wv] = xh; xch[2 * wv + 1] = xb; }
         SXG_ROW_BARRIER();  // B2
@@ -433,44 +455,79 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 // Traceback over the packed mask plane (S5).  The source of H is the LAST candidate in the order
 // D, F, O, E, Q that strictly beat the running maximum (first-wins priority D > F > O > E > Q),
 // unless the cell is a STOP.
-__device__ __forceinline__ int p16_winner(const RowsView& R, const DpBuffers& B, const int T, const int r, const int np,
-                                          const int lane_t, const int bit, const int which) {
-    const int tx = R.tbx[r];
-    for (int x = np - 1; x >= 1; --x) {
-        const unsigned m = B.steps[((size_t)(tx + x - 1) * 3 + which) * T + lane_t];
-        if ((m >> bit) & 1u) return x;
-    }
-    return 0;
-}
+// Windowed walk.  The replay is a chain of dependent reads, so one lane chasing HBM (the first
+// version) paid a full memory round trip per step -- 18 % of the slot time on the headline
+// workload.  Here the whole of wave 0 takes part: lane l fetches, in ONE round trip, everything a
+// step through row (top - l) can need -- the mask words of the two lane-columns around the
+// diagonal through the current cell, the row descriptor and the node id -- into an LDS window of 64
+// rows; the walk itself then runs out of LDS (every lane executes it redundantly, lane 0 writes)
+// and only returns to HBM when it leaves the window (an indel run wider than half a strip, a
+// predecessor far up the order, the hi -> lo half crossing) or needs a fold-step plane of a
+// multi-predecessor row.
+constexpr int TBW_ROWS = 64;
+constexpr int TBW_STRIDE = 31;  // dwords per window row (odd: conflict-free fills)
+static_assert(TBW_ROWS * TBW_STRIDE * 4 <= LDS_META_BYTES, "traceback window lives in the descriptor area");
 
-template <bool PAIRS>
-__device__ __noinline__ int traceback_p16(const RowsView& R, const DpBuffers& B, const int T, const int W, const int sw, int i, int j,
-                                          int32_t* posnode, int32_t* pair_row, int32_t* pair_pos) {
+template <bool PAIRS, int W>
+__device__ __noinline__ int traceback_p16(const RowsView& R, const DpBuffers& B, const int T, const int sw, int i, int j,
+                                          int32_t* posnode, int32_t* pair_row, int32_t* pair_pos, char* smem) {
     const int TW = T * W;
+    const int lane = threadIdx.x & 63;
+    uint32_t* win = (uint32_t*)(smem + LDS_CTL_BYTES);
+    // first of the two lane-columns fetched for a row whose expected (half-local) column is x
+    auto col0 = [&](int x) -> int { return x < W / 2 ? 0 : min((x - W / 2) / W, T - 2); };
     int n = 0, st = SRC_STOP;
+    int wtop = -1, wjj = 0, whalf = -1;
     for (;;) {
         if (i == 0) {
             if (j == 0 || sw) break;
-            if (PAIRS) { pair_row[n] = 0; pair_pos[n] = j - 1; }
+            if (PAIRS && lane == 0) { pair_row[n] = 0; pair_pos[n] = j - 1; }
             ++n; --j;
             continue;
         }
         const int r = i - 1;
         const int half = j >= TW ? 1 : 0, jj = j - half * TW;
         const int lt = jj / W, bit = (jj - lt * W) + 16 * half;
-        // one round trip per step: the 9 mask words of the cell's lane and the row descriptor
-        // (which carries the first two predecessors) are fetched together
-        const uint32_t* mw = (const uint32_t*)B.tb + ((size_t)i * T + lt) * P16_TB_WORDS;
-        uint32_t m[P16_TB_WORDS];
+        int l = wtop - i;
+        int c0 = col0(wjj - l);
+        if (wtop < 0 || l < 0 || l >= TBW_ROWS || half != whalf || (unsigned)(lt - c0) > 1u) {
+            wtop = i; wjj = jj; whalf = half;
+            const int row = i - lane;
+            if (row >= 1) {
+                const int c = col0(jj - lane);
+                const uint32_t* mw = (const uint32_t*)B.tb + ((size_t)row * T + c) * P16_TB_WORDS;
+                uint32_t v[2 * P16_TB_WORDS];
 #pragma unroll
-        for (int x = 0; x < P16_TB_WORDS; ++x) m[x] = mw[x];
-        const int4 d0 = *(const int4*)(R.meta + 8 * (size_t)r), d1 = *(const int4*)(R.meta + 8 * (size_t)r + 4);
-        const int node = R.row_node[r];
-        const int pb = d0.x, np = d0.y & 0xffff, q0 = d0.z, q1 = d1.x;
+                for (int x = 0; x < 2 * P16_TB_WORDS; ++x) v[x] = mw[x];
+                const int4 d0 = *(const int4*)(R.meta + 8 * (size_t)(row - 1)), d1 = *(const int4*)(R.meta + 8 * (size_t)(row - 1) + 4);
+                const int node = R.row_node[row - 1];
+                uint32_t* e = win + lane * TBW_STRIDE;
+#pragma unroll
+                for (int x = 0; x < 2 * P16_TB_WORDS; ++x) e[x] = v[x];
+                e[18] = (uint32_t)d0.x; e[19] = (uint32_t)d0.y; e[20] = (uint32_t)d0.z; e[21] = (uint32_t)d1.x;
+                e[22] = (uint32_t)node; e[29] = (uint32_t)d1.w;
+                if ((d0.y & 0xffff) >= 2) {  // first fold step of a multi-predecessor row (D, F, O planes)
+                    const uint32_t* sp = B.steps + (size_t)d1.w * 3 * T + c;
+#pragma unroll
+                    for (int w3 = 0; w3 < 3; ++w3) { e[23 + 2 * w3] = sp[(size_t)w3 * T]; e[24 + 2 * w3] = sp[(size_t)w3 * T + 1]; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            l = 0; c0 = col0(jj);
+        }
+        const uint32_t* e = win + l * TBW_STRIDE;
+        const uint32_t* m = e + (lt - c0) * P16_TB_WORDS;
+        const int pb = (int)e[18], np = (int)(e[19] & 0xffffu), q0 = (int)e[20], q1 = (int)e[21], node = (int)e[22];
         auto pred_of = [&](int which) -> int {
             if (np == 0) return 0;
             if (np == 1) return q0;
-            const int ord = p16_winner(R, B, T, r, np, lt, bit, which);
+            const int tx = (int)e[29];
+            int ord = 0;
+            for (int x = np - 1; x >= 2 && !ord; --x)
+                if ((B.steps[((size_t)(tx + x - 1) * 3 + which) * T + lt] >> bit) & 1u) ord = x;
+            if (!ord) ord = (int)((e[23 + 2 * which + (lt - c0)] >> bit) & 1u);
             return ord == 0 ? q0 : (ord == 1 ? q1 : R.preds[pb + ord]);
         };
         if (st == SRC_STOP) {
@@ -483,21 +540,23 @@ __device__ __noinline__ int traceback_p16(const RowsView& R, const DpBuffers& B,
             else src = SRC_D;
             if (src == SRC_STOP) break;
             if (src == SRC_D) {
-                if (PAIRS) { pair_row[n] = i; pair_pos[n] = j - 1; }
-                if (posnode) posnode[j - 1] = node;
+                if (lane == 0) {
+                    if (PAIRS) { pair_row[n] = i; pair_pos[n] = j - 1; }
+                    if (posnode) posnode[j - 1] = node;
+                }
                 ++n;
                 i = pred_of(0);
                 --j;
             } else st = src;
         } else if (st == SRC_F || st == SRC_O) {
             const unsigned ext = (m[st == SRC_F ? PM_FX : PM_OX] >> bit) & 1u;
-            if (PAIRS) { pair_row[n] = i; pair_pos[n] = -1; }
+            if (PAIRS && lane == 0) { pair_row[n] = i; pair_pos[n] = -1; }
             ++n;
             i = pred_of(st == SRC_F ? 1 : 2);
             if (!ext) st = SRC_STOP;
         } else {
             const unsigned ext = (m[st == SRC_E ? PM_EX : PM_QX] >> bit) & 1u;
-            if (PAIRS) { pair_row[n] = 0; pair_pos[n] = j - 1; }
+            if (PAIRS && lane == 0) { pair_row[n] = 0; pair_pos[n] = j - 1; }
             ++n; --j;
             if (!ext) st = SRC_STOP;
         }

@@ -193,10 +193,9 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                 else dp_fill<W, CVX, H16, SW>(S, V.R, N, seq, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 PROF(2);
-                if (t == 0 && res.bi >= 0) {
-                    if constexpr (RM == 2) traceback_p16<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
-                    else traceback<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
-                }
+                if constexpr (RM == 2) {  // wave 0 walks together (LDS window)
+                    if (t < 64 && res.bi >= 0) traceback_p16<false, W>(V.R, V.B, T, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr, smem);
+                } else if (t == 0 && res.bi >= 0) traceback<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
                 score = res.bi >= 0 ? res.best : 0;
                 __syncthreads();
                 PROF(3);
@@ -298,9 +297,10 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
                 if constexpr (RM == 2) dp_fill_p16<W, CVX, SW>(S, V.R, N, A.bases + so, len, V.B, smem, res);
                 else dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
+                if constexpr (RM == 2) {
+                    if (t < 64 && res.bi >= 0) npairs = traceback_p16<true, W>(V.R, V.B, T, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos, smem);
+                } else if (t == 0 && res.bi >= 0) npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
                 if (t == 0 && res.bi >= 0) {
-                    if constexpr (RM == 2) npairs = traceback_p16<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
-                    else npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
                     score = res.best;
                     const int64_t out0 = A.row_off[p] + A.seq_off[p];
                     for (int k = 0; k < npairs; ++k) {  // reverse into the output
@@ -353,9 +353,9 @@ struct Variant {
 // columns (~165 VGPRs, <= 512 threads) / 12 (128 VGPRs); packed sweep 12 (~152) / 8 (124).
 static bool variant_for_len(int maxlen, int rm, Variant* v) {
     static const int kNW[] = {1, 2, 3, 4, 8, 12, 16};
-    static const int kW32[] = {16, 12, 8}, kW16[] = {12, 8};
+    static const int kW32[] = {16, 12, 8}, kW16[] = {12, 11, 10, 9, 8};
     const int* ws = rm == 2 ? kW16 : kW32;
-    const int nws = rm == 2 ? 2 : 3;
+    const int nws = rm == 2 ? 5 : 3;
     const int need = maxlen + 1;
     long best_cols = -1;
     for (int wi = 0; wi < nws; ++wi)
@@ -397,8 +397,10 @@ static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
     SXG_PICK(pick_block, 256, 8); SXG_PICK(pick_block, 256, 12); SXG_PICK(pick_block, 256, 16);
     SXG_PICK(pick_block, 512, 8); SXG_PICK(pick_block, 512, 12); SXG_PICK(pick_block, 512, 16);
     SXG_PICK(pick_block, 1024, 8); SXG_PICK(pick_block, 1024, 12);
-    SXG_PICK16(pick_block, 256, 8); SXG_PICK16(pick_block, 256, 12);
-    SXG_PICK16(pick_block, 512, 8); SXG_PICK16(pick_block, 512, 12);
+    SXG_PICK16(pick_block, 256, 8); SXG_PICK16(pick_block, 256, 9); SXG_PICK16(pick_block, 256, 10);
+    SXG_PICK16(pick_block, 256, 11); SXG_PICK16(pick_block, 256, 12);
+    SXG_PICK16(pick_block, 512, 8); SXG_PICK16(pick_block, 512, 9); SXG_PICK16(pick_block, 512, 10);
+    SXG_PICK16(pick_block, 512, 11); SXG_PICK16(pick_block, 512, 12);
     SXG_PICK16(pick_block, 1024, 8);
     return nullptr;
 }
@@ -406,8 +408,10 @@ static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool sw) {
     SXG_PICK(pick_align, 256, 8); SXG_PICK(pick_align, 256, 12); SXG_PICK(pick_align, 256, 16);
     SXG_PICK(pick_align, 512, 8); SXG_PICK(pick_align, 512, 12); SXG_PICK(pick_align, 512, 16);
     SXG_PICK(pick_align, 1024, 8); SXG_PICK(pick_align, 1024, 12);
-    SXG_PICK16(pick_align, 256, 8); SXG_PICK16(pick_align, 256, 12);
-    SXG_PICK16(pick_align, 512, 8); SXG_PICK16(pick_align, 512, 12);
+    SXG_PICK16(pick_align, 256, 8); SXG_PICK16(pick_align, 256, 9); SXG_PICK16(pick_align, 256, 10);
+    SXG_PICK16(pick_align, 256, 11); SXG_PICK16(pick_align, 256, 12);
+    SXG_PICK16(pick_align, 512, 8); SXG_PICK16(pick_align, 512, 9); SXG_PICK16(pick_align, 512, 10);
+    SXG_PICK16(pick_align, 512, 11); SXG_PICK16(pick_align, 512, 12);
     SXG_PICK16(pick_align, 1024, 8);
     return nullptr;
 }
@@ -792,6 +796,17 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             pl->work.push_back(b);
         }
         std::sort(plans.begin(), plans.end(), [](const LaunchPlan& a, const LaunchPlan& b) { return a.variant.Lpad() > b.variant.Lpad(); });
+        // a geometry within 12 % of a wider one of the same kind joins it: one full launch beats two
+        // partial ones, and the per-block choice above is already within a strip width of optimal
+        for (size_t i = 0; i < plans.size(); ++i)
+            for (size_t j = i + 1; j < plans.size();) {
+                const LaunchPlan &a = plans[i], &b = plans[j];
+                if (a.variant.RM == b.variant.RM && a.cvx == b.cvx && a.sw == b.sw &&
+                    (double)b.variant.Lpad() >= 0.88 * (double)a.variant.Lpad()) {
+                    plans[i].work.insert(plans[i].work.end(), b.work.begin(), b.work.end());
+                    plans.erase(plans.begin() + (long)j);
+                } else ++j;
+            }
         const uint64_t budget = arena_budget(h);
         uint64_t want_bytes = 0;
         for (auto& pl : plans) {
