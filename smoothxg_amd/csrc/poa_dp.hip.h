@@ -106,6 +106,15 @@ template <> struct RowWord<false> {
     static __device__ __forceinline__ int h_of(type w) { return (int)w.x; }
 };
 
+// Pointers that reach the sweeps through structs in private memory lose their address space and
+// the compiler falls back to FLAT loads/stores: 64-bit VGPR addresses, and -- worse -- every flat
+// access also counts on lgkmcnt, so each "s_waitcnt lgkmcnt(0)" in front of a barrier or behind a
+// ds_bpermute waited for all outstanding HBM traffic.  The hot paths therefore re-type their
+// base pointers as global once (scalar base + lane offset, vmcnt only).
+#define SXG_GLOBAL __attribute__((address_space(1)))
+template <class Tp> __device__ __forceinline__ SXG_GLOBAL Tp* sxg_global(Tp* p) { return (SXG_GLOBAL Tp*)p; }
+template <class Tp> __device__ __forceinline__ SXG_GLOBAL const Tp* sxg_global(const Tp* p) { return (SXG_GLOBAL const Tp*)p; }
+
 struct DpBuffers {
     uint8_t* tb;       // [(rows_cap+1) * Lpad] traceback bytes, row-major, row 0 unused
     uint32_t* steps;   // [step_cap * 3 * T] fold-step masks of multi-pred rows: for step s (=
@@ -114,7 +123,49 @@ struct DpBuffers {
     void* pool;        // [pool_slots * Lpad] packed rows
     void* row0;        // [Lpad] packed virtual source row
     void* park;        // [Lpad] parked previous row when it cannot live in LDS
+    int prio_rank;     // launch rank of this workgroup among its CU's co-residents (see sxg_rotate_prio)
+    uint32_t* prio_board;          // this CU's progress board (PRIO_BOARD_SLOTS words) or nullptr
+    unsigned long long prio_rem0;  // estimated cells this workgroup still has to do, at row 0 of this sweep
+    unsigned long long* row_prof;  // SXG_ROW_PROF builds: 12 per-slot accumulators of row segments
 };
+constexpr int PRIO_BOARD_SLOTS = 16;   // co-resident workgroups per CU the board can tell apart
+constexpr int PRIO_BOARD_CUS = 4096;   // __smid() & 0xfff
+
+// Fair shares between co-resident workgroups.  The CU's instruction arbiter is oldest-wave-first,
+// and workgroups k, k+#CU, k+2#CU, ... (launched in that order) share a CU: measured on the headline
+// run the four co-residents finished at 0.64 / 0.74 / 0.86 / 0.98 of the kernel time although their
+// blocks cost the same, so the CU ran its last quarter with one or two waves per SIMD.  User
+// priority beats age, so every workgroup steps through priorities 3,2,1,0 in 41 us slices of the
+// 100 MHz wall clock, offset by its launch rank: at any moment the co-residents hold four
+// different priorities and over a rotation everybody gets the same share.
+__device__ __forceinline__ void sxg_set_prio(const unsigned p) {
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+// Closed loop on top of that idea (block kernel): every workgroup posts the work it has left on its
+// CU's board and takes as priority the number of co-residents that have LESS left, so the one
+// furthest from its end always runs first and the four converge on a common finish.
+__device__ __forceinline__ void sxg_balance_prio(const DpBuffers& B, const unsigned long long done) {
+    const unsigned long long left = B.prio_rem0 > done ? B.prio_rem0 - done : 0;
+    const unsigned mine = (unsigned)min(left >> 16, 0xfffffffeull) + 1u;
+    if (threadIdx.x == 0) __hip_atomic_store(B.prio_board + B.prio_rank, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned behind = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // launch ranks 0..7 (occupancy never exceeds 8 workgroups per CU here)
+        const unsigned other = __hip_atomic_load(B.prio_board + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        behind += (k != B.prio_rank && other != 0u && other < mine) ? 1u : 0u;
+    }
+    sxg_set_prio(min(__builtin_amdgcn_readfirstlane(behind), 3u));
+}
+__device__ __forceinline__ void sxg_rotate_prio(const int rank) {
+    const unsigned ph = ((unsigned)((unsigned long long)wall_clock64() >> 12) + (unsigned)rank) & 3u;
+    if (ph == 0) __builtin_amdgcn_s_setprio(3);
+    else if (ph == 1) __builtin_amdgcn_s_setprio(2);
+    else if (ph == 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 
 struct DpResult {
     int best, bi, bj;  // end cell (row index 1-based); bi < 0: empty alignment
@@ -242,6 +293,8 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
     const int kL = L - j0;                          // strip-local index of the end column L
 
     for (int i = 1; i <= N; ++i) {
+        if (B.prio_board) { if ((i & 15) == 1) sxg_balance_prio(B, (unsigned long long)i * (unsigned long long)L); }
+        else if ((i & 3) == 1) sxg_rotate_prio(B.prio_rank);
         const int r = i - 1;
         if ((r & (META_CHUNK - 1)) == 0) {
             // stage the descriptors of the next 256 rows (all waves are past row r-1 here)

@@ -27,6 +27,9 @@ namespace sxg {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// native vector types: usable behind address-space-qualified pointers (HIP's u32x2/i32x4 classes are not)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NEGP = -16384;  // "minus infinity" of the packed sweep
 constexpr int P16_TB_WORDS = 9;
@@ -48,11 +51,11 @@ __device__ __forceinline__ int pk_hi(int v) { return v >> 16; }
 constexpr int LDS16_X = 64;  // ints of exchange scratch after the four [16] arrays of dp_fill
 
 // Row words of the packed ring: (Hpk, deltas) per lane and column.
-__device__ __forceinline__ uint2 p16_pack_row(int h, int f, int o) {
+__device__ __forceinline__ u32x2 p16_pack_row(int h, int f, int o) {
     const int df = pk_minu(pk_sub(h, f), 0x00ff00ff), dq = pk_minu(pk_sub(h, o), 0x00ff00ff);
-    return make_uint2((unsigned)h, (unsigned)(df | (dq << 8)));
+    return u32x2{(unsigned)h, (unsigned)(df | (dq << 8))};
 }
-__device__ __forceinline__ void p16_unpack_row(uint2 w, int& h, int& f, int& o) {
+__device__ __forceinline__ void p16_unpack_row(u32x2 w, int& h, int& f, int& o) {
     h = (int)w.x;
     f = pk_sub(h, (int)(w.y & 0x00ff00ffu));
     o = pk_sub(h, (int)((w.y >> 8) & 0x00ff00ffu));
@@ -68,8 +71,8 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     const int TW = T * W;           // columns of one half
     constexpr unsigned ALL = ((1u << W) - 1u) * 0x00010001u;
     int* lds = (int*)smem;
-    const int4* lmeta = (const int4*)(smem + LDS_CTL_BYTES);
-    uint2* lrow = (uint2*)(smem + LDS_CTL_BYTES + LDS_META_BYTES);  // parked register row (>= 3 preds)
+    const i32x4* lmeta = (const i32x4*)(smem + LDS_CTL_BYTES);
+    u32x2* lrow = (u32x2*)(smem + LDS_CTL_BYTES + LDS_META_BYTES);  // parked register row (>= 3 preds)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int j0 = t * W;           // first column of my lo strip; hi strip starts at TW + j0
     // scoring values are block-uniform: keep them (and everything derived) in SGPRs
@@ -98,6 +101,19 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         let[k2] = v;
     }
 
+    // Rows in HBM (ring, row 0) are laid out [column-in-strip][lane] and the mask plane
+    // [row][word][lane]: a load/store instruction then covers 64 consecutive words of a wave
+    // instead of 64 different cache lines (the lane-major layout kept the texture-address unit
+    // busier than the VALU).  Every access is "uniform pointer"[ut]: scalar base, one loop-invariant
+    // lane offset register, no per-access address arithmetic.
+    const unsigned ut = (unsigned)t;
+    SXG_GLOBAL u32x2* const g_row0 = sxg_global((u32x2*)B.row0);
+    SXG_GLOBAL u32x2* const g_pool = sxg_global((u32x2*)B.pool);
+    SXG_GLOBAL uint32_t* const g_tb = sxg_global((uint32_t*)B.tb);
+    SXG_GLOBAL uint32_t* const g_steps = sxg_global(B.steps);
+    SXG_GLOBAL const int32_t* const g_meta = sxg_global((const int32_t*)R.meta);
+    SXG_GLOBAL const int32_t* const g_preds = sxg_global((const int32_t*)R.preds);
+    SXG_GLOBAL const int32_t* const g_slot = sxg_global((const int32_t*)R.slot);
     int Hp[W], Fp[W], Op[W], Hleft;
     // virtual row 0
 #pragma unroll
@@ -124,26 +140,33 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         Hleft = pk2(h2[0], h2[1]);
     }
     {
-        uint2* r0 = (uint2*)B.row0 + j0;
 #pragma unroll
-        for (int k = 0; k < W; ++k) r0[k] = p16_pack_row(Hp[k], Fp[k], Op[k]);
+        for (int k = 0; k < W; ++k) (g_row0 + k * T)[ut] = p16_pack_row(Hp[k], Fp[k], Op[k]);
     }
     int best_lo = SW ? 0 : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;
     const int kL_lo = L - j0, kL_hi = L - TW - j0;  // strip-local index of the end column L
 
     unsigned fxm = 0, oxm = 0;
     int prev_p0 = -2;
+#ifdef SXG_ROW_PROF
+    unsigned long long racc[12] = {0};  // [row kind: 0 = register fast path, 1 = other][segment]
+#define RP_MARK(seg) do { const unsigned long long tn_ = clock64(); racc[rk_ * 6 + (seg)] += tn_ - rt_; rt_ = tn_; } while (0)
+#else
+#define RP_MARK(seg) do { } while (0)
+#endif
     for (int i = 1; i <= N; ++i) {
+        if (B.prio_board) { if ((i & 15) == 1) sxg_balance_prio(B, (unsigned long long)i * (unsigned long long)L); }
+        else if ((i & 3) == 1) sxg_rotate_prio(B.prio_rank);
         const int r = i - 1;
         if ((r & (META_CHUNK - 1)) == 0) {
             __syncthreads();
-            const int4* gm = (const int4*)(R.meta + 8 * (size_t)r);
-            int4* lm = (int4*)(smem + LDS_CTL_BYTES);
+            SXG_GLOBAL const i32x4* gm = (SXG_GLOBAL const i32x4*)(g_meta + 8 * (size_t)r);
+            i32x4* lm = (i32x4*)(smem + LDS_CTL_BYTES);
             const int nrow = min(META_CHUNK, N - r);
             for (int x = t; x < 2 * nrow; x += T) lm[x] = gm[x];
             __syncthreads();
         }
-        const int4 m0 = lmeta[2 * (r & (META_CHUNK - 1))], m1 = lmeta[2 * (r & (META_CHUNK - 1)) + 1];
+        const i32x4 m0 = lmeta[2 * (r & (META_CHUNK - 1))], m1 = lmeta[2 * (r & (META_CHUNK - 1)) + 1];
         const int pb = __builtin_amdgcn_readfirstlane(m0.x);
         const int info = __builtin_amdgcn_readfirstlane(m0.y);
         const int p0 = __builtin_amdgcn_readfirstlane(m0.z);
@@ -157,6 +180,10 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 #pragma unroll
         for (int k2 = 0; k2 < NL; ++k2) SXG_PIN("+v"(let[k2]));
 
+#ifdef SXG_ROW_PROF
+        const int rk_ = (np <= 1 && p0 == i - 1) ? 0 : 1;
+        unsigned long long rt_ = clock64();
+#endif
         int Hc[W];
         // sibling rows (alternative alleles): the same single predecessor as the row just done, so
         // F, O and their ext bits carry over unchanged and only the diagonal H is fetched
@@ -181,20 +208,30 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 // hi = last column of the lo half (lane T-1)
 #define P16_LOAD_LEFT(sp_base, hl)                                                    \
     do {                                                                              \
-        if (t > 0) hl = (int)(sp_base)[(size_t)(j0 - 1)].x;                           \
-        else hl = pk2(NEGP, pk_lo((int)(sp_base)[(size_t)(TW - 1)].x));               \
+        if (t > 0) hl = (int)((sp_base) + (W - 1) * T - 1)[ut].x;                     \
+        else hl = pk2(NEGP, pk_lo((int)(sp_base)[TW - 1].x));                         \
+    } while (0)
+
+// words of the stored row of predecessor p_ (slot sl_) and the column to their left
+#define P16_FETCH(p_, sl_, wr_, hl_)                                                                        \
+    do {                                                                                                    \
+        {                                                                                                   \
+            SXG_GLOBAL const u32x2* base_ = ((p_) == 0) ? g_row0 : g_pool + (size_t)(sl_) * TW;            \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = (base_ + k * T)[ut];                     \
+            P16_LOAD_LEFT(base_, hl_);                                                                      \
+        }                                                                                                   \
     } while (0)
 
         if (np <= 1 && p0 == i - 1) {
 #pragma unroll
             for (int k = 0; k < W; ++k) P16_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
         } else if (sib) {
-            const uint2* base = (p0 == 0) ? (const uint2*)B.row0 : (const uint2*)B.pool + (size_t)s0 * TW;
+            u32x2 wr[W];
             int hl;
-            P16_LOAD_LEFT(base, hl);
+            P16_FETCH(p0, s0, wr, hl);
             Hc[0] = hl;
 #pragma unroll
-            for (int k = 1; k < W; ++k) Hc[k] = (int)base[j0 + k - 1].x;
+            for (int k = 1; k < W; ++k) Hc[k] = (int)wr[k - 1].x;
         } else {
             const bool reg0 = (p0 == i - 1), reg1 = (np == 2 && p1 == i - 1);
             const bool park = np >= 3;
@@ -208,17 +245,12 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 #pragma unroll
                 for (int k = 0; k < W; ++k) P16_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
             } else {
-                uint2 wr[W];
+                u32x2 wr[W];
                 int hl = Hleft;
                 if (reg0) {
 #pragma unroll
                     for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
-                } else {
-                    const uint2* base = (p0 == 0) ? (const uint2*)B.row0 : (const uint2*)B.pool + (size_t)s0 * TW;
-#pragma unroll
-                    for (int k = 0; k < W; ++k) wr[k] = base[j0 + k];
-                    P16_LOAD_LEFT(base, hl);
-                }
+                } else P16_FETCH(p0, s0, wr, hl);
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     int hs, fs, os;
@@ -232,20 +264,15 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                 int p, sl;
                 if (x == 1) { p = reg1 ? p0 : p1; sl = reg1 ? s0 : s1; }
                 else {
-                    p = __builtin_amdgcn_readfirstlane(R.preds[pb + x]);
-                    sl = (p >= 1 && p != i - 1) ? __builtin_amdgcn_readfirstlane(R.slot[p - 1]) : -1;
+                    p = __builtin_amdgcn_readfirstlane(g_preds[pb + x]);
+                    sl = (p >= 1 && p != i - 1) ? __builtin_amdgcn_readfirstlane(g_slot[p - 1]) : -1;
                 }
-                uint2 wr[W];
+                u32x2 wr[W];
                 int hl = Hleft;
                 if (p == i - 1) {
 #pragma unroll
                     for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
-                } else {
-                    const uint2* base = (p == 0) ? (const uint2*)B.row0 : (const uint2*)B.pool + (size_t)sl * TW;
-#pragma unroll
-                    for (int k = 0; k < W; ++k) wr[k] = base[j0 + k];
-                    P16_LOAD_LEFT(base, hl);
-                }
+                } else P16_FETCH(p, sl, wr, hl);
                 // take-over test "cand + ge > cur" = sign of (cur - cand - ge); the value is the max
                 // either way (on a tie both are equal); masks: xor as in the 32-bit sweep
                 unsigned dm = ge ? ALL : 0u, fmk = dm, omk = CVX ? dm : 0u;
@@ -280,17 +307,19 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                     hl = hs;
                     SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm), "+v"(dm), "+v"(fmk), "+v"(omk), "+v"(hl));
                 }
-                uint32_t* st = B.steps + ((size_t)(tx + x - 1) * 3) * T + t;
-                st[0] = dm; st[T] = fmk; st[2 * T] = omk;
+                SXG_GLOBAL uint32_t* st = g_steps + ((size_t)(tx + x - 1) * 3) * T;
+                st[ut] = dm; (st + T)[ut] = fmk; (st + 2 * T)[ut] = omk;
             }
         }
 #undef P16_INIT
+#undef P16_FETCH
 #undef P16_LOAD_LEFT
         if (!CVX) {
 #pragma unroll
             for (int k = 0; k < W; ++k) Op[k] = NEG2;
         }
 
+        RP_MARK(0);  // predecessor rows read, F/O/diagonal set up
         // ---- pass 1: H before the in-row gaps, strip-local carries
         unsigned gtf = 0, gto = 0;  // F / O strictly beat the running maximum
         int a = NEG2, b = NEG2;
@@ -322,7 +351,9 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             if (lane >= d) { ya_lo = max(ya_lo, o0); ya_hi = max(ya_hi, o1); yb_lo = max(yb_lo, o2); yb_hi = max(yb_hi, o3); }
         }
         if (lane == 63) { tot[wv] = ya_lo; tot[16 + wv] = ya_hi; tot[32 + wv] = yb_lo; tot[48 + wv] = yb_hi; }
+        RP_MARK(1);  // pass 1 + in-wave scan
         SXG_ROW_BARRIER();  // B1
+        RP_MARK(2);  // waiting at B1
         {
             int b0 = NEG * 2, b1 = NEG * 2, b2 = NEG * 2, b3 = NEG * 2, lo_a = NEG * 2, lo_b = NEG * 2;
             for (int x = 0; x < NW; ++x) {
@@ -373,7 +404,9 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         exm &= ALL; qxm &= ALL;
         int lh = __shfl_up(xh, 1), lb = __shfl_up(xb, 1);
         if (lane == 63) { xch[2 * wv] = xh; xch[2 * wv + 1] = xb; }
+        RP_MARK(3);  // carry combine + pass 2
         SXG_ROW_BARRIER();  // B2
+        RP_MARK(4);  // waiting at B2
         if (lane == 0) {
             if (wv > 0) { lh = xch[2 * (wv - 1)]; lb = xch[2 * (wv - 1) + 1]; }
             else {
@@ -407,19 +440,26 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 
         // ---- stores
         {
-            uint32_t* dst = (uint32_t*)B.tb + ((size_t)i * T + t) * P16_TB_WORDS;
-            dst[PM_STOP] = stp; dst[PM_GTF] = gtf; dst[PM_GTO] = gto; dst[PM_GTE] = gte; dst[PM_GTQ] = gtq;
-            dst[PM_FX] = fxm; dst[PM_OX] = oxm; dst[PM_EX] = exm; dst[PM_QX] = qxm;
+            SXG_GLOBAL uint32_t* dst = g_tb + (size_t)i * P16_TB_WORDS * T;  // [row][word][lane]
+            (dst + PM_STOP * T)[ut] = stp; (dst + PM_GTF * T)[ut] = gtf; (dst + PM_GTO * T)[ut] = gto;
+            (dst + PM_GTE * T)[ut] = gte; (dst + PM_GTQ * T)[ut] = gtq; (dst + PM_FX * T)[ut] = fxm;
+            (dst + PM_OX * T)[ut] = oxm; (dst + PM_EX * T)[ut] = exm; (dst + PM_QX * T)[ut] = qxm;
         }
         if (flags & ROW_STORE) {
-            uint2* dst = (uint2*)B.pool + (size_t)myslot * TW + j0;
+            SXG_GLOBAL u32x2* dst = g_pool + (size_t)myslot * TW;
 #pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = p16_pack_row(Hc[k], Fp[k], Op[k]);
+            for (int k = 0; k < W; ++k) (dst + k * T)[ut] = p16_pack_row(Hc[k], Fp[k], Op[k]);
         }
 #pragma unroll
         for (int k = 0; k < W; ++k) Hp[k] = Hc[k];
         Hleft = lh;
+        RP_MARK(5);  // end-cell bookkeeping + stores
     }
+#ifdef SXG_ROW_PROF
+    if (t == 0 && B.row_prof)
+        for (int k = 0; k < 12; ++k) B.row_prof[k] += racc[k];
+#endif
+#undef RP_MARK
 
     // ---- end cell: greatest score, then smallest row, then smallest column (two candidates per lane)
     unsigned long long key = 0;
@@ -469,7 +509,9 @@ constexpr int TBW_STRIDE = 31;  // dwords per window row (odd: conflict-free fil
 static_assert(TBW_ROWS * TBW_STRIDE * 4 <= LDS_META_BYTES, "traceback window lives in the descriptor area");
 
 template <bool PAIRS, int W>
-__device__ __noinline__ int traceback_p16(const RowsView& R, const DpBuffers& B, const int T, const int sw, int i, int j,
+// (views by value: a reference to the kernel's private copy trips an AMDGPU back-end assertion on
+// the private-aperture null check for some strip widths)
+__device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const int T, const int sw, int i, int j,
                                           int32_t* posnode, int32_t* pair_row, int32_t* pair_pos, char* smem) {
     const int TW = T * W;
     const int lane = threadIdx.x & 63;
@@ -495,19 +537,20 @@ __device__ __noinline__ int traceback_p16(const RowsView& R, const DpBuffers& B,
             const int row = i - lane;
             if (row >= 1) {
                 const int c = col0(jj - lane);
-                const uint32_t* mw = (const uint32_t*)B.tb + ((size_t)row * T + c) * P16_TB_WORDS;
+                SXG_GLOBAL const uint32_t* mw = sxg_global((const uint32_t*)B.tb) + (size_t)row * P16_TB_WORDS * T + c;  // [row][word][lane]
                 uint32_t v[2 * P16_TB_WORDS];
 #pragma unroll
-                for (int x = 0; x < 2 * P16_TB_WORDS; ++x) v[x] = mw[x];
-                const int4 d0 = *(const int4*)(R.meta + 8 * (size_t)(row - 1)), d1 = *(const int4*)(R.meta + 8 * (size_t)(row - 1) + 4);
-                const int node = R.row_node[row - 1];
+                for (int x = 0; x < P16_TB_WORDS; ++x) { v[x] = mw[(size_t)x * T]; v[P16_TB_WORDS + x] = mw[(size_t)x * T + 1]; }
+                SXG_GLOBAL const i32x4* dm = (SXG_GLOBAL const i32x4*)(sxg_global((const int32_t*)R.meta) + 8 * (size_t)(row - 1));
+                const i32x4 d0 = dm[0], d1 = dm[1];
+                const int node = sxg_global((const int32_t*)R.row_node)[row - 1];
                 uint32_t* e = win + lane * TBW_STRIDE;
 #pragma unroll
                 for (int x = 0; x < 2 * P16_TB_WORDS; ++x) e[x] = v[x];
                 e[18] = (uint32_t)d0.x; e[19] = (uint32_t)d0.y; e[20] = (uint32_t)d0.z; e[21] = (uint32_t)d1.x;
                 e[22] = (uint32_t)node; e[29] = (uint32_t)d1.w;
                 if ((d0.y & 0xffff) >= 2) {  // first fold step of a multi-predecessor row (D, F, O planes)
-                    const uint32_t* sp = B.steps + (size_t)d1.w * 3 * T + c;
+                    SXG_GLOBAL const uint32_t* sp = sxg_global((const uint32_t*)B.steps) + (size_t)d1.w * 3 * T + c;
 #pragma unroll
                     for (int w3 = 0; w3 < 3; ++w3) { e[23 + 2 * w3] = sp[(size_t)w3 * T]; e[24 + 2 * w3] = sp[(size_t)w3 * T + 1]; }
                 }
@@ -526,9 +569,9 @@ __device__ __noinline__ int traceback_p16(const RowsView& R, const DpBuffers& B,
             const int tx = (int)e[29];
             int ord = 0;
             for (int x = np - 1; x >= 2 && !ord; --x)
-                if ((B.steps[((size_t)(tx + x - 1) * 3 + which) * T + lt] >> bit) & 1u) ord = x;
+                if ((sxg_global((const uint32_t*)B.steps)[((size_t)(tx + x - 1) * 3 + which) * T + lt] >> bit) & 1u) ord = x;
             if (!ord) ord = (int)((e[23 + 2 * which + (lt - c0)] >> bit) & 1u);
-            return ord == 0 ? q0 : (ord == 1 ? q1 : R.preds[pb + ord]);
+            return ord == 0 ? q0 : (ord == 1 ? q1 : sxg_global((const int32_t*)R.preds)[pb + ord]);
         };
         if (st == SRC_STOP) {
             int src;

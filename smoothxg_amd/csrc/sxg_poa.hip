@@ -48,7 +48,7 @@ static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int s
     const size_t C = (size_t)nodes_cap + 4, S = (size_t)std::max(nodes_cap, Lpad) + 4, Rr = (size_t)rows_cap + 4;
     L.scratch_len = (int)S;
     size_t cur = 0;
-    L.hdr = lay(cur, 256);
+    L.hdr = lay(cur, 512);
     L.code = lay(cur, C);
     L.rank = lay(cur, 4 * C); L.order = lay(cur, 4 * C); L.order_tmp = lay(cur, 4 * C); L.leader = lay(cur, 4 * C);
     L.gmem = lay(cur, 20 * C);
@@ -133,6 +133,9 @@ struct BlockArgs {
     int want_consensus;
     int park_in_lds;
     int pf_off;  // byte offset of the LDS prefetch area, -1 = off
+    int num_cu;  // compute units of the device (co-residency of workgroups, sxg_rotate_prio)
+    uint32_t* prio_board;              // [PRIO_BOARD_CUS][PRIO_BOARD_SLOTS] progress board, zeroed per launch
+    const unsigned long long* est;     // [n_work] estimated cells of work item wi (host cost model)
 };
 
 // Kernel classes <TMAX, W>: TMAX bounds blockDim.x (the actual T = 64 * strips is a run-time
@@ -156,6 +159,8 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
     WgCtx ctx{lds + 128};
     const int t = threadIdx.x;
     SlotViews V = slot_views(A.arena + (size_t)blockIdx.x * A.lay.total, A.lay);
+    V.B.prio_rank = (int)(blockIdx.x / (unsigned)A.num_cu) & (PRIO_BOARD_SLOTS - 1);
+    V.B.prio_board = A.prio_board ? A.prio_board + (size_t)(__smid() & (PRIO_BOARD_CUS - 1)) * PRIO_BOARD_SLOTS : nullptr;
     const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap};
     for (;;) {
         __syncthreads();
@@ -164,6 +169,8 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
         const int wi = s_work;
         if (wi >= A.n_work) break;
         const int b = A.work[wi];
+        const unsigned long long est_total = A.est ? A.est[wi] : 0ull;
+        unsigned long long done_cells = 0;
         const int s0 = A.blk_off[b], s1 = A.blk_off[b + 1];
         const int64_t base0 = A.seq_off[s0];
         const Scoring S = normalise(A.params[A.per_block_params ? b : 0]);
@@ -171,6 +178,11 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
         __syncthreads();
         int status = ST_OK;
         unsigned long long* prof = (unsigned long long*)(A.arena + (size_t)blockIdx.x * A.lay.total + A.lay.hdr + 64);
+        V.B.row_prof = prof + 28;
+        if ((t & 63) == 0) {  // placement of every wave (debug dump): smid | raw HW_ID, and the slot's start
+            prof[10 + (t >> 6)] = ((unsigned long long)__smid() << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(GETREG_IMMED(31, 0, HW_ID));
+            if (t == 0 && prof[8] == 0) prof[8] = (unsigned long long)wall_clock64();
+        }
         unsigned long long tc0 = clock64(), tc1;
 #define PROF(k) do { if (t == 0) { tc1 = clock64(); prof[k] += tc1 - tc0; tc0 = tc1; } } while (0)
         for (int s = s0; s < s1 && status == ST_OK; ++s) {
@@ -189,6 +201,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                 if (status != ST_OK) break;
                 PROF(1);
                 DpResult res;
+                V.B.prio_rem0 = est_total > done_cells ? est_total - done_cells : 0ull;
                 if constexpr (RM == 2) dp_fill_p16<W, CVX, SW>(S, V.R, N, seq, len, V.B, smem, res);
                 else dp_fill<W, CVX, H16, SW>(S, V.R, N, seq, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
@@ -201,6 +214,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                 PROF(3);
             }
             if (t == 0) { A.score[s] = score; A.cells[s] = (unsigned long long)N * (unsigned long long)len; }
+            done_cells += (unsigned long long)N * (unsigned long long)len;
             add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
             PROF(4);
         }
@@ -224,7 +238,9 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             if (t == 0) { A.n_nodes[b] = N; A.n_edges[b] = E; A.n_cons[b] = nc; }
         } else if (t == 0) { A.n_nodes[b] = 0; A.n_edges[b] = 0; A.n_cons[b] = 0; }
         if (t == 0) A.status[b] = status;
+        if (t == 0 && V.B.prio_board) __hip_atomic_store(V.B.prio_board + V.B.prio_rank, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PROF(5);
+        if (t == 0) prof[9] = (unsigned long long)wall_clock64();
 #undef PROF
     }
 }
@@ -240,6 +256,7 @@ struct AlignArgs {
     int32_t* pair_row; int32_t* pair_pos;  // worst-case layout: problem p at row_off[p] + seq_off[p]
     int park_in_lds;
     int pf_off;
+    int num_cu;
 };
 
 template <int TMAX, int W, bool CVX, int RM, bool SW>
@@ -253,6 +270,8 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
     WgCtx ctx{lds + 128};
     const int t = threadIdx.x;
     SlotViews V = slot_views(A.arena + (size_t)blockIdx.x * A.lay.total, A.lay);
+    V.B.prio_rank = (int)(blockIdx.x / (unsigned)A.num_cu) & (PRIO_BOARD_SLOTS - 1);
+    V.B.prio_board = nullptr; V.B.prio_rem0 = 0; V.B.row_prof = nullptr;
     const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap};
     for (;;) {
         __syncthreads();
@@ -393,7 +412,11 @@ template <int TMAX, int W, int RM> static KernelFn<AlignArgs> pick_align(bool cv
     } while (0)
 #define SXG_PICK16(FN, TM, Wd) \
     do { if (v.TMAX == TM && v.W == Wd && v.RM == 2) return FN<TM, Wd, 2>(cvx, sw); } while (0)
+// SXG_DEV_ONLY_W=<w>: development builds instantiate a single packed class (seconds instead of minutes)
 static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
+#ifdef SXG_DEV_ONLY_W
+    SXG_PICK16(pick_block, SXG_DEV_ONLY_TMAX, SXG_DEV_ONLY_W);
+#else
     SXG_PICK(pick_block, 256, 8); SXG_PICK(pick_block, 256, 12); SXG_PICK(pick_block, 256, 16);
     SXG_PICK(pick_block, 512, 8); SXG_PICK(pick_block, 512, 12); SXG_PICK(pick_block, 512, 16);
     SXG_PICK(pick_block, 1024, 8); SXG_PICK(pick_block, 1024, 12);
@@ -402,9 +425,13 @@ static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
     SXG_PICK16(pick_block, 512, 8); SXG_PICK16(pick_block, 512, 9); SXG_PICK16(pick_block, 512, 10);
     SXG_PICK16(pick_block, 512, 11); SXG_PICK16(pick_block, 512, 12);
     SXG_PICK16(pick_block, 1024, 8);
+#endif
     return nullptr;
 }
 static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool sw) {
+#ifdef SXG_DEV_ONLY_W
+    SXG_PICK16(pick_align, SXG_DEV_ONLY_TMAX, SXG_DEV_ONLY_W);
+#else
     SXG_PICK(pick_align, 256, 8); SXG_PICK(pick_align, 256, 12); SXG_PICK(pick_align, 256, 16);
     SXG_PICK(pick_align, 512, 8); SXG_PICK(pick_align, 512, 12); SXG_PICK(pick_align, 512, 16);
     SXG_PICK(pick_align, 1024, 8); SXG_PICK(pick_align, 1024, 12);
@@ -413,6 +440,7 @@ static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool sw) {
     SXG_PICK16(pick_align, 512, 8); SXG_PICK16(pick_align, 512, 9); SXG_PICK16(pick_align, 512, 10);
     SXG_PICK16(pick_align, 512, 11); SXG_PICK16(pick_align, 512, 12);
     SXG_PICK16(pick_align, 1024, 8);
+#endif
     return nullptr;
 }
 
@@ -473,7 +501,7 @@ struct BlockMeta {
 };
 
 struct PlanRes {
-    DevBuf arena, work, queue;
+    DevBuf arena, work, queue, est;
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
@@ -542,7 +570,7 @@ extern "C" void sxg_poa_destroy(sxg_poa_handle* h) {
     (void)hipSetDevice(h->device);
     release_all(h);
     for (PlanRes* r : h->planres) {
-        r->arena.release(); r->work.release(); r->queue.release();
+        r->arena.release(); r->work.release(); r->queue.release(); r->est.release();
         if (r->e0) (void)hipEventDestroy(r->e0);
         if (r->e1) (void)hipEventDestroy(r->e1);
         if (r->stream) (void)hipStreamDestroy(r->stream);
@@ -658,6 +686,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
 struct LaunchPlan {
     Variant variant; bool cvx, sw;
     std::vector<int32_t> work;  // block ids, largest cost first
+    std::vector<unsigned long long> est;  // cost-model cells per work item (priority balancing)
     // filled by prepare_plan
     SlotLayout lay; KernelFn<BlockArgs> kern = nullptr; int per_cu = 1; int64_t want_slots = 0, n_slots = 0;
     int smem = 0, pf_off = -1; bool park_lds = true; uint64_t cells = 0, bytes = 0; float ms = 0;
@@ -704,10 +733,15 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
 static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
     const Variant V = P.variant;
     int rc;
+    if (!P.kern) return fail(SXG_E_INVALID, "no kernel class built for this geometry");
     if ((rc = R.arena.ensure((size_t)P.n_slots * P.lay.total))) return rc;
-    if ((rc = R.work.ensure(4 * P.work.size())) || (rc = R.queue.ensure(256))) return rc;
+    const size_t board_bytes = (size_t)PRIO_BOARD_CUS * PRIO_BOARD_SLOTS * 4;
+    if ((rc = R.work.ensure(4 * P.work.size())) || (rc = R.queue.ensure(256 + board_bytes)) || (rc = R.est.ensure(8 * P.work.size()))) return rc;
     HIPCHK(hipMemcpyAsync(R.work.p, P.work.data(), 4 * P.work.size(), hipMemcpyHostToDevice, R.stream));
-    HIPCHK(hipMemsetAsync(R.queue.p, 0, 4, R.stream));
+    P.est.resize(P.work.size());
+    for (size_t k = 0; k < P.work.size(); ++k) P.est[k] = (unsigned long long)std::max(h->meta[P.work[k]].cost, 1.0);
+    HIPCHK(hipMemcpyAsync(R.est.p, P.est.data(), 8 * P.est.size(), hipMemcpyHostToDevice, R.stream));
+    HIPCHK(hipMemsetAsync(R.queue.p, 0, 256 + board_bytes, R.stream));
     BlockArgs A;
     A.blk_off = h->d_blk_off.as<int32_t>(); A.seq_off = h->d_seq_off.as<int64_t>(); A.bases = h->d_bases.as<uint8_t>();
     A.weights = h->has_weights ? h->d_weights.as<uint32_t>() : nullptr;
@@ -723,10 +757,13 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
     A.want_consensus = h->want_consensus;
     A.park_in_lds = P.park_lds ? 1 : 0;
     A.pf_off = P.pf_off;
+    A.num_cu = std::max(h->num_cu, 1);
+    A.prio_board = getenv("SXG_POA_NO_BALANCE") ? nullptr : (uint32_t*)(R.queue.as<uint8_t>() + 256);
+    A.est = R.est.as<unsigned long long>();
     const bool dbg = getenv("SXG_POA_DEBUG") != nullptr;
     if (dbg)
         for (int64_t sl = 0; sl < P.n_slots; ++sl)
-            HIPCHK(hipMemsetAsync(R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr, 0, 256, R.stream));
+            HIPCHK(hipMemsetAsync(R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr, 0, 512, R.stream));
     HIPCHK(hipStreamWaitEvent(R.stream, h->ev0, 0));
     HIPCHK(hipEventRecord(R.e0, R.stream));
     hipLaunchKernelGGL(P.kern, dim3((unsigned)P.n_slots), dim3(V.T()), (size_t)P.smem, R.stream, A);
@@ -738,18 +775,53 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
 
 static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt) {
     const Variant V = P.variant;
-    unsigned long long acc[8] = {0};
+    unsigned long long acc[8] = {0}, smin = ~0ull, smax = 0;
     for (int64_t sl = 0; sl < P.n_slots; ++sl) {
         unsigned long long one[8];
         HIPCHK(hipMemcpy(one, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64, 64, hipMemcpyDeviceToHost));
         for (int k = 0; k < 8; ++k) acc[k] += one[k];
+        unsigned long long st = 0;
+        for (int k = 0; k < 6; ++k) st += one[k];
+        smin = std::min(smin, st); smax = std::max(smax, st);
     }
+    if (const char* path = getenv("SXG_POA_SLOT_CSV")) {  // per-slot placement and wall-clock span
+        if (FILE* f = fopen(path, "a")) {
+            for (int64_t sl = 0; sl < P.n_slots; ++sl) {
+                unsigned long long v[26];
+                HIPCHK(hipMemcpy(v, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64, sizeof(v), hipMemcpyDeviceToHost));
+                fprintf(f, "%lld,%llu,%llu", (long long)sl, v[8], v[9]);
+                for (int w = 0; w < V.NW && w < 16; ++w) fprintf(f, ",%llx", v[10 + w]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+#ifdef SXG_ROW_PROF
+    {
+        unsigned long long ra[12] = {0};
+        for (int64_t sl = 0; sl < P.n_slots; ++sl) {
+            unsigned long long one[12];
+            HIPCHK(hipMemcpy(one, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64 + 28 * 8, sizeof(one), hipMemcpyDeviceToHost));
+            for (int k = 0; k < 12; ++k) ra[k] += one[k];
+        }
+        double rt = 1e-9;
+        for (int k = 0; k < 12; ++k) rt += (double)ra[k];
+        static const char* seg[6] = {"setup", "pass1+scan", "wait B1", "combine+pass2", "wait B2", "stores"};
+        for (int kind = 0; kind < 2; ++kind) {
+            fprintf(stderr, "[sxg]   row profile (%s):", kind ? "other rows" : "register rows");
+            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f%%", seg[k], 100.0 * (double)ra[kind * 6 + k] / rt);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     double tot = 1e-9;
     for (int k = 0; k < 6; ++k) tot += (double)acc[k];
     size_t fr = 0, tt = 0;
     (void)hipMemGetInfo(&fr, &tt);
     fprintf(stderr, "[sxg] variant T=%d W=%d cvx=%d rowmode=%d attempt=%d work=%zu slots=%lld per_cu=%d smem=%d slot_bytes=%zu free=%zu ms=%.2f\n",
             V.T(), V.W, (int)P.cvx, V.RM, attempt, P.work.size(), (long long)P.n_slots, P.per_cu, P.smem, P.lay.total, fr, P.ms);
+    fprintf(stderr, "[sxg]   slot busy (of the longest slot): min %.1f%% mean %.1f%%\n", 100.0 * (double)smin / (double)std::max(smax, 1ull),
+            100.0 * tot / (double)P.n_slots / (double)std::max(smax, 1ull));
     fprintf(stderr, "[sxg]   slot time: other %.1f%% prep_rows %.1f%% dp_fill %.1f%% traceback %.1f%% add_alignment %.1f%% output %.1f%%\n",
             100 * acc[0] / tot, 100 * acc[1] / tot, 100 * acc[2] / tot, 100 * acc[3] / tot, 100 * acc[4] / tot, 100 * acc[5] / tot);
     return SXG_OK;
@@ -1169,6 +1241,7 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         A.pair_row = d_pr.as<int32_t>(); A.pair_pos = d_pp.as<int32_t>();
         A.park_in_lds = (V.RM == 2 || dp_park_in_lds(V.Lpad(), wb)) ? 1 : 0;
         A.pf_off = pf_off;
+        A.num_cu = std::max(h->num_cu, 1);
         hipLaunchKernelGGL(kern, dim3((unsigned)n_slots), dim3(V.T()), (size_t)smem, h->stream, A);
         HCK(hipGetLastError());
         HCK(hipStreamSynchronize(h->stream));
