@@ -115,6 +115,27 @@ template <> struct RowWord<false> {
 template <class Tp> __device__ __forceinline__ SXG_GLOBAL Tp* sxg_global(Tp* p) { return (SXG_GLOBAL Tp*)p; }
 template <class Tp> __device__ __forceinline__ SXG_GLOBAL const Tp* sxg_global(const Tp* p) { return (SXG_GLOBAL const Tp*)p; }
 
+// Wave-wide inclusive max-scan and one-lane shift on the DPP data path (gfx9 row_shr / row_bcast /
+// wave_shr): 6 + 1 full-rate VALU instructions per value instead of 6 ds_bpermute round trips
+// through the LDS crossbar plus their compare/select.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int sxg_dpp_max(const int v) {
+    return max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ int sxg_wave_incl_max(int v) {
+    v = sxg_dpp_max<0x111, 0xf>(v);  // row_shr:1
+    v = sxg_dpp_max<0x112, 0xf>(v);  // row_shr:2
+    v = sxg_dpp_max<0x114, 0xf>(v);  // row_shr:4
+    v = sxg_dpp_max<0x118, 0xf>(v);  // row_shr:8
+    v = sxg_dpp_max<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = sxg_dpp_max<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// lane l receives v of lane l-1; lane 0 receives `first`
+__device__ __forceinline__ int sxg_wave_shr1(const int v, const int first) {
+    return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+
 struct DpBuffers {
     uint8_t* tb;       // [(rows_cap+1) * Lpad] traceback bytes, row-major, row 0 unused
     uint32_t* steps;   // [step_cap * 3 * T] fold-step masks of multi-pred rows: for step s (=

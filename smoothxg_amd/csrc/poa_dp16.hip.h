@@ -345,11 +345,8 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         // y = a - s*W*e with strip index s (lo: t, hi: T + t); E entering strip s = max_{s'<s} y_{s'} + (s-1)*W*e
         int ya_lo = pk_lo(a) - t * We, ya_hi = pk_hi(a) - (T + t) * We;
         int yb_lo = CVX ? pk_lo(b) - t * Wc : NEG, yb_hi = CVX ? pk_hi(b) - (T + t) * Wc : NEG;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o0 = __shfl_up(ya_lo, d), o1 = __shfl_up(ya_hi, d), o2 = __shfl_up(yb_lo, d), o3 = __shfl_up(yb_hi, d);
-            if (lane >= d) { ya_lo = max(ya_lo, o0); ya_hi = max(ya_hi, o1); yb_lo = max(yb_lo, o2); yb_hi = max(yb_hi, o3); }
-        }
+        ya_lo = sxg_wave_incl_max(ya_lo); ya_hi = sxg_wave_incl_max(ya_hi);
+        if (CVX) { yb_lo = sxg_wave_incl_max(yb_lo); yb_hi = sxg_wave_incl_max(yb_hi); }
         if (lane == 63) { tot[wv] = ya_lo; tot[16 + wv] = ya_hi; tot[32 + wv] = yb_lo; tot[48 + wv] = yb_hi; }
         RP_MARK(1);  // pass 1 + in-wave scan
         SXG_ROW_BARRIER();  // B1
@@ -363,9 +360,8 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             }
             b1 = max(b1, lo_a); b3 = max(b3, lo_b);  // every lo strip precedes every hi strip
             ya_lo = max(ya_lo, b0); ya_hi = max(ya_hi, b1); yb_lo = max(yb_lo, b2); yb_hi = max(yb_hi, b3);
-            int e0 = __shfl_up(ya_lo, 1), e1 = __shfl_up(ya_hi, 1), e2 = __shfl_up(yb_lo, 1), e3 = __shfl_up(yb_hi, 1);
-            if (lane == 0) { e0 = b0; e1 = b1; e2 = b2; e3 = b3; }
-            ya_lo = e0; ya_hi = e1; yb_lo = e2; yb_hi = e3;
+            ya_lo = sxg_wave_shr1(ya_lo, b0); ya_hi = sxg_wave_shr1(ya_hi, b1);
+            yb_lo = sxg_wave_shr1(yb_lo, b2); yb_hi = sxg_wave_shr1(yb_hi, b3);
         }
         const int Ein_lo = (t == 0) ? NEGP : max(ya_lo + (t - 1) * We, NEGP);
         const int Ein_hi = max(ya_hi + (T + t - 1) * We, NEGP);
@@ -402,7 +398,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         const int xh = Hc[W - 1];
         const int xb = (int)(((exm >> W) & 0x00010001u) | (((qxm >> W) & 0x00010001u) << 1));  // bits 0,1 (lo strip), 16,17 (hi strip)
         exm &= ALL; qxm &= ALL;
-        int lh = __shfl_up(xh, 1), lb = __shfl_up(xb, 1);
+        int lh = sxg_wave_shr1(xh, 0), lb = sxg_wave_shr1(xb, 0);
         if (lane == 63) { xch[2 * wv] = xh; xch[2 * wv + 1] = xb; }
         RP_MARK(3);  // carry combine + pass 2
         SXG_ROW_BARRIER();  // B2
