@@ -13,8 +13,9 @@
 //  * the traceback plane stores those mask words (9 per lane per row) instead of one byte per
 //    cell; the 6-way source of H is resolved from "strictly beat the running maximum" bits in
 //    priority order Q > E > O > F > D at traceback time;
-//  * stored rows keep the register format: per lane and column one word of packed H and one of
-//    packed 8-bit H-F / H-O deltas;
+//  * rows carry OUTGOING gap candidates (max(H+g, F+e), max(H+q, O+c)) instead of F and O: computed
+//    once at the end of a row, consumed for free by a register successor and with an unpack by a
+//    stored one; stored rows hold packed H plus the two 8-bit distances to the candidates;
 //  * the end cell of a local alignment is found with a packed running maximum per row and a
 //    wave-uniform search of the column only in rows that improve it.
 // Applicability: every reachable score and intermediate fits +-15800 (host check); otherwise the
@@ -50,16 +51,24 @@ __device__ __forceinline__ int pk_hi(int v) { return v >> 16; }
 
 constexpr int LDS16_X = 64;  // ints of exchange scratch after the four [16] arrays of dp_fill
 
-// Row words of the packed ring: (Hpk, deltas) per lane and column.
-__device__ __forceinline__ u32x2 p16_pack_row(int h, int f, int o) {
-    const int df = pk_minu(pk_sub(h, f), 0x00ff00ff), dq = pk_minu(pk_sub(h, o), 0x00ff00ff);
-    return u32x2{(unsigned)h, (unsigned)(df | (dq << 8))};
+// Row words of the packed ring, per lane and column: packed H, and the distances H - oF, H - oO
+// to the row's OUTGOING gap candidates oF = max(H + g, F + e), oO = max(H + q, O + c) -- what every
+// successor takes as its F / O.  H >= F and g <= e < 0 bound the distances to [-e, -g] and [-c, -q]:
+// one byte each, never clamped (host check: |g|, |q| <= 120).  The EXTEND bit of a candidate is
+// implicit: extend won iff oF > H + g iff the distance is below -g.
+template <bool CVX>
+__device__ __forceinline__ u32x2 p16_pack_row(int h, int of, int oo) {
+    const int df = pk_sub(h, of);
+    return u32x2{(unsigned)h, (unsigned)(CVX ? (df | (pk_sub(h, oo) << 8)) : df)};
 }
-__device__ __forceinline__ void p16_unpack_row(u32x2 w, int& h, int& f, int& o) {
+__device__ __forceinline__ void p16_unpack_row(u32x2 w, int& h, int& of, int& oo) {
     h = (int)w.x;
-    f = pk_sub(h, (int)(w.y & 0x00ff00ffu));
-    o = pk_sub(h, (int)((w.y >> 8) & 0x00ff00ffu));
+    of = pk_sub(h, (int)(w.y & 0x00ff00ffu));
+    oo = pk_sub(h, (int)((w.y >> 8) & 0x00ff00ffu));
 }
+// bit k (lo) / 16+k (hi) <- bit 7 / 23 of v
+#define SXG_BIT7_TO(mask, v, k) \
+    mask |= ((((unsigned)(v)) >> ((k) <= 7 ? 7 - (k) : 0)) << ((k) > 7 ? (k) - 7 : 0)) & (0x00010001u << (k))
 
 template <int W, bool CVX, bool SW>
 __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R, const int N,
@@ -82,6 +91,8 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     const int sm = __builtin_amdgcn_readfirstlane(S.m), sn = __builtin_amdgcn_readfirstlane(S.n);
     const int MN2 = pk2(sn - sm, sn - sm), M2 = pk2(sm, sm), ONE2 = 0x00010001, NEG2 = pk2(NEGP, NEGP);
     const int We = W * e, Wc = W * c;
+    // distance + CB sets bit 7 of a byte iff the distance reached -g (-q): the candidate was an OPEN
+    const unsigned CB = ((unsigned)(128 + g) & 0xffu) * 0x00010001u | ((unsigned)(128 + q) & 0xffu) * 0x01000100u;
     int* tot = lds;            // [4][16]: a_lo, a_hi, b_lo, b_hi inclusive totals per wave
     int* xch = lds + 64;       // [16][2]: (Hc[W-1] packed, ext bits) of every wave's last lane
 
@@ -126,7 +137,9 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = max(a > b ? a : b, NEGP); }
             h2[hf] = h;
         }
-        Hp[k] = pk2(h2[0], h2[1]); Fp[k] = NEG2; Op[k] = NEG2;
+        Hp[k] = pk2(h2[0], h2[1]);
+        Fp[k] = pk_add(Hp[k], G2);                  // nothing to extend in row 0: both candidates open
+        Op[k] = CVX ? pk_add(Hp[k], Q2) : NEG2;
     }
     {
         int h2[2];
@@ -141,13 +154,13 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     }
     {
 #pragma unroll
-        for (int k = 0; k < W; ++k) (g_row0 + k * T)[ut] = p16_pack_row(Hp[k], Fp[k], Op[k]);
+        for (int k = 0; k < W; ++k) (g_row0 + k * T)[ut] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
     }
     int best_lo = SW ? 0 : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;
     const int kL_lo = L - j0, kL_hi = L - TW - j0;  // strip-local index of the end column L
 
-    unsigned fxm = 0, oxm = 0;
-    int prev_p0 = -2;
+    unsigned fxm = 0, oxm = 0;  // EXTEND bits that go with Fp / Op
+    bool next_sib = false;      // decided at the end of a row for its successor
 #ifdef SXG_ROW_PROF
     unsigned long long racc[12] = {0};  // [row kind: 0 = register fast path, 1 = other][segment]
 #define RP_MARK(seg) do { const unsigned long long tn_ = clock64(); racc[rk_ * 6 + (seg)] += tn_ - rt_; rt_ = tn_; } while (0)
@@ -185,25 +198,10 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         unsigned long long rt_ = clock64();
 #endif
         int Hc[W];
-        // sibling rows (alternative alleles): the same single predecessor as the row just done, so
-        // F, O and their ext bits carry over unchanged and only the diagonal H is fetched
-        const bool sib = np <= 1 && p0 == prev_p0 && p0 != i - 1;
-        if (!sib) { fxm = 0; oxm = 0; }
-        prev_p0 = np <= 1 ? p0 : -2;
-
-#define P16_INIT(k, hs, fs, os, hprev)                        \
-    do {                                                      \
-        const int c1_ = pk_add((hs), G2), c2_ = pk_add((fs), E2); \
-        Hc[k] = (hprev);                                      \
-        Fp[k] = pk_max(c1_, c2_);                             \
-        SXG_SIGN_TO(fxm, pk_sub(c1_, c2_), k);                \
-        if (CVX) {                                            \
-            const int d1_ = pk_add((hs), Q2), d2_ = pk_add((os), C2); \
-            Op[k] = pk_max(d1_, d2_);                         \
-            SXG_SIGN_TO(oxm, pk_sub(d1_, d2_), k);            \
-        }                                                     \
-        SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm)); \
-    } while (0)
+        // Fp/Op/fxm/oxm arrive holding the previous row's OUTGOING candidates -- or, when the previous
+        // row announced this one as its sibling (an alternative allele: the same single predecessor),
+        // that row's own F/O, which are this row's too.
+        const bool sib = next_sib;
 // the column left of my strips in a stored row: lane t-1's last column; lane 0: lo = none,
 // hi = last column of the lo half (lane T-1)
 #define P16_LOAD_LEFT(sp_base, hl)                                                    \
@@ -211,20 +209,18 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         if (t > 0) hl = (int)((sp_base) + (W - 1) * T - 1)[ut].x;                     \
         else hl = pk2(NEGP, pk_lo((int)(sp_base)[TW - 1].x));                         \
     } while (0)
-
 // words of the stored row of predecessor p_ (slot sl_) and the column to their left
 #define P16_FETCH(p_, sl_, wr_, hl_)                                                                        \
     do {                                                                                                    \
-        {                                                                                                   \
-            SXG_GLOBAL const u32x2* base_ = ((p_) == 0) ? g_row0 : g_pool + (size_t)(sl_) * TW;            \
-            _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = (base_ + k * T)[ut];                     \
-            P16_LOAD_LEFT(base_, hl_);                                                                      \
-        }                                                                                                   \
+        SXG_GLOBAL const u32x2* base_ = ((p_) == 0) ? g_row0 : g_pool + (size_t)(sl_) * TW;                \
+        _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = (base_ + k * T)[ut];                         \
+        P16_LOAD_LEFT(base_, hl_);                                                                          \
     } while (0)
 
         if (np <= 1 && p0 == i - 1) {
+            // register predecessor: its outgoing candidates ARE this row's F and O
 #pragma unroll
-            for (int k = 0; k < W; ++k) P16_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
+            for (int k = 0; k < W; ++k) Hc[k] = k ? Hp[k - 1] : Hleft;
         } else if (sib) {
             u32x2 wr[W];
             int hl;
@@ -237,13 +233,15 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             const bool park = np >= 3;
             if (park) {
 #pragma unroll
-                for (int k = 0; k < W; ++k) lrow[j0 + k] = p16_pack_row(Hp[k], Fp[k], Op[k]);
+                for (int k = 0; k < W; ++k) lrow[j0 + k] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
             }
             const int ge = reg1 ? 1 : 0;
             const int GE2 = ge ? ONE2 : 0;
+            unsigned nfx = 0, nox = 0;  // OPEN (= not EXTEND) bits while the predecessors are folded
             if ((reg0 || reg1) && !park) {
 #pragma unroll
-                for (int k = 0; k < W; ++k) P16_INIT(k, Hp[k], Fp[k], Op[k], (k ? Hp[k - 1] : Hleft));
+                for (int k = 0; k < W; ++k) Hc[k] = k ? Hp[k - 1] : Hleft;
+                nfx = ~fxm; nox = ~oxm;
             } else {
                 u32x2 wr[W];
                 int hl = Hleft;
@@ -253,11 +251,14 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                 } else P16_FETCH(p0, s0, wr, hl);
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    int hs, fs, os;
-                    p16_unpack_row(wr[k], hs, fs, os);
-                    P16_INIT(k, hs, fs, os, hl);
+                    int hs;
+                    p16_unpack_row(wr[k], hs, Fp[k], Op[k]);
+                    const unsigned tn = wr[k].y + CB;
+                    SXG_BIT7_TO(nfx, tn, k);
+                    if (CVX) SXG_SIGN_TO(nox, tn, k);
+                    Hc[k] = hl;
                     hl = hs;
-                    SXG_PIN("+v"(hl));
+                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(nfx), "+v"(nox), "+v"(hl));
                 }
             }
             for (int x = 1; x < np; ++x) {
@@ -281,22 +282,21 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                     int hs, fs, os;
                     p16_unpack_row(wr[k], hs, fs, os);
                     const unsigned bit = 0x00010001u << k;
+                    const unsigned tn = wr[k].y + CB;
                     {
-                        const int c1 = pk_add(hs, G2), c2 = pk_add(fs, E2);
-                        const int cb = pk_max(c1, c2);
-                        const unsigned x1 = (((unsigned)pk_sub(c1, c2)) >> (15 - k)) & bit;
-                        const unsigned rf = (((unsigned)pk_sub(pk_sub(Fp[k], cb), GE2)) >> (15 - k)) & bit;
-                        Fp[k] = pk_max(Fp[k], cb);
-                        fxm = (fxm & ~rf) | (rf & x1);
+                        unsigned n1 = 0;
+                        SXG_BIT7_TO(n1, tn, k);
+                        const unsigned rf = (((unsigned)pk_sub(pk_sub(Fp[k], fs), GE2)) >> (15 - k)) & bit;
+                        Fp[k] = pk_max(Fp[k], fs);
+                        nfx = (nfx & ~rf) | (rf & n1);
                         fmk ^= rf;
                     }
                     if (CVX) {
-                        const int d1 = pk_add(hs, Q2), d2 = pk_add(os, C2);
-                        const int db = pk_max(d1, d2);
-                        const unsigned x2 = (((unsigned)pk_sub(d1, d2)) >> (15 - k)) & bit;
-                        const unsigned ro = (((unsigned)pk_sub(pk_sub(Op[k], db), GE2)) >> (15 - k)) & bit;
-                        Op[k] = pk_max(Op[k], db);
-                        oxm = (oxm & ~ro) | (ro & x2);
+                        unsigned n2 = 0;
+                        SXG_SIGN_TO(n2, tn, k);
+                        const unsigned ro = (((unsigned)pk_sub(pk_sub(Op[k], os), GE2)) >> (15 - k)) & bit;
+                        Op[k] = pk_max(Op[k], os);
+                        nox = (nox & ~ro) | (ro & n2);
                         omk ^= ro;
                     }
                     {
@@ -305,13 +305,14 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                         dm ^= rd;
                     }
                     hl = hs;
-                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm), "+v"(dm), "+v"(fmk), "+v"(omk), "+v"(hl));
+                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(nfx), "+v"(nox), "+v"(dm), "+v"(fmk), "+v"(omk), "+v"(hl));
                 }
                 SXG_GLOBAL uint32_t* st = g_steps + ((size_t)(tx + x - 1) * 3) * T;
                 st[ut] = dm; (st + T)[ut] = fmk; (st + 2 * T)[ut] = omk;
             }
+            fxm = ~nfx & ALL;
+            oxm = CVX ? ~nox & ALL : 0u;
         }
-#undef P16_INIT
 #undef P16_FETCH
 #undef P16_LOAD_LEFT
         if (!CVX) {
@@ -441,10 +442,42 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             (dst + PM_GTE * T)[ut] = gte; (dst + PM_GTQ * T)[ut] = gtq; (dst + PM_FX * T)[ut] = fxm;
             (dst + PM_OX * T)[ut] = oxm; (dst + PM_EX * T)[ut] = exm; (dst + PM_QX * T)[ut] = qxm;
         }
-        if (flags & ROW_STORE) {
-            SXG_GLOBAL u32x2* dst = g_pool + (size_t)myslot * TW;
+        // ---- outgoing candidates (see p16_pack_row).  A sibling successor -- single predecessor, the
+        // same as mine, not me -- wants my own F/O left in place instead.
+        next_sib = false;
+        if (np <= 1 && i < N && (i & (META_CHUNK - 1)) != 0) {
+            const i32x4 n0 = lmeta[2 * (i & (META_CHUNK - 1))];
+            const int nnp = __builtin_amdgcn_readfirstlane(n0.y) & 0xffff, np0 = __builtin_amdgcn_readfirstlane(n0.z);
+            next_sib = nnp <= 1 && np0 == p0 && np0 != i;
+        }
+        SXG_GLOBAL u32x2* const rdst = g_pool + (size_t)myslot * TW;
+        if (next_sib) {
+            if (flags & ROW_STORE) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) (dst + k * T)[ut] = p16_pack_row(Hc[k], Fp[k], Op[k]);
+                for (int k = 0; k < W; ++k) {
+                    const int tf = pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2));
+                    const int to = CVX ? pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2)) : NEG2;
+                    (rdst + k * T)[ut] = p16_pack_row<CVX>(Hc[k], tf, to);
+                }
+            }
+        } else {
+            fxm = 0; oxm = 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const int c1 = pk_add(Hc[k], G2), c2 = pk_add(Fp[k], E2);
+                Fp[k] = pk_max(c1, c2);
+                SXG_SIGN_TO(fxm, pk_sub(c1, c2), k);
+                if (CVX) {
+                    const int d1 = pk_add(Hc[k], Q2), d2 = pk_add(Op[k], C2);
+                    Op[k] = pk_max(d1, d2);
+                    SXG_SIGN_TO(oxm, pk_sub(d1, d2), k);
+                }
+                SXG_PIN("+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm));
+            }
+            if (flags & ROW_STORE) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) (rdst + k * T)[ut] = p16_pack_row<CVX>(Hc[k], Fp[k], Op[k]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < W; ++k) Hp[k] = Hc[k];

@@ -465,6 +465,8 @@ static bool p16_safe(const Scoring& S, int maxlen, int rows_max) {
         const long ext = std::max(std::max(std::abs(S.e), std::abs(S.c)), 1);
         lo = std::abs(S.g) + std::abs(S.q) + ((long)rows_max + maxlen) * ext + (long)std::abs(S.n) * maxlen;
     }
+    // stored rows keep H - max(H+g, F+e) and H - max(H+q, O+c) in one byte each
+    if (std::abs(S.g) > 120 || std::abs(S.q) > 120) return false;
     return hi < 15800 && lo < 15800;
 }
 static int row_mode(const Scoring& S, int maxlen, int rows_max) {
