@@ -118,13 +118,13 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     // busier than the VALU).  Every access is "uniform pointer"[ut]: scalar base, one loop-invariant
     // lane offset register, no per-access address arithmetic.
     const unsigned ut = (unsigned)t;
-    SXG_GLOBAL u32x2* const g_row0 = sxg_global((u32x2*)B.row0);
-    SXG_GLOBAL u32x2* const g_pool = sxg_global((u32x2*)B.pool);
-    SXG_GLOBAL uint32_t* const g_tb = sxg_global((uint32_t*)B.tb);
-    SXG_GLOBAL uint32_t* const g_steps = sxg_global(B.steps);
-    SXG_GLOBAL const int32_t* const g_meta = sxg_global((const int32_t*)R.meta);
-    SXG_GLOBAL const int32_t* const g_preds = sxg_global((const int32_t*)R.preds);
-    SXG_GLOBAL const int32_t* const g_slot = sxg_global((const int32_t*)R.slot);
+    SXG_GLOBAL u32x2* const g_row0 = sxg_uniform(sxg_global((u32x2*)B.row0));
+    SXG_GLOBAL u32x2* const g_pool = sxg_uniform(sxg_global((u32x2*)B.pool));
+    SXG_GLOBAL uint32_t* const g_tb = sxg_uniform(sxg_global((uint32_t*)B.tb));
+    SXG_GLOBAL uint32_t* const g_steps = sxg_uniform(sxg_global(B.steps));
+    SXG_GLOBAL const int32_t* const g_meta = sxg_uniform(sxg_global((const int32_t*)R.meta));
+    SXG_GLOBAL const int32_t* const g_preds = sxg_uniform(sxg_global((const int32_t*)R.preds));
+    SXG_GLOBAL const int32_t* const g_slot = sxg_uniform(sxg_global((const int32_t*)R.slot));
     int Hp[W], Fp[W], Op[W], Hleft;
     // virtual row 0
 #pragma unroll
@@ -162,8 +162,8 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     unsigned fxm = 0, oxm = 0;  // EXTEND bits that go with Fp / Op
     bool next_sib = false;      // decided at the end of a row for its successor
 #ifdef SXG_ROW_PROF
-    unsigned long long racc[12] = {0};  // [row kind: 0 = register fast path, 1 = other][segment]
-#define RP_MARK(seg) do { const unsigned long long tn_ = clock64(); racc[rk_ * 6 + (seg)] += tn_ - rt_; rt_ = tn_; } while (0)
+    unsigned long long racc[8] = {0};  // per row segment; scalar registers (s_memtime deltas)
+#define RP_MARK(seg) do { const unsigned long long tn_ = __builtin_readcyclecounter(); racc[seg] += tn_ - rt_; rt_ = tn_; } while (0)
 #else
 #define RP_MARK(seg) do { } while (0)
 #endif
@@ -194,8 +194,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         for (int k2 = 0; k2 < NL; ++k2) SXG_PIN("+v"(let[k2]));
 
 #ifdef SXG_ROW_PROF
-        const int rk_ = (np <= 1 && p0 == i - 1) ? 0 : 1;
-        unsigned long long rt_ = clock64();
+        unsigned long long rt_ = __builtin_readcyclecounter();
 #endif
         int Hc[W];
         // Fp/Op/fxm/oxm arrive holding the previous row's OUTGOING candidates -- or, when the previous
@@ -435,6 +434,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             }
         }
 
+        RP_MARK(5);  // hand-over + end-cell bookkeeping
         // ---- stores
         {
             SXG_GLOBAL uint32_t* dst = g_tb + (size_t)i * P16_TB_WORDS * T;  // [row][word][lane]
@@ -442,8 +442,11 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             (dst + PM_GTE * T)[ut] = gte; (dst + PM_GTQ * T)[ut] = gtq; (dst + PM_FX * T)[ut] = fxm;
             (dst + PM_OX * T)[ut] = oxm; (dst + PM_EX * T)[ut] = exm; (dst + PM_QX * T)[ut] = qxm;
         }
+        RP_MARK(6);  // mask-plane stores
         // ---- outgoing candidates (see p16_pack_row).  A sibling successor -- single predecessor, the
-        // same as mine, not me -- wants my own F/O left in place instead.
+        // same as mine, not me -- wants my own F/O left in place instead.  (Requesting the next row's
+        // stored predecessor from here was tried: with the kernel at its 128-VGPR budget any spill
+        // reload behind the request is an in-order vmcnt wait on it, and the row got slower.)
         next_sib = false;
         if (np <= 1 && i < N && (i & (META_CHUNK - 1)) != 0) {
             const i32x4 n0 = lmeta[2 * (i & (META_CHUNK - 1))];
@@ -482,11 +485,11 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 #pragma unroll
         for (int k = 0; k < W; ++k) Hp[k] = Hc[k];
         Hleft = lh;
-        RP_MARK(5);  // end-cell bookkeeping + stores
+        RP_MARK(7);  // outgoing candidates + row store
     }
 #ifdef SXG_ROW_PROF
     if (t == 0 && B.row_prof)
-        for (int k = 0; k < 12; ++k) B.row_prof[k] += racc[k];
+        for (int k = 0; k < 8; ++k) B.row_prof[k] += racc[k];
 #endif
 #undef RP_MARK
 

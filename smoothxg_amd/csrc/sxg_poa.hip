@@ -800,20 +800,18 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
     }
 #ifdef SXG_ROW_PROF
     {
-        unsigned long long ra[12] = {0};
+        unsigned long long ra[8] = {0};
         for (int64_t sl = 0; sl < P.n_slots; ++sl) {
-            unsigned long long one[12];
+            unsigned long long one[8];
             HIPCHK(hipMemcpy(one, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64 + 28 * 8, sizeof(one), hipMemcpyDeviceToHost));
-            for (int k = 0; k < 12; ++k) ra[k] += one[k];
+            for (int k = 0; k < 8; ++k) ra[k] += one[k];
         }
         double rt = 1e-9;
-        for (int k = 0; k < 12; ++k) rt += (double)ra[k];
-        static const char* seg[6] = {"setup", "pass1+scan", "wait B1", "combine+pass2", "wait B2", "stores"};
-        for (int kind = 0; kind < 2; ++kind) {
-            fprintf(stderr, "[sxg]   row profile (%s):", kind ? "other rows" : "register rows");
-            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f%%", seg[k], 100.0 * (double)ra[kind * 6 + k] / rt);
-            fprintf(stderr, "\n");
-        }
+        for (int k = 0; k < 8; ++k) rt += (double)ra[k];
+        static const char* seg[8] = {"setup", "pass1+scan", "wait B1", "combine+pass2", "wait B2", "hand-over+end cell", "mask stores", "outgoing+row store"};
+        fprintf(stderr, "[sxg]   row profile:");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", seg[k], 100.0 * (double)ra[k] / rt);
+        fprintf(stderr, "\n");
     }
 #endif
     double tot = 1e-9;
