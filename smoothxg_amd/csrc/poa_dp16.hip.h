@@ -328,23 +328,34 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             // letters (lo_k, hi_k) of column k as a packed pair; 0 where they equal the node letter
             const unsigned x4 = let[k >> 1] ^ CODE4;
             const int lp = (int)__builtin_amdgcn_perm(0u, x4, (k & 1) ? 0x0c030c02u : 0x0c010c00u);
-            const int nm = pk_minu(lp, ONE2);              // 0 = match, 1 = mismatch
-            int h = pk_add(Hc[k], pk_mad(nm, MN2, M2));    // diagonal + (match ? m : n)
+            // 0 = match, 1 = mismatch.  Opaque to the optimiser on purpose: knowing the 0/1 range it
+            // rewrites the multiply-add below into two compares, two selects and a byte merge.
+            int nm;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(nm) : "v"(lp), "v"(ONE2));
+            int h = pk_mad(nm, MN2, pk_add(Hc[k], M2));    // diagonal + (match ? m : n)
             SXG_SIGN_TO(gtf, pk_sub(h, Fp[k]), k);
             h = pk_max(h, Fp[k]);
             if (CVX) { SXG_SIGN_TO(gto, pk_sub(h, Op[k]), k); h = pk_max(h, Op[k]); }
             Hc[k] = h;
-            // a = max_k (max(h_k, 0 if SW) + g + (W-1-k) e): the open+extend cost to the strip's end is
-            // a per-column scalar constant, and the clamp contributes only its best term (k = W-1)
-            a = pk_max(a, pk_add(h, pk2s(g + (W - 1 - k) * e)));
-            if (CVX) b = pk_max(b, pk_add(h, pk2s(q + (W - 1 - k) * c)));
+            // a' = max_k (h_k + (W-1-k) e) as a running "extend, or restart here"; the opening cost
+            // and the local-alignment clamp (whose best term is k = W-1) are applied once per row below
+            a = pk_max(pk_add(a, E2), h);
+            if (CVX) b = pk_max(pk_add(b, C2), h);
             SXG_PIN("+v"(Hc[k]), "+v"(gtf), "+v"(gto), "+v"(a), "+v"(b));
         }
-        if (SW) { a = pk_max(a, G2); if (CVX) b = pk_max(b, Q2); }
+        if (SW) { a = pk_max(a, 0); if (CVX) b = pk_max(b, 0); }
+        a = pk_add(a, G2);
+        if (CVX) b = pk_add(b, Q2);
         // ---- carries (32-bit).  Strip order: lo strips of lanes 0..T-1, then hi strips.
         // y = a - s*W*e with strip index s (lo: t, hi: T + t); E entering strip s = max_{s'<s} y_{s'} + (s-1)*W*e
-        int ya_lo = pk_lo(a) - t * We, ya_hi = pk_hi(a) - (T + t) * We;
-        int yb_lo = CVX ? pk_lo(b) - t * Wc : NEG, yb_hi = CVX ? pk_hi(b) - (T + t) * Wc : NEG;
+        // (the lane's offsets are rebuilt from an opaque copy of t every row: hoisted out of the loop
+        // they are six more loop-invariant VGPRs, which the allocator spills and reloads per row --
+        // and a scratch reload is an in-order vmcnt wait behind every store still in flight)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const int tWe = __mul24(tt, We), tWc = __mul24(tt, Wc);
+        int ya_lo = pk_lo(a) - tWe, ya_hi = pk_hi(a) - tWe - T * We;
+        int yb_lo = CVX ? pk_lo(b) - tWc : NEG, yb_hi = CVX ? pk_hi(b) - tWc - T * Wc : NEG;
         ya_lo = sxg_wave_incl_max(ya_lo); ya_hi = sxg_wave_incl_max(ya_hi);
         if (CVX) { yb_lo = sxg_wave_incl_max(yb_lo); yb_hi = sxg_wave_incl_max(yb_hi); }
         if (lane == 63) { tot[wv] = ya_lo; tot[16 + wv] = ya_hi; tot[32 + wv] = yb_lo; tot[48 + wv] = yb_hi; }
@@ -363,10 +374,10 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             ya_lo = sxg_wave_shr1(ya_lo, b0); ya_hi = sxg_wave_shr1(ya_hi, b1);
             yb_lo = sxg_wave_shr1(yb_lo, b2); yb_hi = sxg_wave_shr1(yb_hi, b3);
         }
-        const int Ein_lo = (t == 0) ? NEGP : max(ya_lo + (t - 1) * We, NEGP);
-        const int Ein_hi = max(ya_hi + (T + t - 1) * We, NEGP);
-        const int Qin_lo = (t == 0 || !CVX) ? NEGP : max(yb_lo + (t - 1) * Wc, NEGP);
-        const int Qin_hi = !CVX ? NEGP : max(yb_hi + (T + t - 1) * Wc, NEGP);
+        const int Ein_lo = (tt == 0) ? NEGP : max(ya_lo + tWe - We, NEGP);
+        const int Ein_hi = max(ya_hi + tWe + (T - 1) * We, NEGP);
+        const int Qin_lo = (tt == 0 || !CVX) ? NEGP : max(yb_lo + tWc - Wc, NEGP);
+        const int Qin_hi = !CVX ? NEGP : max(yb_hi + tWc + (T - 1) * Wc, NEGP);
         int E = pk2(Ein_lo, Ein_hi), Q = pk2(Qin_lo, Qin_hi);
 
         // ---- pass 2: final H and the remaining decision bits

@@ -145,6 +145,9 @@ struct BlockArgs {
 // RM = row mode: 0 = 32-bit sweep with int16 row words, 1 = 32-bit sweep with int32 row words,
 // 2 = packed-int16 sweep (poa_dp16.hip.h; two strips per lane, W <= 12).
 __host__ __device__ constexpr int sxg_min_waves(int TMAX, int W, int RM) {
+#ifdef SXG_DEV_WAVES
+    return SXG_DEV_WAVES;
+#endif
     return TMAX > 512 ? 4 : (RM == 2 ? (W <= 8 || TMAX == 256 ? 4 : 3) : (W <= 12 ? 4 : 3));
 }
 
