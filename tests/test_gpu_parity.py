@@ -191,3 +191,46 @@ def test_mixed_depth_and_length_batch_properties(engine, oracle):
     seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[b], blk_off[b + 1])]
     g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
     assert_block_equal(res[b], g, sc, cells, label="mixed-cheapest")
+
+
+def _packed_geometry(length):
+    """The (threads, columns per lane) the engine's chooser gives a packed-sweep block whose longest
+    sequence has `length` bases: fewest padded columns, wider strip on ties (sxg_poa.hip)."""
+    best = None
+    for W in (12, 11, 10, 9, 8):
+        for NW in (1, 2, 3, 4, 8, 12, 16):
+            cols = 128 * NW * W
+            if cols < length + 1:
+                continue
+            if W > 8 and NW > 8:
+                continue
+            if best is None or cols < best[0]:
+                best = (cols, 64 * NW, 2 * W)
+            break
+    return best
+
+
+def test_every_packed_strip_width_and_wave_count(engine, oracle):
+    """One block per packed geometry: strip widths 8..12 at 1, 2, 3, 4 and 8 waves; the engine's
+    stats confirm the geometry that ran, the oracle confirms the result."""
+    rng = np.random.default_rng(41)
+    wanted = {}
+    for W in (8, 9, 10, 11, 12):
+        for NW in (1, 2, 3, 4, 8):
+            L = 128 * NW * W - 3
+            cols, T, cpl = _packed_geometry(L)
+            if (T, cpl) == (64 * NW, 2 * W):
+                wanted[(T, cpl)] = L
+    assert {c for (_, c) in wanted} == {16, 18, 20, 22, 24}
+    assert {t for (t, _) in wanted} >= {64, 128, 192, 256, 512}
+    for (T, cpl), L in sorted(wanted.items()):
+        seqs = random_block(rng, 3, L, div=0.02)
+        top = max(len(s) for s in seqs)
+        if _packed_geometry(top)[1:] != (T, cpl):      # indels moved the longest sequence out of the class
+            seqs = [s[:L] for s in seqs]
+        res = engine.run_blocks([seqs], gparams("convex_default", 0))
+        st = engine.stats()
+        assert st["dom_row_mode"] == 2
+        assert (st["dom_threads"], st["dom_cols_per_lane"]) == _packed_geometry(max(len(s) for s in seqs))[1:]
+        g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
+        assert_block_equal(res[0], g, sc, cells, label=f"packed T={T} cols/lane={cpl} L={L}")
