@@ -4,6 +4,7 @@
  *   A2  append_to_sequence (flank padding)            src/smooth.cpp:75-126
  *   A3  sequence collection, orientation, XXH64 dedup src/smooth.cpp:676-743
  *   A4  padding size                                  src/smooth.cpp:1946-1970
+ *   A14 adaptive POA scores per block (-a)            src/smooth.cpp:1972-2069
  *   A9  build_odgi_SPOA (POA graph -> block graph)    src/smooth.cpp:2576-2654
  *   A10 unchop + topological order + re-copy          src/smooth.cpp:935-1010
  *   8f-1 lacing of the block graphs + GFA writer      src/main.cpp:599-1061
@@ -42,6 +43,8 @@ typedef struct sxg_smooth_params {
     uint64_t max_block_depth_for_padding_more;        /* -Y, default 1000 */
     int32_t add_consensus;                            /* embed Consensus_<block> paths (last iteration) */
     const char *consensus_base_name;                  /* default "Consensus_" */
+    int32_t adaptive_poa_params;                      /* -a: per-block scores from the estimated identity, default 0 */
+    int32_t kmer_size;                                /* -k: k-mer size of the identity estimate, default 17 */
 } sxg_smooth_params;
 
 void sxg_smooth_default_params(sxg_smooth_params *p);
@@ -70,6 +73,20 @@ int64_t sxg_blockset_size(const sxg_blockset *b);
  *   "dup\t<rank>\t<path_range index>\t<is_rev 0|1>\t<name>"  every original range            */
 int sxg_block_collect_text(const sxg_graph *g, const sxg_blockset *b, int64_t block_id,
                            const sxg_smooth_params *p, char **out_text);
+
+/* A14, the score tiers of src/smooth.cpp:2032-2069: CLI-convention scores (m,n,g,e,q,c) for a block
+ * whose identity threshold is `est_identity_threshold`; below 0.90 the set/default scores are kept. */
+void sxg_adaptive_poa_scores(float est_identity_threshold, const int32_t set_scores[6], int32_t out_scores[6]);
+
+/* A14, the identity threshold of one block (src/smooth.cpp:1980-2030): the block's path-range
+ * sequences of at least 8*k bases, all-vs-all identity = 1 - mash distance, the 30 % percentile of
+ * the sorted identities, floored at 0.7.  *n_used = sequences that took part; the threshold is only
+ * defined (and only applied) when *n_used > 1.
+ * The reference hashes and compares with rkmh/mkmh, an un-vendored dependency absent from the
+ * snapshot; by decree the Jaccard index is taken EXACTLY over the sets of
+ * canonical k-mers (no sketch), distance = -ln(2J/(1+J))/k, 1 when J = 0.  k <= 32. */
+int sxg_block_identity_threshold(const sxg_graph *g, const sxg_blockset *b, int64_t block_id, int32_t kmer_size,
+                                 float *est_identity_threshold, int32_t *n_used);
 
 /* A9+A10 for one block given its POA result: the normalised block graph as GFA text. */
 int sxg_block_graph_gfa(const sxg_graph *g, const sxg_blockset *b, int64_t block_id,

@@ -17,6 +17,8 @@ oracle/poa_oracle.c through oracle_py.
 import heapq
 import struct
 
+import math
+
 import numpy as np
 import xxhash  # independent XXH64 (the C restatements are pinned against it in tests)
 
@@ -365,7 +367,65 @@ def build_block_graph(c, node_code, seq_paths, cons, consensus_name):
     return G
 
 
-def smooth(g, blocks, add_consensus=False, consensus_base="Consensus_", fraction=0.001, max_depth=1000, **scores):
+# ---- A14: adaptive POA scores (src/smooth.cpp:1972-2069).  rkmh/mkmh are absent from the snapshot:
+# the identity estimate is by decree the exact canonical-k-mer Jaccard turned into a mash distance.
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def canonical_kmers(s, k):
+    out, s = set(), s.upper()
+    for i in range(len(s) - k + 1):
+        w = s[i:i + k]
+        if any(ch not in _COMP for ch in w):
+            continue
+        rc = "".join(_COMP[ch] for ch in reversed(w))
+        out.add(min(w, rc))   # A<C<G<T: the same order as the 2-bit packing of the C++ side
+    return out
+
+
+def mash_identity(a, b, k):
+    inter = len(a & b)
+    uni = len(a) + len(b) - inter
+    dist = 1.0
+    if inter > 0 and uni > 0:
+        J = inter / uni
+        dist = -math.log(2.0 * J / (1.0 + J)) / k
+    return np.float32(1.0 - dist)
+
+
+def identity_threshold(g, ranges, k=17):
+    """(threshold as float32 or None, sequences used): src/smooth.cpp:1985-2026."""
+    km = []
+    for (p, b, e, _) in ranges:
+        seq = "".join(g.sequence(h) for h in g.steps[p][b:e])
+        if len(seq) >= 8 * k:
+            km.append(canonical_kmers(seq, k))
+    if len(km) <= 1:
+        return None, len(km)
+    est = sorted(mash_identity(km[i], km[j], k) for i in range(len(km)) for j in range(i + 1, len(km)))
+    return max(np.float32(0.7), est[int((len(est) - 1) * 0.30)]), len(km)
+
+
+def adaptive_scores(thr, set_scores=(1, 4, 6, 2, 26, 1)):
+    """src/smooth.cpp:2032-2069."""
+    for cut, tier in ((0.99, (1, 19, 39, 3, 81, 1)), (0.98, (1, 13, 31, 3, 51, 1)), (0.97, (1, 9, 16, 2, 41, 1)),
+                      (0.95, (1, 7, 11, 2, 33, 1)), (0.90, (1, 4, 6, 2, 26, 1))):
+        if float(thr) >= cut:
+            return tier
+    return tuple(set_scores)
+
+
+def block_scores(g, ranges, adaptive, k, max_depth, m=1, n=4, g_=6, e=2, q=26, cc=1):
+    sc = (m, n, g_, e, q, cc)
+    if adaptive and 1 < len(ranges) <= max_depth:
+        thr, used = identity_threshold(g, ranges, k)
+        if used > 1:
+            sc = adaptive_scores(thr, sc)
+    return sc
+
+
+def smooth(g, blocks, add_consensus=False, consensus_base="Consensus_", fraction=0.001, max_depth=1000, adaptive=False,
+           kmer_size=17, **scores):
     """One smoothing iteration (src/main.cpp:599-1061 around the per-block POA) -> GFA text."""
     cols = [collect(g, b, fraction, max_depth) for b in blocks]
     graphs, mapping = [], []
@@ -373,7 +433,14 @@ def smooth(g, blocks, add_consensus=False, consensus_base="Consensus_", fraction
         if not c.seqs:
             graphs.append(OGraph())
             continue
-        code, paths, cons = poa(c, **scores)
+        if adaptive:
+            local = scores.get("local", True)
+            base = {kk: vv for kk, vv in scores.items() if kk != "local"}
+            m_, n_, g__, e_, q_, c_ = block_scores(g, blocks[k], True, kmer_size, max_depth, base.get("m", 1), base.get("n", 4),
+                                                   base.get("g", 6), base.get("e", 2), base.get("q", 26), base.get("cc", 1))
+            code, paths, cons = poa(c, m_, n_, g__, e_, q_, c_, local)
+        else:
+            code, paths, cons = poa(c, **scores)
         G = build_block_graph(c, code, paths, cons, (consensus_base + str(k)) if add_consensus else "")
         graphs.append(G)
         if not G.seq:

@@ -19,6 +19,7 @@
 #include <map>
 #include <queue>
 #include <set>
+#include <cmath>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -378,6 +379,82 @@ sxg_poa_params poa_params(const sxg_smooth_params& p) {  // src/smooth.cpp:2098-
     q.mode = p.local_alignment ? SXG_MODE_LOCAL : SXG_MODE_GLOBAL; q.reserved = 0;
     return q;
 }
+// ---------------------------------------------------------------------------------------------
+// A14: src/smooth.cpp:1972-2069.  The estimator is restated by decree (see include/sxg_smooth.h).
+std::vector<uint64_t> canonical_kmers(const std::string& s, int k) {
+    std::vector<uint64_t> v;
+    if ((int)s.size() < k) return v;
+    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    uint64_t fw = 0, rc = 0;
+    int run = 0;
+    for (char ch : s) {
+        int c;
+        switch (ch) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break;
+                      case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; default: c = -1; }
+        if (c < 0) { run = 0; fw = rc = 0; continue; }
+        fw = ((fw << 2) | (uint64_t)c) & mask;
+        rc = (rc >> 2) | ((uint64_t)(3 - c) << (2 * (k - 1)));
+        if (++run >= k) v.push_back(fw < rc ? fw : rc);
+    }
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    return v;
+}
+float mash_identity(const std::vector<uint64_t>& a, const std::vector<uint64_t>& b, int k) {
+    size_t i = 0, j = 0, inter = 0;
+    while (i < a.size() && j < b.size()) {
+        if (a[i] < b[j]) ++i; else if (b[j] < a[i]) ++j; else { ++inter; ++i; ++j; }
+    }
+    const size_t uni = a.size() + b.size() - inter;
+    double dist = 1.0;
+    if (inter > 0 && uni > 0) {
+        const double J = (double)inter / (double)uni;
+        dist = -std::log(2.0 * J / (1.0 + J)) / (double)k;
+    }
+    return (float)(1.0 - dist);
+}
+// returns the number of sequences that took part; *thr is set when that is > 1
+int identity_threshold(const sxg_graph& g, const std::vector<path_range_t>& ranges, int k, float* thr) {
+    std::vector<std::vector<uint64_t>> km;
+    for (auto& r : ranges) {
+        std::string seq;  // :1985-1991, node sequences in step orientation, no padding
+        for (uint64_t st = r.begin; st < r.end; ++st) seq += g.sequence(g.steps[r.path][st]);
+        if (seq.size() >= (size_t)(8 * k)) km.push_back(canonical_kmers(seq, k));  // :1995
+    }
+    if (km.size() > 1) {
+        std::vector<float> est;
+        est.reserve(km.size() * (km.size() - 1) / 2);
+        for (size_t i = 0; i < km.size(); ++i)
+            for (size_t j = i + 1; j < km.size(); ++j) est.push_back(mash_identity(km[i], km[j], k));
+        std::sort(est.begin(), est.end());
+        *thr = std::max((float)0.7, est[(size_t)((double)(est.size() - 1) * 0.30)]);  // :2026
+    }
+    return (int)km.size();
+}
+void adaptive_scores(float thr, const int32_t in[6], int32_t out[6]) {  // :2032-2069
+    static const int32_t tiers[5][6] = {{1, 19, 39, 3, 81, 1}, {1, 13, 31, 3, 51, 1}, {1, 9, 16, 2, 41, 1},
+                                        {1, 7, 11, 2, 33, 1}, {1, 4, 6, 2, 26, 1}};
+    static const double cut[5] = {0.99, 0.98, 0.97, 0.95, 0.90};
+    const int32_t* pick = in;
+    for (int t = 0; t < 5; ++t)
+        if ((double)thr >= cut[t]) { pick = tiers[t]; break; }
+    for (int x = 0; x < 6; ++x) out[x] = pick[x];
+}
+// the scores block `ranges` is aligned with (set/default, or its adaptive tier)
+sxg_poa_params block_poa_params(const sxg_graph& g, const std::vector<path_range_t>& ranges, const sxg_smooth_params& p) {
+    sxg_smooth_params q = p;
+    if (p.adaptive_poa_params && ranges.size() > 1 && ranges.size() <= p.max_block_depth_for_padding_more) {  // :1982
+        float thr = 0;
+        if (identity_threshold(g, ranges, p.kmer_size > 0 ? p.kmer_size : 17, &thr) > 1) {
+            const int32_t in[6] = {p.poa_m, p.poa_n, p.poa_g, p.poa_e, p.poa_q, p.poa_c};
+            int32_t out[6];
+            adaptive_scores(thr, in, out);
+            q.poa_m = out[0]; q.poa_n = out[1]; q.poa_g = out[2]; q.poa_e = out[3]; q.poa_q = out[4]; q.poa_c = out[5];
+        }
+    }
+    return poa_params(q);
+}
+
 std::string cons_name(const sxg_smooth_params& p, int64_t block_id) {
     if (!p.add_consensus) return "";
     return std::string(p.consensus_base_name ? p.consensus_base_name : "Consensus_") + std::to_string(block_id);
@@ -407,6 +484,17 @@ void sxg_smooth_default_params(sxg_smooth_params* p) {
     p->local_alignment = 1;                                                              // src/main.cpp:487
     p->poa_padding_fraction = 0.001f; p->max_block_depth_for_padding_more = 1000;         // src/main.cpp:293-295
     p->add_consensus = 0; p->consensus_base_name = "Consensus_";
+    p->adaptive_poa_params = 0; p->kmer_size = 17;                                        // src/main.cpp:111,304
+}
+
+void sxg_adaptive_poa_scores(float thr, const int32_t set_scores[6], int32_t out_scores[6]) { adaptive_scores(thr, set_scores, out_scores); }
+
+int sxg_block_identity_threshold(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, int32_t kmer_size, float* thr, int32_t* n_used) {
+    if (!g || !b || !thr || !n_used || block_id < 0 || block_id >= (int64_t)b->blocks.size() || kmer_size < 1 || kmer_size > 32)
+        return fail(SXG_E_INVALID, "bad argument");
+    *thr = 0;
+    *n_used = identity_threshold(*g, b->blocks[block_id], kmer_size, thr);
+    return SXG_OK;
 }
 const char* sxg_smooth_last_error(void) { return g_err.c_str(); }
 void sxg_smooth_free(void* p) { free(p); }
@@ -511,7 +599,7 @@ int sxg_block_graph_gfa(const sxg_graph* g, const sxg_blockset* b, int64_t block
     const collected_t c = collect(*g, b->blocks[block_id], *p);
     batch_t B;
     add_to_batch(B, c);
-    const sxg_poa_params pp = poa_params(*p);
+    const sxg_poa_params pp = block_poa_params(*g, b->blocks[block_id], *p);
     sxg_poa_batch_in in;
     memset(&in, 0, sizeof(in));
     in.n_blocks = 1; in.blk_off = B.blk_off.data(); in.seq_off = B.seq_off.data(); in.bases = B.bases.data();
@@ -535,12 +623,16 @@ int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_p
     batch_t B;
     for (int64_t k = 0; k < nb; ++k) { col[k] = collect(*g, b->blocks[k], *p); add_to_batch(B, col[k]); }
     // phase 2: ONE batched POA call (replaces src/smooth.cpp:752-786 of every block)
-    const sxg_poa_params pp = poa_params(*p);
+    // A14: with -a every block brings its own scores (the engine's per_block_params)
+    std::vector<sxg_poa_params> pps;
+    if (p->adaptive_poa_params) for (int64_t k = 0; k < nb; ++k) pps.push_back(block_poa_params(*g, b->blocks[k], *p));
+    if (pps.empty()) pps.push_back(poa_params(*p));
     sxg_poa_batch_in in;
     memset(&in, 0, sizeof(in));
     uint8_t dummy = 0;
     in.n_blocks = (int32_t)nb; in.blk_off = B.blk_off.data(); in.seq_off = B.seq_off.data();
-    in.bases = B.bases.empty() ? &dummy : B.bases.data(); in.weights = B.weights.data(); in.params = &pp;
+    in.bases = B.bases.empty() ? &dummy : B.bases.data(); in.weights = B.weights.data(); in.params = pps.data();
+    in.per_block_params = p->adaptive_poa_params && nb > 0 ? 1 : 0;
     in.want_consensus = p->add_consensus;
     sxg_poa_batch_out out;
     memset(&out, 0, sizeof(out));

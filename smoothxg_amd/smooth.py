@@ -19,13 +19,14 @@ class SmoothParams(C.Structure):
     _fields_ = [("poa_m", C.c_int32), ("poa_n", C.c_int32), ("poa_g", C.c_int32), ("poa_e", C.c_int32),
                 ("poa_q", C.c_int32), ("poa_c", C.c_int32), ("local_alignment", C.c_int32),
                 ("poa_padding_fraction", C.c_float), ("max_block_depth_for_padding_more", C.c_uint64),
-                ("add_consensus", C.c_int32), ("consensus_base_name", C.c_char_p)]
+                ("add_consensus", C.c_int32), ("consensus_base_name", C.c_char_p),
+                ("adaptive_poa_params", C.c_int32), ("kmer_size", C.c_int32)]
 
 
 EXPORTS = ["sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_free", "sxg_graph_from_gfa",
            "sxg_graph_free", "sxg_graph_node_count", "sxg_graph_path_count", "sxg_blockset_by_path_windows",
            "sxg_blockset_free", "sxg_blockset_size", "sxg_block_collect_text", "sxg_block_graph_gfa",
-           "sxg_smooth_gfa"]
+           "sxg_smooth_gfa", "sxg_adaptive_poa_scores", "sxg_block_identity_threshold"]
 
 
 def load_library():
@@ -53,6 +54,9 @@ def load_library():
     L.sxg_block_collect_text.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), C.POINTER(vp)]
     L.sxg_block_graph_gfa.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
     L.sxg_smooth_gfa.argtypes = [vp, vp, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
+    L.sxg_adaptive_poa_scores.restype = None
+    L.sxg_adaptive_poa_scores.argtypes = [C.c_float, C.POINTER(C.c_int32 * 6), C.POINTER(C.c_int32 * 6)]
+    L.sxg_block_identity_threshold.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -67,6 +71,13 @@ def default_params(**kw):
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+def adaptive_poa_scores(est_identity_threshold, set_scores=(1, 4, 6, 2, 26, 1)):
+    """A14: the score tier (m, n, g, e, q, c; CLI convention) of src/smooth.cpp:2032-2069."""
+    a, o = (C.c_int32 * 6)(*set_scores), (C.c_int32 * 6)()
+    load_library().sxg_adaptive_poa_scores(est_identity_threshold, C.byref(a), C.byref(o))
+    return tuple(o)
 
 
 def gpu_provider(engine):
@@ -117,6 +128,13 @@ class Smoother:
             return C.string_at(out).decode()
         finally:
             self.L.sxg_smooth_free(out)
+
+    def identity_threshold(self, block_id, kmer_size=17):
+        """A14: (threshold, sequences used); the threshold only counts when more than one was used."""
+        thr, n = C.c_float(), C.c_int32()
+        if self.L.sxg_block_identity_threshold(self.g, self.b, block_id, kmer_size, C.byref(thr), C.byref(n)):
+            raise SmoothError(self.L.sxg_smooth_last_error().decode())
+        return thr.value, n.value
 
     def collect_text(self, block_id, params):
         out = C.c_void_p()

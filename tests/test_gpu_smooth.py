@@ -37,3 +37,38 @@ def test_global_alignment_and_block_graph_on_gpu(engine):
         c = SO.collect(g, blocks[k])
         code, paths, cn = SO.poa(c, local=False)
         assert sm.block_graph_gfa(k, p, S.gpu_provider(engine)) == SO.to_gfa(SO.build_block_graph(c, code, paths, cn, ""))
+
+
+def _haplotype_gfa(seed, n_paths, length, sub, node_bp=80):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    anc = rng.integers(0, 4, length)
+    lines, plines, nid = ["H\tVN:Z:1.0"], [], 1
+    for p in range(n_paths):
+        hap = anc.copy()
+        mut = rng.random(length) < sub * (1 + p % 3)          # blocks of different identity
+        hap[mut] = (hap[mut] + rng.integers(1, 4, int(mut.sum()))) % 4
+        text = "".join("ACGT"[c] for c in hap)
+        steps = []
+        for a in range(0, length, node_bp):
+            lines.append("S\t%d\t%s" % (nid, text[a:a + node_bp]))
+            steps.append("%d+" % nid)
+            nid += 1
+        plines.append("P\thap%d\t%s\t*" % (p, ",".join(steps)))
+    return "\n".join(lines + plines) + "\n"
+
+
+@pytest.mark.parametrize("sub", [0.001, 0.008])
+def test_adaptive_scores_reach_the_gpu_per_block(engine, sub):
+    """A14 (-a) end to end on the GPU: per-block score tiers (q up to 81) through per_block_params."""
+    text = _haplotype_gfa(7, 8, 3000, sub)
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 1000)
+    blocks = SO.blockset_by_path_windows(g, 1000)
+    picked = {SO.block_scores(g, r, True, 17, 1000) for r in blocks}
+    assert picked - {(1, 4, 6, 2, 26, 1)}, picked            # some upper tier is in play
+    got = sm.smooth_gfa(S.default_params(adaptive_poa_params=1), S.gpu_provider(engine))
+    assert got == SO.smooth(g, blocks, adaptive=True, kmer_size=17)
+    out = SO.Graph(got)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)

@@ -35,10 +35,10 @@ class OracleProvider:
         so = np.ctypeslib.as_array(i.seq_off, (ns + 1,)).copy() if ns else np.zeros(1, np.int64)
         bases = np.ctypeslib.as_array(i.bases, (max(int(so[-1]), 1),)).copy()
         w = np.ctypeslib.as_array(i.weights, (max(ns, 1),)).copy() if i.weights else np.ones(max(ns, 1), np.uint32)
-        pr = i.params[0]
-        par = O.mkparams(pr.m, pr.n, pr.g, pr.e, pr.q, pr.c, pr.mode)
         node_off, cons_off, codes, paths, cons = [0], [0], [], [], []
         for b in range(nb):
+            pr = i.params[b if i.per_block_params else 0]
+            par = O.mkparams(pr.m, pr.n, pr.g, pr.e, pr.q, pr.c, pr.mode)
             seqs = [bases[so[s]:so[s + 1]] for s in range(blk[b], blk[b + 1])]
             if seqs:
                 g, _, _ = O.block_run(seqs, w[blk[b]:blk[b + 1]], par)
@@ -86,6 +86,27 @@ def synthetic_gfa(seed, n_paths=5, n_nodes=60, with_reverse=True):
             steps = [s[:-1] + ("-" if s[-1] == "+" else "+") for s in reversed(steps)]
         lines.append("P\tpath%d\t%s\t*" % (p, ",".join(steps)))
     return "\n".join(lines) + "\n"
+
+
+def haplotype_gfa(seed, n_paths=5, length=900, sub=0.01, node_bp=60):
+    """Near-identical haplotypes, every path on its own chain of nodes: blocks of high identity
+    (the adaptive score tiers of A14 need >= 0.90)."""
+    rng = np.random.default_rng(seed)
+    anc = rng.integers(0, 4, length)
+    lines, nid = ["H\tVN:Z:1.0"], 1
+    plines = []
+    for p in range(n_paths):
+        hap = anc.copy()
+        mut = rng.random(length) < sub
+        hap[mut] = (hap[mut] + rng.integers(1, 4, int(mut.sum()))) % 4
+        text = "".join("ACGT"[c] for c in hap)
+        steps = []
+        for a in range(0, length, node_bp):
+            lines.append("S\t%d\t%s" % (nid, text[a:a + node_bp]))
+            steps.append("%d+" % nid)
+            nid += 1
+        plines.append("P\thap%d\t%s\t*" % (p, ",".join(steps)))
+    return "\n".join(lines + plines) + "\n"
 
 
 @pytest.fixture(scope="module")
@@ -159,6 +180,84 @@ def test_drb1_fixture_round_trip(prov):
     assert got == SO.smooth(g, blocks)
     out = SO.Graph(got)
     assert sorted(out.pname) == sorted(g.pname)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+def test_adaptive_score_tiers_are_the_reference_table():
+    """src/smooth.cpp:2032-2069, every tier and both sides of every cut."""
+    table = {0.99: (1, 19, 39, 3, 81, 1), 0.98: (1, 13, 31, 3, 51, 1), 0.97: (1, 9, 16, 2, 41, 1),
+             0.95: (1, 7, 11, 2, 33, 1), 0.90: (1, 4, 6, 2, 26, 1)}
+    custom = (2, 5, 7, 3, 30, 2)
+    for cut, tier in table.items():
+        for thr in (np.float32(cut + 0.004), np.float32(cut)):
+            want = tier if float(thr) >= cut else None
+            if want is not None:
+                assert S.adaptive_poa_scores(float(thr), custom) == want == SO.adaptive_scores(thr, custom)
+    for thr in (0.7, 0.85, 0.8999):
+        assert S.adaptive_poa_scores(thr, custom) == custom == SO.adaptive_scores(np.float32(thr), custom)
+    for thr in np.linspace(0.69, 1.0, 63, dtype=np.float32):
+        assert S.adaptive_poa_scores(float(thr), custom) == SO.adaptive_scores(thr, custom)
+
+
+def test_identity_threshold_matches_oracle():
+    """A14 estimator (exact canonical-k-mer Jaccard -> mash distance, 30 % percentile, floor 0.7)."""
+    for seed, k in ((4, 5), (5, 7), (6, 11)):
+        text = synthetic_gfa(seed, n_paths=6, n_nodes=80)
+        g = SO.Graph(text)
+        sm = S.Smoother(text, 150)
+        for b, ranges in enumerate(SO.blockset_by_path_windows(g, 150)):
+            thr, used = SO.identity_threshold(g, ranges, k)
+            got_thr, got_used = sm.identity_threshold(b, k)
+            assert got_used == used
+            if used > 1:
+                assert np.float32(got_thr) == thr, (seed, b, got_thr, thr)
+    text = open(DRB1).read()
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 700)
+    blocks = SO.blockset_by_path_windows(g, 700)
+    tiers = set()
+    for b in (0, 3, 7, 11):
+        thr, used = SO.identity_threshold(g, blocks[b], 17)
+        got_thr, got_used = sm.identity_threshold(b, 17)
+        assert (got_used, np.float32(got_thr)) == (used, thr)
+        tiers.add(SO.adaptive_scores(thr))
+    assert len(tiers) >= 1
+
+
+@pytest.mark.parametrize("seed", [4, 6])
+def test_adaptive_iteration_matches_oracle(prov, seed):
+    """-a end to end: per-block scores reach the POA provider (per_block_params) and the smoothed
+    graph equals the oracle stack's, paths preserved."""
+    text = synthetic_gfa(seed, n_paths=6, n_nodes=80)
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 200)
+    blocks = SO.blockset_by_path_windows(g, 200)
+    p = S.default_params(adaptive_poa_params=1, kmer_size=5)
+    picked = {SO.block_scores(g, r, True, 5, 1000) for r in blocks}
+    got = sm.smooth_gfa(p, prov.provider())
+    assert got == SO.smooth(g, blocks, adaptive=True, kmer_size=5)
+    out = SO.Graph(got)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+    assert picked  # at least the default tier
+
+
+@pytest.mark.parametrize("sub,tier", [(0.0005, (1, 19, 39, 3, 81, 1)), (0.004, (1, 13, 31, 3, 51, 1)), (0.012, (1, 9, 16, 2, 41, 1)),
+                                      (0.02, (1, 7, 11, 2, 33, 1))])
+def test_adaptive_iteration_high_identity_tiers(prov, sub, tier):
+    """Haplotypes of graded divergence land in the upper score tiers; the iteration still equals
+    the oracle stack's and preserves every path."""
+    text = haplotype_gfa(int(sub * 1e5), sub=sub)
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 450)
+    blocks = SO.blockset_by_path_windows(g, 450)
+    picked = [SO.block_scores(g, r, True, 15, 1000) for r in blocks]
+    assert tier in picked, picked
+    p = S.default_params(adaptive_poa_params=1, kmer_size=15)
+    got = sm.smooth_gfa(p, prov.provider())
+    assert got == SO.smooth(g, blocks, adaptive=True, kmer_size=15)
+    out = SO.Graph(got)
     for q, nm in enumerate(g.pname):
         assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
 
