@@ -35,7 +35,16 @@ enum : int {
     ST_TBX_OVERFLOW = 3,    // too many multi-pred rows / in-degree beyond plane capacity
     ST_NODES_OVERFLOW = 4,
     ST_TOO_LONG = 5,
+    ST_RANGE_OVERFLOW = 6,  // a global alignment outgrew the score range of the narrow sweep (re-run wider)
 };
+
+// Lower bound of every reachable global-alignment score: the all-gap path (a gap down a chain of
+// `rows` predecessors plus a gap over `cols` columns); H is a maximum over paths, so it is never below.
+SXG_HD long sxg_gap_cost(int g, int e, int q, int c, long k) {
+    if (k <= 0) return 0;
+    const long a = g + (k - 1) * (long)e, b = q + (k - 1) * (long)c;
+    return a > b ? a : b;
+}
 
 struct Scoring {
     int m, n, g, e, q, c;  // normalised (linear: e=q=c=g; affine: q=g,c=e)

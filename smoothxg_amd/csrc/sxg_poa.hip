@@ -198,6 +198,11 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             int score = 0;
             if (len + 1 > T * CPL) { status = ST_TOO_LONG; break; }
             if (N + len > A.lay.nodes_cap) { status = ST_NODES_OVERFLOW; break; }
+            if (RM != 1 && !S.sw &&
+                -(sxg_gap_cost(S.g, S.e, S.q, S.c, N) + sxg_gap_cost(S.g, S.e, S.q, S.c, len)) >= (RM == 2 ? 15800 : 30000)) {
+                status = ST_RANGE_OVERFLOW;
+                break;
+            }
             if (N > 0 && len > 0) {
                 PROF(0);
                 status = prep_rows(ctx, V.G, V.R, caps);
@@ -447,34 +452,32 @@ static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool sw) {
     return nullptr;
 }
 
-// Is an int16 H safe for the packed row words?  |H| bound: SW 0..m*L; NW additionally the
-// all-gap path through at most rows_max nodes.
-static bool h16_safe(const Scoring& S, int maxlen, int rows_max) {
-    long hi = (long)std::abs(S.m) * maxlen;
-    long lo = 0;
-    if (!S.sw) {
-        const long ext = std::max(std::max(std::abs(S.e), std::abs(S.c)), 1);
-        lo = std::abs(S.g) + std::abs(S.q) + ((long)rows_max + maxlen) * ext + (long)std::abs(S.n) * maxlen;
-    }
-    return hi < 30000 && lo < 30000;
+// Score ranges.  Local alignment: 0..m*L.  Global: additionally down to the all-gap path through
+// `rows` graph rows (sxg_gap_cost).  `rows` is exact for the align-only API; for whole blocks the
+// graph grows while the block runs, so the host assumes the smallest possible graph (one node per base
+// of the longest sequence) and the kernel re-checks with the true row count before every sweep,
+// answering ST_RANGE_OVERFLOW when it no longer fits: the block is then re-run one step wider.
+static long score_floor(const Scoring& S, int maxlen, int rows) {
+    if (S.sw) return 0;
+    return -(sxg_gap_cost(S.g, S.e, S.q, S.c, rows) + sxg_gap_cost(S.g, S.e, S.q, S.c, maxlen));
 }
-
-// Can the packed-int16 sweep run?  Every reachable score and every intermediate (score +- one
-// penalty, difference of two scores) must stay inside int16 with NEGP = -16384 as "-inf".
-static bool p16_safe(const Scoring& S, int maxlen, int rows_max) {
+// int16 H in the row words of the 32-bit sweep
+static bool h16_safe(const Scoring& S, int maxlen, int rows) {
+    return (long)std::abs(S.m) * maxlen < 30000 && score_floor(S, maxlen, rows) < 30000;
+}
+// Packed-int16 sweep: every reachable score and every intermediate (score +- one penalty, difference
+// of two scores) must stay inside int16 with NEGP = -16384 as "-inf".
+static bool p16_safe(const Scoring& S, int maxlen, int rows) {
     if (getenv("SXG_POA_NO_PACKED")) return false;
-    long hi = (long)std::abs(S.m) * maxlen, lo = 0;
-    if (!S.sw) {
-        const long ext = std::max(std::max(std::abs(S.e), std::abs(S.c)), 1);
-        lo = std::abs(S.g) + std::abs(S.q) + ((long)rows_max + maxlen) * ext + (long)std::abs(S.n) * maxlen;
-    }
     // stored rows keep H - max(H+g, F+e) and H - max(H+q, O+c) in one byte each
     if (std::abs(S.g) > 120 || std::abs(S.q) > 120) return false;
-    return hi < 15800 && lo < 15800;
+    return (long)std::abs(S.m) * maxlen < 15800 && score_floor(S, maxlen, rows) < 15800;
 }
-static int row_mode(const Scoring& S, int maxlen, int rows_max) {
-    if (p16_safe(S, maxlen, rows_max)) return 2;
-    return h16_safe(S, maxlen, rows_max) ? 0 : 1;
+// narrowest mode >= `at_least` (2 = packed < 0 = int16 row words < 1 = int32 row words)
+static int row_mode(const Scoring& S, int maxlen, int rows, int at_least = 2) {
+    if (at_least == 2 && p16_safe(S, maxlen, rows)) return 2;
+    if (at_least != 1 && h16_safe(S, maxlen, rows)) return 0;
+    return 1;
 }
 
 struct DevBuf {
@@ -654,7 +657,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
             if (s > in->blk_off[b]) m.cost += (double)len * (l1 + 0.05 * prev);
             prev += (double)len;
         }
-        m.rm = row_mode(m.S, m.maxlen, (int)std::min<int64_t>(m.sumlen + 8, (1 << 20) - 1));
+        m.rm = row_mode(m.S, m.maxlen, m.maxlen);  // optimistic; the kernel re-checks (see score_floor)
         m.fits = variant_for_len(m.maxlen, m.rm, &m.variant);
     }
     // sanitise letters while copying to a staging buffer
@@ -923,8 +926,15 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         lap("launches");
         HIPCHK(hipMemcpy(status.data(), h->d_status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
         std::vector<int32_t> again;
-        for (int b : pending)
+        for (int b : pending) {
             if (status[b] == ST_ROWS_OVERFLOW || status[b] == ST_POOL_OVERFLOW || status[b] == ST_TBX_OVERFLOW) again.push_back(b);
+            else if (status[b] == ST_RANGE_OVERFLOW) {  // one step wider: packed -> int16 row words -> int32 row words
+                BlockMeta& m = h->meta[b];
+                m.rm = row_mode(m.S, m.maxlen, m.maxlen, m.rm == 2 ? 0 : 1);
+                m.fits = variant_for_len(m.maxlen, m.rm, &m.variant);
+                if (m.fits) again.push_back(b);  // (the wider sweeps cover every length the packed one does)
+            }
+        }
         if (attempt < 2) h->stats.retries += (int)again.size();
         pending.swap(again);
         for (auto& pl : plans) all_plans.push_back(std::move(pl));

@@ -234,3 +234,23 @@ def test_every_packed_strip_width_and_wave_count(engine, oracle):
         assert (st["dom_threads"], st["dom_cols_per_lane"]) == _packed_geometry(max(len(s) for s in seqs))[1:]
         g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
         assert_block_equal(res[0], g, sc, cells, label=f"packed T={T} cols/lane={cpl} L={L}")
+
+
+def test_global_alignment_outgrows_the_packed_range_and_is_rerun_wider(engine, oracle):
+    """Affine global alignment, 3 kbp: the packed sweep is chosen for the smallest possible graph, the
+    divergent sequences grow the graph until gap(N) + gap(L) leaves +-15800, the kernel answers
+    RANGE_OVERFLOW and the engine re-runs the block with the 32-bit sweep -- same results."""
+    rng = np.random.default_rng(77)
+    seqs = random_block(rng, 8, 3000, div=0.25)
+    g, sc, cells = oracle.block_run(seqs, None, oparams("affine_4param", 1))
+    assert len(g.nodes()[0]) > 5200                      # -(g + 2(N-1)) - (g + 2(L-1)) < -15800 from N ~ 4900 on
+    res = engine.run_blocks([seqs], gparams("affine_4param", 1))
+    st = engine.stats()
+    assert st["retries"] >= 1 and st["dom_row_mode"] != 2
+    assert_block_equal(res[0], g, sc, cells, label="range-rerun")
+    # ... while a similar block that stays small runs packed to the end
+    calm = random_block(rng, 4, 3000, div=0.01)
+    g2, sc2, cells2 = oracle.block_run(calm, None, oparams("affine_4param", 1))
+    res2 = engine.run_blocks([calm], gparams("affine_4param", 1))
+    assert engine.stats()["dom_row_mode"] == 2 and engine.stats()["retries"] == 0
+    assert_block_equal(res2[0], g2, sc2, cells2, label="range-ok")
