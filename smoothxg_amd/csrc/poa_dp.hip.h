@@ -78,6 +78,10 @@ struct WgCtx {
 
 // ---------------------------------------------------------------------------------------
 // packed row words of the row pool
+// native vector types: usable behind address-space-qualified pointers (HIP's uint2/int4 classes are not)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 template <bool H16> struct RowWord;
 template <> struct RowWord<true> {
     using type = uint32_t;
@@ -93,10 +97,10 @@ template <> struct RowWord<true> {
     static __device__ __forceinline__ int h_of(type w) { return (int)(short)(w & 0xffffu); }
 };
 template <> struct RowWord<false> {
-    using type = uint2;
+    using type = u32x2;
     static __device__ __forceinline__ type pack(int h, int f, int o) {
         const unsigned df = (unsigned)min(h - f, 65535), dq = (unsigned)min(h - o, 65535);
-        return make_uint2((unsigned)h, df | (dq << 16));
+        return u32x2{(unsigned)h, df | (dq << 16)};
     }
     static __device__ __forceinline__ void unpack(type w, int& h, int& f, int& o) {
         h = (int)w.x;
@@ -276,6 +280,15 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
     const unsigned lds_pf = (unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)(pf_off >= 0 ? pf_off : 0);
     const unsigned lds_pfl = lds_pf + (unsigned)PF_PIECES * (unsigned)T * 16u;  // [T] 4-byte H left of each strip
     int pf_row = -1;                                                            // row whose words are (being) fetched
+    // global, scalar base pointers (see sxg_global / sxg_uniform)
+    SXG_GLOBAL Word* const g_row0 = sxg_uniform(sxg_global((Word*)B.row0));
+    SXG_GLOBAL Word* const g_pool = sxg_uniform(sxg_global((Word*)B.pool));
+    SXG_GLOBAL uint8_t* const g_tb = sxg_uniform(sxg_global(B.tb));
+    SXG_GLOBAL uint32_t* const g_steps = sxg_uniform(sxg_global(B.steps));
+    SXG_GLOBAL const int32_t* const g_meta = sxg_uniform(sxg_global((const int32_t*)R.meta));
+    SXG_GLOBAL const int32_t* const g_preds = sxg_uniform(sxg_global((const int32_t*)R.preds));
+    SXG_GLOBAL const int32_t* const g_slot = sxg_uniform(sxg_global((const int32_t*)R.slot));
+    const unsigned uj0 = (unsigned)(t * W);
     const int g = S.g, e = S.e, q = S.q, c = S.c, mm = S.m, mn = S.n;
     const int We = W * e, Wc = W * c;
     int* tot_a = lds;        // [16]
@@ -313,9 +326,8 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
         Hleft = j < 0 ? NEG : h;
     }
     {
-        Word* r0 = (Word*)B.row0 + j0;
 #pragma unroll
-        for (int k = 0; k < W; ++k) r0[k] = RWt::pack(Hp[k], Fp[k], Op[k]);
+        for (int k = 0; k < W; ++k) (g_row0 + k)[uj0] = RWt::pack(Hp[k], Fp[k], Op[k]);
     }
     // end-cell tracking.  Local: key = H<<5 | (31-k) so that one max per column finds the
     // greatest H and, among equals, the smallest column; rows are compared on H only (strictly).
@@ -329,8 +341,8 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
         if ((r & (META_CHUNK - 1)) == 0) {
             // stage the descriptors of the next 256 rows (all waves are past row r-1 here)
             __syncthreads();
-            const int4* gm = (const int4*)(R.meta + 8 * (size_t)r);
-            int4* lm = (int4*)(smem + LDS_CTL_BYTES);
+            SXG_GLOBAL const i32x4* gm = (SXG_GLOBAL const i32x4*)(g_meta + 8 * (size_t)r);
+            i32x4* lm = (i32x4*)(smem + LDS_CTL_BYTES);
             const int nrow = min(META_CHUNK, N - r);
             for (int x = t; x < 2 * nrow; x += T) lm[x] = gm[x];
             __syncthreads();
@@ -422,10 +434,10 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
                 } else if (p0 == pf_row) {
                     SXG_READ_PF(wr, hl);
                 } else {
-                    const Word* sp = ((p0 == 0) ? (const Word*)B.row0 : (const Word*)B.pool + (size_t)s0 * Lpad) + j0;
+                    SXG_GLOBAL const Word* sp = (p0 == 0) ? g_row0 : g_pool + (size_t)s0 * Lpad;
 #pragma unroll
-                    for (int k = 0; k < W; ++k) wr[k] = sp[k];
-                    hl = j0 > 0 ? RWt::h_of(sp[-1]) : NEG;
+                    for (int k = 0; k < W; ++k) wr[k] = (sp + k)[uj0];
+                    hl = j0 > 0 ? RWt::h_of((sp - 1)[uj0]) : NEG;
                 }
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
@@ -441,8 +453,8 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
                 int p, sl;
                 if (x == 1) { p = reg1 ? p0 : p1; sl = reg1 ? s0 : s1; }
                 else {
-                    p = __builtin_amdgcn_readfirstlane(R.preds[pb + x]);
-                    sl = (p >= 1 && p != i - 1) ? __builtin_amdgcn_readfirstlane(R.slot[p - 1]) : -1;
+                    p = __builtin_amdgcn_readfirstlane(g_preds[pb + x]);
+                    sl = (p >= 1 && p != i - 1) ? __builtin_amdgcn_readfirstlane(g_slot[p - 1]) : -1;
                 }
                 Word wr[W];
                 int hl = Hleft;
@@ -452,10 +464,10 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
                 } else if (p == pf_row) {
                     SXG_READ_PF(wr, hl);
                 } else {
-                    const Word* sp = ((p == 0) ? (const Word*)B.row0 : (const Word*)B.pool + (size_t)sl * Lpad) + j0;
+                    SXG_GLOBAL const Word* sp = (p == 0) ? g_row0 : g_pool + (size_t)sl * Lpad;
 #pragma unroll
-                    for (int k = 0; k < W; ++k) wr[k] = sp[k];
-                    hl = j0 > 0 ? RWt::h_of(sp[-1]) : NEG;
+                    for (int k = 0; k < W; ++k) wr[k] = (sp + k)[uj0];
+                    hl = j0 > 0 ? RWt::h_of((sp - 1)[uj0]) : NEG;
                 }
                 // fold: "cand + ge > cur" is (cand > cur) for ge = 0 and (cand >= cur) for ge = 1;
                 // the masks start at 0 (ge = 0: set on take-over) or ALL (ge = 1: cleared on
@@ -488,8 +500,8 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
                     if (SXG_GROUP_END(k))
                         SXG_PIN(SXG_COLS(Hc, k), SXG_COLS(Fp, k), SXG_COLS(Op, k), "+v"(fxm), "+v"(oxm), "+v"(dm), "+v"(fmk), "+v"(omk), "+v"(hl));
                 }
-                uint32_t* st = B.steps + ((size_t)(tx + x - 1) * 3) * T + t;
-                st[0] = dm; st[T] = fmk; st[2 * T] = omk;
+                SXG_GLOBAL uint32_t* st = g_steps + ((size_t)(tx + x - 1) * 3) * T;
+                st[(unsigned)t] = dm; (st + T)[(unsigned)t] = fmk; (st + 2 * T)[(unsigned)t] = omk;
             }
         }
 #undef SXG_INIT
@@ -513,7 +525,7 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
             else if (np1 == 2) { tp = r1n ? q0 : q1; ts = r1n ? t0 : t1; }     // register row first, then this one
             if (tp == i) tp = -1;                                              // (parked copy of the register row)
             if (tp >= 0) {
-                const char* src = (const char*)((tp == 0) ? (const Word*)B.row0 : (const Word*)B.pool + (size_t)ts * Lpad);
+                const char* src = (const char*)((tp == 0) ? (const Word*)B.row0 : (const Word*)B.pool + (size_t)ts * Lpad);  // (opt-in path)
                 const char* mine = src + (size_t)j0 * sizeof(Word);
                 // the LDS side of the DMA is a wave-uniform base (M0) + lane * size
                 const unsigned wave0 = (unsigned)__builtin_amdgcn_readfirstlane(wv) * 64u;
@@ -546,22 +558,17 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
         fm &= ~om;
         // carries: Ein(t) = max_{s<t} (a_s + (t-1-s)*W*e)
         int ya = a - t * We, yb = CVX ? b - t * Wc : NEG;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int oa = __shfl_up(ya, d), ob = __shfl_up(yb, d);
-            if (lane >= d) { ya = max(ya, oa); yb = max(yb, ob); }
-        }
+        ya = sxg_wave_incl_max(ya);
+        if (CVX) yb = sxg_wave_incl_max(yb);
         if (NW > 1) {
             if (lane == 63) { tot_a[wv] = ya; tot_b[wv] = yb; }
             SXG_ROW_BARRIER();  // B1
             int ba = NEG * 2, bb = NEG * 2;
             for (int x = 0; x < wv; ++x) { ba = max(ba, tot_a[x]); bb = max(bb, tot_b[x]); }
             ya = max(ya, ba); yb = max(yb, bb);
-            int ea = __shfl_up(ya, 1), eb = __shfl_up(yb, 1);
-            if (lane == 0) { ea = ba; eb = bb; }
-            ya = ea; yb = eb;
+            ya = sxg_wave_shr1(ya, ba); yb = sxg_wave_shr1(yb, bb);
         } else {
-            ya = __shfl_up(ya, 1); yb = __shfl_up(yb, 1);
+            ya = sxg_wave_shr1(ya, NEG * 2); yb = sxg_wave_shr1(yb, NEG * 2);
         }
         int E = (t == 0) ? NEG : ya + (t - 1) * We;
         int Q = (t == 0 || !CVX) ? NEG : yb + (t - 1) * Wc;
@@ -599,7 +606,7 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
         }
         // hand H of my last column and the ext flags of the next column to the right neighbour
         int xh = Hc[W - 1], xb = (int)(ebit | (qbit << 1));
-        int lh = __shfl_up(xh, 1), lb = __shfl_up(xb, 1);
+        int lh = sxg_wave_shr1(xh, 0), lb = sxg_wave_shr1(xb, 0);
         if (NW > 1) {
             if (lane == 63) { xch_h[wv] = xh; xch_b[wv] = xb; }
             SXG_ROW_BARRIER();  // B2
@@ -610,14 +617,14 @@ __device__ __forceinline__ void dp_fill(const Scoring& S, const RowsView& R, con
 
         // ---- stores
         {
-            unsigned* dst = (unsigned*)(B.tb + (size_t)i * Lpad + j0);
+            SXG_GLOBAL unsigned* dst = (SXG_GLOBAL unsigned*)(g_tb + (size_t)i * Lpad);  // W bytes per lane
 #pragma unroll
-            for (int k4 = 0; k4 < W / 4; ++k4) dst[k4] = tbw[k4];
+            for (int k4 = 0; k4 < W / 4; ++k4) (dst + k4)[uj0 / 4] = tbw[k4];
         }
         if (flags & ROW_STORE) {
-            Word* dst = (Word*)B.pool + (size_t)myslot * Lpad + j0;
+            SXG_GLOBAL Word* dst = g_pool + (size_t)myslot * Lpad;
 #pragma unroll
-            for (int k = 0; k < W; ++k) dst[k] = RWt::pack(Hc[k], Fp[k], Op[k]);
+            for (int k = 0; k < W; ++k) (dst + k)[uj0] = RWt::pack(Hc[k], Fp[k], Op[k]);
         }
 #pragma unroll
         for (int k = 0; k < W; ++k) Hp[k] = Hc[k];

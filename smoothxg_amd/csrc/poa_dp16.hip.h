@@ -28,9 +28,6 @@ namespace sxg {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-// native vector types: usable behind address-space-qualified pointers (HIP's u32x2/i32x4 classes are not)
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NEGP = -16384;  // "minus infinity" of the packed sweep
 constexpr int P16_TB_WORDS = 9;
