@@ -185,12 +185,18 @@ __device__ __forceinline__ void sxg_balance_prio(const DpBuffers& B, const unsig
     const unsigned long long left = B.prio_rem0 > done ? B.prio_rem0 - done : 0;
     const unsigned mine = (unsigned)min(left >> 16, 0xfffffffeull) + 1u;
     if (threadIdx.x == 0) __hip_atomic_store(B.prio_board + B.prio_rank, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the eight ranks come through the scalar data path (s_load, glc: past the constant cache): a
+    // vector load here would be waited for with vmcnt, in order behind every store still in flight
+    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+    u32x8 bw;
+    const unsigned long long bp = (unsigned long long)B.prio_board;
+    const unsigned long long bps = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(bp >> 32)) << 32) |
+                                   __builtin_amdgcn_readfirstlane((unsigned)bp);
+    asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bw) : "s"(bps) : "memory");
     unsigned behind = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {  // launch ranks 0..7 (occupancy never exceeds 8 workgroups per CU here)
-        const unsigned other = __hip_atomic_load(B.prio_board + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        behind += (k != B.prio_rank && other != 0u && other < mine) ? 1u : 0u;
-    }
+    for (int k = 0; k < 8; ++k)  // launch ranks 0..7 (occupancy never exceeds 8 workgroups per CU here)
+        behind += (k != B.prio_rank && bw[k] != 0u && bw[k] < mine) ? 1u : 0u;
     sxg_set_prio(min(__builtin_amdgcn_readfirstlane(behind), 3u));
 }
 __device__ __forceinline__ void sxg_rotate_prio(const int rank) {

@@ -555,6 +555,9 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                                           int32_t* posnode, int32_t* pair_row, int32_t* pair_pos, char* smem) {
     const int TW = T * W;
     const int lane = threadIdx.x & 63;
+    // the block's only serial phase (three waves wait for this one): a dependent-read chain that
+    // rarely has an instruction ready, so top priority costs the co-residents next to nothing
+    __builtin_amdgcn_s_setprio(3);
     uint32_t* win = (uint32_t*)(smem + LDS_CTL_BYTES);
     // first of the two lane-columns fetched for a row whose expected (half-local) column is x
     auto col0 = [&](int x) -> int { return x < W / 2 ? 0 : min((x - W / 2) / W, T - 2); };
