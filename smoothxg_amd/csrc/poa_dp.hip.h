@@ -190,8 +190,9 @@ __device__ __forceinline__ void sxg_balance_prio(const DpBuffers& B, const unsig
     typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
     u32x8 bw;
     const unsigned long long bp = (unsigned long long)B.prio_board;
-    const unsigned long long bps = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(bp >> 32)) << 32) |
-                                   __builtin_amdgcn_readfirstlane((unsigned)bp);
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bp >> 32));  // (the builtin returns int:
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)bp);          //  no sign extension, please)
+    const unsigned long long bps = ((unsigned long long)bhi << 32) | blo;
     asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bw) : "s"(bps) : "memory");
     unsigned behind = 0;
 #pragma unroll
