@@ -5,6 +5,7 @@
  *   A3  sequence collection, orientation, XXH64 dedup src/smooth.cpp:676-743
  *   A4  padding size                                  src/smooth.cpp:1946-1970
  *   A14 adaptive POA scores per block (-a)            src/smooth.cpp:1972-2069
+ *   A8' MSA -> MAF rows of a block (-m)               src/smooth.cpp:782-905, src/maf.hpp:35-66
  *   A9  build_odgi_SPOA (POA graph -> block graph)    src/smooth.cpp:2576-2654
  *   A10 unchop + topological order + re-copy          src/smooth.cpp:935-1010
  *   8f-1 lacing of the block graphs + GFA writer      src/main.cpp:599-1061
@@ -92,6 +93,20 @@ int sxg_block_identity_threshold(const sxg_graph *g, const sxg_blockset *b, int6
 int sxg_block_graph_gfa(const sxg_graph *g, const sxg_blockset *b, int64_t block_id,
                         const sxg_smooth_params *p, sxg_poa_run_fn run, sxg_poa_free_fn fre, void *ctx,
                         char **out_gfa);
+
+/* MAF rows of one block (src/smooth.cpp:782-905): the block's MSA (consensus row last when
+ * add_consensus) with the padding blanked (first/last poa_padding non-gap characters of every row),
+ * all-gap flank columns trimmed, and one record per (sequence, duplicate) in the reference's emission
+ * order, as text lines  "<src>\t<start>\t<size>\t<+|->\t<srcSize>\t<text>".  For a reverse range
+ * start counts from the end of the path (MAF convention, :873-876). */
+int sxg_block_maf_rows(const sxg_graph *g, const sxg_blockset *b, int64_t block_id, const sxg_smooth_params *p,
+                       sxg_poa_run_fn run, sxg_poa_free_fn fre, void *ctx, char **out_rows);
+
+/* The same rows as one MAF block, formatted as write_maf_rows does (src/maf.hpp:35-66: "s " lines,
+ * columns padded to the widest entry, a blank line at the end).  The reference walks a hash map there,
+ * so its order of sources is unspecified; here sources appear in first-emission order. */
+int sxg_block_maf(const sxg_graph *g, const sxg_blockset *b, int64_t block_id, const sxg_smooth_params *p,
+                  sxg_poa_run_fn run, sxg_poa_free_fn fre, void *ctx, char **out_maf);
 
 /* One smoothing iteration over all blocks: collect -> ONE batched POA call -> block graphs ->
  * lace -> validate (every path spells its original sequence, src/main.cpp:770-810) -> unchop ->

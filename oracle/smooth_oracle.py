@@ -367,6 +367,75 @@ def build_block_graph(c, node_code, seq_paths, cons, consensus_name):
     return G
 
 
+# ---- MSA -> MAF rows (src/smooth.cpp:782-905) and the MAF block text (src/maf.hpp:35-66)
+def poa_msa(c, add_consensus, m=1, n=4, g=6, e=2, q=26, cc=1, local=True):
+    seqs = [np.array([CODE.get(ch, 4) for ch in s], np.uint8) for s in c.seqs]
+    G, _, _ = O.block_run(seqs, c.weights, O.mkparams(m, -n, -g, -e, -q, -cc, 0 if local else 1))
+    return G.msa(add_consensus), len(G.consensus())
+
+
+def maf_rows(g, ranges, c, msa, consensus_name, consensus_len):
+    """[(src, start, size, is_rev, src_size, text)] in the reference's emission order."""
+    if not msa:
+        return []
+    msa = [list(r) for r in msa]
+    L, pad = len(msa[0]), c.poa_padding
+    for r in msa:
+        left, j = pad, 0
+        while left > 0:
+            if r[j] != "-":
+                r[j] = "-"
+                left -= 1
+            j += 1
+        left, j = pad, L
+        while left > 0:
+            j -= 1
+            if r[j] != "-":
+                r[j] = "-"
+                left -= 1
+    has = [any(r[col] != "-" for r in msa) for col in range(L)]
+    b0 = next((k for k in range(L) if has[k]), L)
+    e0 = next((k for k in range(L - 1, -1, -1) if has[k]), -1) + 1
+    rows, n = [], len(msa)
+    for rank in range(n):
+        is_cons = bool(consensus_name) and rank == n - 1
+        for x in range(1 if is_cons else len(c.dup_rank[rank])):
+            if not is_cons:
+                p, b, e, _ = ranges[c.dup_rank[rank][x]]
+                rev = c.dup_is_revs[rank][x]
+                plen = g.pos[p][-1]
+                last = e - 1
+                start = plen - g.pos[p][last] - len(g.seq[g.steps[p][last] >> 1]) if rev else g.pos[p][b]
+                rows.append((g.pname[p], start, len(c.seqs[rank]) - 2 * pad, rev, plen, "".join(msa[rank][b0:e0]) if b0 < e0 else ""))
+            else:
+                rows.append((consensus_name, 0, consensus_len - 2 * pad, False, consensus_len - 2 * pad,
+                             "".join(msa[rank][b0:e0]) if b0 < e0 else ""))
+    return rows
+
+
+def maf_rows_text(rows):
+    return "".join("%s\t%d\t%d\t%s\t%d\t%s\n" % (s, st, sz, "-" if rv else "+", ps, tx) for (s, st, sz, rv, ps, tx) in rows)
+
+
+def maf_block_text(rows):
+    """src/maf.hpp:35-66; sources in first-emission order (the reference's hash-map order is unspecified)."""
+    w_src = max((len(r[0]) for r in rows), default=0)
+    w_start = max((len(str(r[1])) for r in rows), default=0)
+    w_size = max((len(str(r[2])) for r in rows), default=0)
+    w_ps = max((len(str(r[4])) for r in rows), default=0)
+    order = []
+    for r in rows:
+        if r[0] not in order:
+            order.append(r[0])
+    out = ""
+    for src in order:
+        for (s, st, sz, rv, ps, tx) in rows:
+            if s == src:
+                out += "s " + s.ljust(w_src) + str(st).rjust(w_start + 1) + str(sz).rjust(w_size + 1) + ("-" if rv else "+").rjust(2) + \
+                       str(ps).rjust(w_ps + 1) + " " + tx + "\n"
+    return out + "\n"
+
+
 # ---- A14: adaptive POA scores (src/smooth.cpp:1972-2069).  rkmh/mkmh are absent from the snapshot:
 # the identity estimate is by decree the exact canonical-k-mer Jaccard turned into a mash distance.
 _COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}

@@ -455,6 +455,85 @@ sxg_poa_params block_poa_params(const sxg_graph& g, const std::vector<path_range
     return poa_params(q);
 }
 
+// ---------------------------------------------------------------------------------------------
+// MSA -> MAF rows: src/smooth.cpp:782-905
+struct maf_row_t { std::string src; uint64_t start, size; bool rev; uint64_t src_size; std::string text; };
+
+std::vector<maf_row_t> maf_rows_from_msa(const sxg_graph& g, const std::vector<path_range_t>& ranges, const collected_t& c,
+                                         std::vector<std::string> msa, const std::string& consensus_name, size_t consensus_len) {
+    std::vector<maf_row_t> rows;
+    if (msa.empty()) return rows;
+    const bool add_consensus = !consensus_name.empty();
+    const size_t msa_l = msa[0].size();
+    const uint64_t pad = (uint64_t)c.poa_padding;
+    for (auto& r : msa) {  // :791-812 blank the padding
+        size_t j = 0;
+        for (uint64_t left = pad; left > 0; ++j)
+            if (r[j] != '-') { r[j] = '-'; --left; }
+        j = msa_l;
+        for (uint64_t left = pad; left > 0;) {
+            --j;
+            if (r[j] != '-') { r[j] = '-'; --left; }
+        }
+    }
+    auto col_has_letter = [&](size_t col) { for (auto& r : msa) if (r[col] != '-') return true; return false; };
+    size_t b0 = 0;                       // :815-829
+    while (b0 < msa_l && !col_has_letter(b0)) ++b0;
+    int64_t e0 = (int64_t)msa_l - 1;     // :832-847
+    while (e0 >= 0 && !col_has_letter((size_t)e0)) --e0;
+    e0 += 1;
+    const size_t num_seqs = msa.size();
+    for (size_t rank = 0; rank < num_seqs; ++rank) {
+        const bool is_cons = add_consensus && rank == num_seqs - 1;
+        const size_t ndup = is_cons ? 1 : c.dup_rank_in_path_ranges[rank].size();  // :772-779 placeholder entry
+        for (size_t x = 0; x < ndup; ++x) {
+            maf_row_t row;
+            if (!is_cons) {  // :861-880
+                const path_range_t& pr = ranges[c.dup_rank_in_path_ranges[rank][x]];
+                row.src = g.pname[pr.path];
+                row.rev = c.dup_is_revs[rank][x];
+                row.src_size = g.pos[pr.path].back();
+                const uint64_t last = pr.end - 1;
+                row.start = row.rev ? row.src_size - g.pos[pr.path][last] - g.seq[nid(g.steps[pr.path][last])].size() : g.pos[pr.path][pr.begin];
+                row.size = c.seqs[rank].size() - 2 * pad;
+            } else {         // :881-889
+                row.src = consensus_name; row.rev = false; row.src_size = consensus_len - 2 * pad; row.start = 0; row.size = row.src_size;
+            }
+            row.text = (int64_t)b0 < e0 ? msa[rank].substr(b0, (size_t)e0 - b0) : std::string();
+            rows.push_back(row);
+        }
+    }
+    return rows;
+}
+std::string maf_rows_text(const std::vector<maf_row_t>& rows) {
+    std::string o;
+    for (auto& r : rows)
+        o += r.src + "\t" + std::to_string(r.start) + "\t" + std::to_string(r.size) + "\t" + (r.rev ? "-" : "+") + "\t" + std::to_string(r.src_size) +
+             "\t" + r.text + "\n";
+    return o;
+}
+std::string maf_block_text(const std::vector<maf_row_t>& rows) {  // src/maf.hpp:35-66
+    size_t w_src = 0, w_start = 0, w_size = 0, w_srcsize = 0;
+    std::vector<std::string> order;
+    for (auto& r : rows) {
+        w_src = std::max(w_src, r.src.size());
+        w_start = std::max(w_start, std::to_string(r.start).size());
+        w_size = std::max(w_size, std::to_string(r.size).size());
+        w_srcsize = std::max(w_srcsize, std::to_string(r.src_size).size());
+        if (std::find(order.begin(), order.end(), r.src) == order.end()) order.push_back(r.src);
+    }
+    auto setw = [](const std::string& v, size_t w) { return (v.size() < w ? std::string(w - v.size(), ' ') : std::string()) + v; };
+    std::string o;
+    for (auto& src : order)
+        for (auto& r : rows) {
+            if (r.src != src) continue;
+            o += "s " + r.src + std::string(w_src - r.src.size(), ' ') + setw(std::to_string(r.start), w_start + 1) +
+                 setw(std::to_string(r.size), w_size + 1) + setw(r.rev ? "-" : "+", 2) + setw(std::to_string(r.src_size), w_srcsize + 1) + " " +
+                 r.text + "\n";
+        }
+    return o + "\n";
+}
+
 std::string cons_name(const sxg_smooth_params& p, int64_t block_id) {
     if (!p.add_consensus) return "";
     return std::string(p.consensus_base_name ? p.consensus_base_name : "Consensus_") + std::to_string(block_id);
@@ -611,6 +690,53 @@ int sxg_block_graph_gfa(const sxg_graph* g, const sxg_blockset* b, int64_t block
     const ograph_t G = block_graph_from_out(c, B, out, 0, cons_name(*p, block_id));
     if (fre) fre(&out);
     *out_gfa = dup_out(to_gfa(G));
+    return SXG_OK;
+}
+
+static int block_maf_rows(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, const sxg_smooth_params* p, sxg_poa_run_fn run,
+                          sxg_poa_free_fn fre, void* ctx, std::vector<maf_row_t>& rows) {
+    if (!g || !b || !p || !run || block_id < 0 || block_id >= (int64_t)b->blocks.size()) return fail(SXG_E_INVALID, "bad argument");
+    const collected_t c = collect(*g, b->blocks[block_id], *p);
+    rows.clear();
+    if (c.seqs.empty()) return SXG_OK;
+    batch_t B;
+    add_to_batch(B, c);
+    const sxg_poa_params pp = block_poa_params(*g, b->blocks[block_id], *p);
+    sxg_poa_batch_in in;
+    memset(&in, 0, sizeof(in));
+    in.n_blocks = 1; in.blk_off = B.blk_off.data(); in.seq_off = B.seq_off.data(); in.bases = B.bases.data();
+    in.weights = B.weights.data(); in.params = &pp; in.want_consensus = p->add_consensus; in.want_msa = 1;
+    sxg_poa_batch_out out;
+    memset(&out, 0, sizeof(out));
+    const int rc = run(ctx, &in, &out);
+    if (rc != SXG_OK) return fail(rc, "POA provider failed");
+    if (!out.msa || !out.msa_off || !out.msa_cols) { if (fre) fre(&out); return fail(SXG_E_INVALID, "POA provider returned no MSA"); }
+    const size_t nrow = c.seqs.size() + (p->add_consensus ? 1 : 0), cols = (size_t)out.msa_cols[0];
+    std::vector<std::string> msa;
+    for (size_t r = 0; r < nrow; ++r) msa.emplace_back(out.msa + out.msa_off[0] + r * cols, cols);
+    const size_t cons_len = out.cons_off ? (size_t)(out.cons_off[1] - out.cons_off[0]) : 0;
+    if (fre) fre(&out);
+    rows = maf_rows_from_msa(*g, b->blocks[block_id], c, msa, cons_name(*p, block_id), cons_len);
+    return SXG_OK;
+}
+
+int sxg_block_maf_rows(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, const sxg_smooth_params* p, sxg_poa_run_fn run,
+                       sxg_poa_free_fn fre, void* ctx, char** out_rows) {
+    if (!out_rows) return fail(SXG_E_INVALID, "NULL argument");
+    std::vector<maf_row_t> rows;
+    const int rc = block_maf_rows(g, b, block_id, p, run, fre, ctx, rows);
+    if (rc != SXG_OK) return rc;
+    *out_rows = dup_out(maf_rows_text(rows));
+    return SXG_OK;
+}
+
+int sxg_block_maf(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, const sxg_smooth_params* p, sxg_poa_run_fn run,
+                  sxg_poa_free_fn fre, void* ctx, char** out_maf) {
+    if (!out_maf) return fail(SXG_E_INVALID, "NULL argument");
+    std::vector<maf_row_t> rows;
+    const int rc = block_maf_rows(g, b, block_id, p, run, fre, ctx, rows);
+    if (rc != SXG_OK) return rc;
+    *out_maf = dup_out(maf_block_text(rows));
     return SXG_OK;
 }
 

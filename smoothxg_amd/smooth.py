@@ -26,7 +26,8 @@ class SmoothParams(C.Structure):
 EXPORTS = ["sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_free", "sxg_graph_from_gfa",
            "sxg_graph_free", "sxg_graph_node_count", "sxg_graph_path_count", "sxg_blockset_by_path_windows",
            "sxg_blockset_free", "sxg_blockset_size", "sxg_block_collect_text", "sxg_block_graph_gfa",
-           "sxg_smooth_gfa", "sxg_adaptive_poa_scores", "sxg_block_identity_threshold"]
+           "sxg_smooth_gfa", "sxg_adaptive_poa_scores", "sxg_block_identity_threshold",
+           "sxg_block_maf_rows", "sxg_block_maf"]
 
 
 def load_library():
@@ -54,6 +55,8 @@ def load_library():
     L.sxg_block_collect_text.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), C.POINTER(vp)]
     L.sxg_block_graph_gfa.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
     L.sxg_smooth_gfa.argtypes = [vp, vp, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
+    L.sxg_block_maf_rows.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
+    L.sxg_block_maf.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
     L.sxg_adaptive_poa_scores.restype = None
     L.sxg_adaptive_poa_scores.argtypes = [C.c_float, C.POINTER(C.c_int32 * 6), C.POINTER(C.c_int32 * 6)]
     L.sxg_block_identity_threshold.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -144,6 +147,16 @@ class Smoother:
         run, fre, ctx = provider
         out = C.c_void_p()
         return self._text(self.L.sxg_block_graph_gfa(self.g, self.b, block_id, C.byref(params), run, fre, ctx, C.byref(out)), out)
+
+    def block_maf_rows(self, block_id, params, provider):
+        run, fre, ctx = provider
+        out = C.c_void_p()
+        return self._text(self.L.sxg_block_maf_rows(self.g, self.b, block_id, C.byref(params), run, fre, ctx, C.byref(out)), out)
+
+    def block_maf(self, block_id, params, provider):
+        run, fre, ctx = provider
+        out = C.c_void_p()
+        return self._text(self.L.sxg_block_maf(self.g, self.b, block_id, C.byref(params), run, fre, ctx, C.byref(out)), out)
 
     def smooth_gfa(self, params, provider):
         run, fre, ctx = provider

@@ -72,3 +72,18 @@ def test_adaptive_scores_reach_the_gpu_per_block(engine, sub):
     out = SO.Graph(got)
     for q, nm in enumerate(g.pname):
         assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+@pytest.mark.parametrize("cons", [0, 1])
+def test_maf_rows_from_the_gpu_msa(engine, cons):
+    """MSA -> MAF rows (src/smooth.cpp:782-905) with the MSA coming from the GPU engine."""
+    text = open(DRB1).read()
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 900)
+    blocks = SO.blockset_by_path_windows(g, 900)
+    p = S.default_params(add_consensus=cons)
+    for k in (0, 4, 8):
+        c = SO.collect(g, blocks[k])
+        msa, clen = SO.poa_msa(c, bool(cons))
+        rows = SO.maf_rows(g, blocks[k], c, msa, ("Consensus_%d" % k) if cons else "", clen)
+        assert sm.block_maf(k, p, S.gpu_provider(engine)) == SO.maf_block_text(rows)

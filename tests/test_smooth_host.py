@@ -36,6 +36,7 @@ class OracleProvider:
         bases = np.ctypeslib.as_array(i.bases, (max(int(so[-1]), 1),)).copy()
         w = np.ctypeslib.as_array(i.weights, (max(ns, 1),)).copy() if i.weights else np.ones(max(ns, 1), np.uint32)
         node_off, cons_off, codes, paths, cons = [0], [0], [], [], []
+        msa_off, msa_cols, msa_txt = [0], [], b""
         for b in range(nb):
             pr = i.params[b if i.per_block_params else 0]
             par = O.mkparams(pr.m, pr.n, pr.g, pr.e, pr.q, pr.c, pr.mode)
@@ -45,12 +46,20 @@ class OracleProvider:
                 codes.append(g.nodes()[0])
                 paths += [g.seq_path(k) for k in range(len(seqs))]
                 cons.append(g.consensus())
+                if i.want_msa:
+                    rows = g.msa(bool(i.want_consensus))
+                    msa_cols.append(len(rows[0]))
+                    msa_txt += "".join(rows).encode()
+            if not seqs or not i.want_msa:
+                msa_cols.append(0)
+            msa_off.append(len(msa_txt))
             node_off.append(node_off[-1] + (len(codes[-1]) if seqs else 0))
             cons_off.append(cons_off[-1] + (len(cons[-1]) if seqs else 0))
         cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs) if xs else np.zeros(1, dt), dt)
         arrs = dict(node_off=np.asarray(node_off, np.int64), cons_off=np.asarray(cons_off, np.int64),
                     node_code=cat(codes, np.uint8), paths=cat(paths, np.int32), cons=cat(cons, np.int32),
-                    status=np.zeros(max(nb, 1), np.int32))
+                    status=np.zeros(max(nb, 1), np.int32), msa_off=np.asarray(msa_off, np.int64),
+                    msa_cols=np.asarray(msa_cols[:max(nb, 1)] or [0], np.int32), msa=np.frombuffer(msa_txt + b"\0", np.uint8).copy())
         self.keep.append(arrs)
         o.n_blocks, o.n_seqs = nb, ns
         o.status = arrs["status"].ctypes.data_as(C.POINTER(C.c_int32))
@@ -59,6 +68,10 @@ class OracleProvider:
         o.seq_path_nodes = arrs["paths"].ctypes.data_as(C.POINTER(C.c_int32))
         o.cons_off = arrs["cons_off"].ctypes.data_as(C.POINTER(C.c_int64))
         o.cons_nodes = arrs["cons"].ctypes.data_as(C.POINTER(C.c_int32))
+        if i.want_msa:
+            o.msa_off = arrs["msa_off"].ctypes.data_as(C.POINTER(C.c_int64))
+            o.msa_cols = arrs["msa_cols"].ctypes.data_as(C.POINTER(C.c_int32))
+            o.msa = arrs["msa"].ctypes.data
         return 0
 
     def _free(self, pout):
@@ -260,6 +273,40 @@ def test_adaptive_iteration_high_identity_tiers(prov, sub, tier):
     out = SO.Graph(got)
     for q, nm in enumerate(g.pname):
         assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+@pytest.mark.parametrize("cons", [0, 1])
+def test_maf_rows_match_oracle(prov, cons):
+    """MSA -> MAF rows (src/smooth.cpp:782-905) and the MAF block text (src/maf.hpp:35-66): synthetic
+    graphs with reverse steps (strand '-', start counted from the path's end) and DRB1 blocks."""
+    cases = [(synthetic_gfa(4, n_paths=6, n_nodes=80), 150, None), (synthetic_gfa(5, n_paths=6, n_nodes=80), 400, None),
+             (open(DRB1).read(), 700, (0, 9))]
+    seen_rev = False
+    for text, target, pick in cases:
+        g = SO.Graph(text)
+        sm = S.Smoother(text, target)
+        blocks = SO.blockset_by_path_windows(g, target)
+        p = S.default_params(add_consensus=cons)
+        for k in (pick if pick else range(min(len(blocks), 4))):
+            c = SO.collect(g, blocks[k])
+            if not c.seqs:
+                assert sm.block_maf_rows(k, p, prov.provider()) == ""
+                continue
+            msa, clen = SO.poa_msa(c, bool(cons))
+            rows = SO.maf_rows(g, blocks[k], c, msa, ("Consensus_%d" % k) if cons else "", clen)
+            seen_rev |= any(r[3] for r in rows)
+            assert sm.block_maf_rows(k, p, prov.provider()) == SO.maf_rows_text(rows)
+            maf = sm.block_maf(k, p, prov.provider())
+            assert maf == SO.maf_block_text(rows)
+            # every record spells the unpadded sequence of its range, in the record's strand
+            for (src, start, size, rev, psize, txt), line in zip(rows, [l for l in maf.split("\n") if l.startswith("s ")]):
+                letters = txt.replace("-", "")
+                assert len(letters) == size
+                if not src.startswith("Consensus_"):
+                    full = g.path_sequence(g.pname.index(src))
+                    want = SO.revcomp(full)[start:start + size] if rev else full[start:start + size]
+                    assert letters == want
+    assert seen_rev
 
 
 def test_unchop_and_order_decrees():
