@@ -228,6 +228,12 @@ __host__ __device__ constexpr int dp_lds_bytes(int Lpad, int word_bytes) {
 __host__ __device__ constexpr bool dp_park_in_lds(int Lpad, int word_bytes) {
     return Lpad * word_bytes <= 64 * 1024;
 }
+// packed sweep: descriptors + parked row (8 B per lane and column = 4 B per padded column) + the
+// query letters of every lane (one word per two columns, rounded up for odd strip widths)
+__host__ __device__ constexpr int dp16_let_words(int W) { return (W + 1) / 2; }
+__host__ __device__ constexpr int dp16_lds_bytes(int T, int W) {
+    return LDS_CTL_BYTES + LDS_META_BYTES + T * W * 8 + T * dp16_let_words(W) * 4;
+}
 __host__ __device__ constexpr int dp_lds_launch_bytes(int Lpad, int word_bytes) {
     return dp_park_in_lds(Lpad, word_bytes) ? dp_lds_bytes(Lpad, word_bytes) : LDS_CTL_BYTES + LDS_META_BYTES;
 }

@@ -78,7 +78,6 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     constexpr unsigned ALL = ((1u << W) - 1u) * 0x00010001u;
     int* lds = (int*)smem;
     const i32x4* lmeta = (const i32x4*)(smem + LDS_CTL_BYTES);
-    u32x2* lrow = (u32x2*)(smem + LDS_CTL_BYTES + LDS_META_BYTES);  // parked register row (>= 3 preds)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int j0 = t * W;           // first column of my lo strip; hi strip starts at TW + j0
     // scoring values are block-uniform: keep them (and everything derived) in SGPRs
@@ -108,6 +107,15 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         }
         let[k2] = v;
     }
+    // The letters live in LDS, not in registers: six loop-invariant VGPRs less, which is what the
+    // allocator otherwise evicts to scratch around the multi-predecessor path -- and a scratch reload
+    // is an in-order vmcnt wait behind the fold-step stores just issued.  Lane-major, read back with
+    // two wide LDS loads per row.
+    // (raw LDS byte offset: the dynamic LDS starts right behind the kernel's static LDS)
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    const unsigned llet_off = (unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)(LDS_CTL_BYTES + LDS_META_BYTES + TW * 8 + t * NL * 4);
+#pragma unroll
+    for (int k2 = 0; k2 < NL; ++k2) ((lds_u32*)(size_t)llet_off)[k2] = let[k2];
 
     // Rows in HBM (ring, row 0) are laid out [column-in-strip][lane] and the mask plane
     // [row][word][lane]: a load/store instruction then covers 64 consecutive words of a wave
@@ -187,8 +195,6 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         const int tx = __builtin_amdgcn_readfirstlane(m1.w);
         const int np = info & 0xffff, code = (info >> 16) & 0xff, flags = (info >> 24) & 0xff;
         const unsigned CODE4 = (unsigned)code * 0x01010101u;
-#pragma unroll
-        for (int k2 = 0; k2 < NL; ++k2) SXG_PIN("+v"(let[k2]));
 
 #ifdef SXG_ROW_PROF
         unsigned long long rt_ = __builtin_readcyclecounter();
@@ -227,9 +233,16 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         } else {
             const bool reg0 = (p0 == i - 1), reg1 = (np == 2 && p1 == i - 1);
             const bool park = np >= 3;
+            // my slice of the parked row, as a raw LDS offset rebuilt from an opaque t (one loop-invariant
+            // address register less to spill around this path)
+            typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+            int tp_ = t;
+            asm volatile("" : "+v"(tp_));
+            lds_u32x2* const lrow_t = (lds_u32x2*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() +
+                                                           (unsigned)(LDS_CTL_BYTES + LDS_META_BYTES) + (unsigned)(tp_ * W) * 8u);
             if (park) {
 #pragma unroll
-                for (int k = 0; k < W; ++k) lrow[j0 + k] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
+                for (int k = 0; k < W; ++k) lrow_t[k] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
             }
             const int ge = reg1 ? 1 : 0;
             const int GE2 = ge ? ONE2 : 0;
@@ -243,7 +256,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                 int hl = Hleft;
                 if (reg0) {
 #pragma unroll
-                    for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
+                    for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];
                 } else P16_FETCH(p0, s0, wr, hl);
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
@@ -268,7 +281,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                 int hl = Hleft;
                 if (p == i - 1) {
 #pragma unroll
-                    for (int k = 0; k < W; ++k) wr[k] = lrow[j0 + k];
+                    for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];
                 } else P16_FETCH(p, sl, wr, hl);
                 // take-over test "cand + ge > cur" = sign of (cur - cand - ge); the value is the max
                 // either way (on a tie both are equal); masks: xor as in the 32-bit sweep
@@ -317,6 +330,12 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         }
 
         RP_MARK(0);  // predecessor rows read, F/O/diagonal set up
+        {   // this row's copy of my query letters (an opaque address keeps the loads inside the loop)
+            unsigned lo_ = llet_off;
+            asm volatile("" : "+v"(lo_));
+#pragma unroll
+            for (int k2 = 0; k2 < NL; ++k2) let[k2] = ((lds_u32*)(size_t)lo_)[k2];
+        }
         // ---- pass 1: H before the in-row gaps, strip-local carries
         unsigned gtf = 0, gto = 0;  // F / O strictly beat the running maximum
         int a = NEG2, b = NEG2;

@@ -727,7 +727,7 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
-    if (V.RM == 2) { P.smem = dp_lds_bytes(Lpad, wb); P.park_lds = true; }  // packed sweep parks in LDS only
+    if (V.RM == 2) { P.smem = dp16_lds_bytes(V.T(), V.W); P.park_lds = true; }  // packed sweep parks in LDS only
     P.pf_off = (V.RM != 2 && getenv("SXG_POA_PREFETCH")) ? dp_pf_offset(Lpad, wb, V.T()) : -1;
     if (P.pf_off >= 0) P.smem += dp_pf_bytes(Lpad, wb, V.T());
     if (P.smem > 48 * 1024)
@@ -1232,7 +1232,7 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
                                             (int)maxe + 8, V.T(), V.Lpad(), wb, true, V.RM == 2);
         auto kern = align_kernel(pl.variant, pl.cvx, pl.sw);
         int per_cu = 1;
-        int smem = V.RM == 2 ? dp_lds_bytes(V.Lpad(), wb) : dp_lds_launch_bytes(V.Lpad(), wb);
+        int smem = V.RM == 2 ? dp16_lds_bytes(V.T(), V.W) : dp_lds_launch_bytes(V.Lpad(), wb);
         const int pf_off = (V.RM != 2 && getenv("SXG_POA_PREFETCH")) ? dp_pf_offset(V.Lpad(), wb, V.T()) : -1;
         if (pf_off >= 0) smem += dp_pf_bytes(V.Lpad(), wb, V.T());
         if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
