@@ -1,0 +1,55 @@
+"""Fold the outputs of profiles/run_pmc.sh and profiles/run_sq_pmc.sh (gpurun_out/) into the tracked
+evidence: profiles/<round>/ns_sw_* and profiles/traffic.json.  Usage: python profiles/tools/collect.py r01"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, "gpurun_out")
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+dst = os.path.join(ROOT, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(OUT, "prof_stats", "*kernel_stats.csv"))[0]
+row = [r for r in csv.DictReader(open(stats)) if "poa_block" in r["Name"]][0]
+vals = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(os.path.join(OUT, "prof_pmc_" + c, "*counter_collection.csv"))[0]
+    vals[c] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                  if "poa_block" in r["Kernel_Name"] and r["Counter_Name"] == c)
+    shutil.copy(f, os.path.join(dst, "ns_sw_pmc_%s.csv" % c))
+shutil.copy(stats, os.path.join(dst, "ns_sw_kernel_stats.csv"))
+F, W = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+traffic = {"ns_sw": {
+    "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python bench.py --workload ns "
+               "--steps 1 --warmup 0 --no-cpu-baseline (profiles/run_pmc.sh)",
+    "kernel": row["Name"], "kernel_ms_avg_rocprof": float(row["AverageNs"]) / 1e6,
+    "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W,
+    "correction": "MI355X_MICROARCH.md HBM section: counters are KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide "
+                  "coalesced streaming reads (calibrated there for 16 B/lane; the row ring is read 8 B/lane, 512 B per wave "
+                  "instruction, which the guide lists as uncalibrated) -> FETCH doubled as the conservative reading; "
+                  "WRITE_SIZE taken as is (uncalibrated)",
+    "hbm_bytes_per_launch": (2 * F + W) * 1024, "hbm_bytes_per_launch_uncorrected": (F + W) * 1024}}
+json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+
+agg = {}
+for d in sorted(glob.glob(os.path.join(OUT, "pmc16_*/"))):
+    for f in glob.glob(d + "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "poa_block" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]] = agg.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+if agg:
+    json.dump({"command": "profiles/run_sq_pmc.sh (one launch of the ns workload, kernel %s)" % row["Name"], "counters": agg},
+              open(os.path.join(dst, "ns_sw_sq_counters.json"), "w"), indent=1)
+b = os.path.join(OUT, "bench_ns_sw.json")
+if os.path.exists(b):
+    d = json.loads(open(b).read().strip().splitlines()[-1])
+    d["roofline"]["traffic"] = traffic["ns_sw"]["hbm_bytes_per_launch"]
+    open(os.path.join(dst, "bench_ns_sw.json"), "w").write(json.dumps(d) + "\n")
+    print("bench: %.1f %s, kernel %.1f ms, frac %.3f" % (d["value"], d["unit"], d["roofline"]["kernel_ms_per_launch"], d["roofline"]["frac"]))
+print("rocprof kernel avg %.1f ms; HBM bytes/launch %.3e (uncorrected %.3e); VALU instrs %.3e" % (
+    traffic["ns_sw"]["kernel_ms_avg_rocprof"], traffic["ns_sw"]["hbm_bytes_per_launch"],
+    traffic["ns_sw"]["hbm_bytes_per_launch_uncorrected"], agg.get("SQ_INSTS_VALU", float("nan"))))
