@@ -10,7 +10,7 @@
 // What changes with packing:
 //  * no packed compare exists, so every "which candidate won" bit is the SIGN of a packed
 //    difference, shifted into bit k (lo strip) / bit 16+k (hi strip) of a per-row mask word;
-//  * the traceback plane stores those mask words (9 per lane per row) instead of one byte per
+//  * the traceback plane stores those mask words (8 per lane per row) instead of one byte per
 //    cell; the 6-way source of H is resolved from "strictly beat the running maximum" bits in
 //    priority order Q > E > O > F > D at traceback time;
 //  * rows carry OUTGOING gap candidates (max(H+g, F+e), max(H+q, O+c)) instead of F and O: computed
@@ -30,9 +30,11 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NEGP = -16384;  // "minus infinity" of the packed sweep
-constexpr int P16_TB_WORDS = 9;
+constexpr int P16_TB_WORDS = 8;
 // mask words of one lane and row in the packed traceback plane
-enum : int { PM_STOP = 0, PM_GTF = 1, PM_GTO = 2, PM_GTE = 3, PM_GTQ = 4, PM_FX = 5, PM_OX = 6, PM_EX = 7, PM_QX = 8 };
+// (no STOP word: a local alignment stops where H is 0, and the traceback knows H of every cell it visits
+// -- it starts from the best score and undoes one recorded step at a time)
+enum : int { PM_GTF = 0, PM_GTO = 1, PM_GTE = 2, PM_GTQ = 3, PM_FX = 4, PM_OX = 5, PM_EX = 6, PM_QX = 7 };
 
 __device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b))); }
 __device__ __forceinline__ int pk_sub(int a, int b) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); }
@@ -399,7 +401,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         // ---- pass 2: final H and the remaining decision bits
         // exm/qxm: EXTEND bit of E/Q of column k; the decision made at column k belongs to column
         // k+1, so it goes straight to bit k+1 (bit W = the hand-over to the next lane)
-        unsigned gte = 0, gtq = 0, stp = 0, exm = 0, qxm = 0;
+        unsigned gte = 0, gtq = 0, exm = 0, qxm = 0;
         int rowmax = SW ? 0 : NEG2;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
@@ -407,7 +409,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             SXG_SIGN_TO(gte, pk_sub(h, E), k);
             h = pk_max(h, E);
             if (CVX) { SXG_SIGN_TO(gtq, pk_sub(h, Q), k); h = pk_max(h, Q); }
-            if (SW) { SXG_SIGN_TO(stp, pk_sub(h, ONE2), k); h = pk_max(h, 0); }
+            if (SW) h = pk_max(h, 0);
             Hc[k] = h;
             rowmax = pk_max(rowmax, h);
             const int c1 = pk_add(h, G2), c2 = pk_add(E, E2);
@@ -418,7 +420,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                 SXG_SIGN_TO(qxm, pk_sub(d1, d2), k + 1);
                 Q = pk_max(d1, d2);
             }
-            SXG_PIN("+v"(Hc[k]), "+v"(gte), "+v"(gtq), "+v"(stp), "+v"(exm), "+v"(qxm), "+v"(E), "+v"(Q), "+v"(rowmax));
+            SXG_PIN("+v"(Hc[k]), "+v"(gte), "+v"(gtq), "+v"(exm), "+v"(qxm), "+v"(E), "+v"(Q), "+v"(rowmax));
         }
         // hand my last column and the ext bits of the next column to the right neighbour; the lo
         // half's last lane feeds lane 0's hi strip
@@ -465,7 +467,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         // ---- stores
         {
             SXG_GLOBAL uint32_t* dst = g_tb + (size_t)i * P16_TB_WORDS * T;  // [row][word][lane]
-            (dst + PM_STOP * T)[ut] = stp; (dst + PM_GTF * T)[ut] = gtf; (dst + PM_GTO * T)[ut] = gto;
+            (dst + PM_GTF * T)[ut] = gtf; (dst + PM_GTO * T)[ut] = gto;
             (dst + PM_GTE * T)[ut] = gte; (dst + PM_GTQ * T)[ut] = gtq; (dst + PM_FX * T)[ut] = fxm;
             (dst + PM_OX * T)[ut] = oxm; (dst + PM_EX * T)[ut] = exm; (dst + PM_QX * T)[ut] = qxm;
         }
@@ -564,24 +566,35 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 // predecessor far up the order, the hi -> lo half crossing) or needs a fold-step plane of a
 // multi-predecessor row.
 constexpr int TBW_ROWS = 64;
-constexpr int TBW_STRIDE = 31;  // dwords per window row (odd: conflict-free fills)
-static_assert(TBW_ROWS * TBW_STRIDE * 4 <= LDS_META_BYTES, "traceback window lives in the descriptor area");
+constexpr int TBW_STRIDE = 29;  // dwords per window row (odd: conflict-free fills)
+// window row: 2 x P16_TB_WORDS mask words, then
+enum : int { EO_PB = 16, EO_INFO = 17, EO_Q0 = 18, EO_Q1 = 19, EO_NODE = 20, EO_STEP = 21 /* ..26 */, EO_TX = 27 };
+static_assert(2 * P16_TB_WORDS == EO_PB, "window row layout");
+static_assert((TBW_ROWS * TBW_STRIDE + TBW_ROWS) * 4 <= LDS_META_BYTES, "traceback window lives in the descriptor area");
 
+// H is tracked along the walk (hv): it starts at the end cell's score and every recorded step is undone
+// -- a diagonal step subtracts the letter score, leaving a gap state subtracts the opening cost, each
+// extension the extension cost.  A local alignment ends at the first H = 0 (STOP has top priority, S5), so
+// the sweep records no STOP bit.  The query letters of the window's diagonal ride along in the window.
 template <bool PAIRS, int W>
 // (views by value: a reference to the kernel's private copy trips an AMDGPU back-end assertion on
 // the private-aperture null check for some strip widths)
-__device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const int T, const int sw, int i, int j,
-                                          int32_t* posnode, int32_t* pair_row, int32_t* pair_pos, char* smem) {
+__device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const Scoring S, const uint8_t* seq, const int best,
+                                          const int T, int i, int j, int32_t* posnode, int32_t* pair_row, int32_t* pair_pos,
+                                          char* smem) {
     const int TW = T * W;
     const int lane = threadIdx.x & 63;
+    const int sw = S.sw;
     // the block's only serial phase (three waves wait for this one): a dependent-read chain that
     // rarely has an instruction ready, so top priority costs the co-residents next to nothing
     __builtin_amdgcn_s_setprio(3);
     uint32_t* win = (uint32_t*)(smem + LDS_CTL_BYTES);
+    uint32_t* wlet = win + TBW_ROWS * TBW_STRIDE;  // [64] query letters of columns jtop, jtop-1, ...
     // first of the two lane-columns fetched for a row whose expected (half-local) column is x
     auto col0 = [&](int x) -> int { return x < W / 2 ? 0 : min((x - W / 2) / W, T - 2); };
     int n = 0, st = SRC_STOP;
-    int wtop = -1, wjj = 0, whalf = -1;
+    int hv = best, gv = 0;  // H of the current cell (state H) / value of the gap state being walked
+    int wtop = -1, wjj = 0, whalf = -1, wj = 0;
     for (;;) {
         if (i == 0) {
             if (j == 0 || sw) break;
@@ -589,13 +602,14 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             ++n; --j;
             continue;
         }
+        if (sw && st == SRC_STOP && hv == 0) break;
         const int r = i - 1;
         const int half = j >= TW ? 1 : 0, jj = j - half * TW;
         const int lt = jj / W, bit = (jj - lt * W) + 16 * half;
         int l = wtop - i;
         int c0 = col0(wjj - l);
         if (wtop < 0 || l < 0 || l >= TBW_ROWS || half != whalf || (unsigned)(lt - c0) > 1u) {
-            wtop = i; wjj = jj; whalf = half;
+            wtop = i; wjj = jj; whalf = half; wj = j;
             const int row = i - lane;
             if (row >= 1) {
                 const int c = col0(jj - lane);
@@ -609,14 +623,15 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                 uint32_t* e = win + lane * TBW_STRIDE;
 #pragma unroll
                 for (int x = 0; x < 2 * P16_TB_WORDS; ++x) e[x] = v[x];
-                e[18] = (uint32_t)d0.x; e[19] = (uint32_t)d0.y; e[20] = (uint32_t)d0.z; e[21] = (uint32_t)d1.x;
-                e[22] = (uint32_t)node; e[29] = (uint32_t)d1.w;
+                e[EO_PB] = (uint32_t)d0.x; e[EO_INFO] = (uint32_t)d0.y; e[EO_Q0] = (uint32_t)d0.z; e[EO_Q1] = (uint32_t)d1.x;
+                e[EO_NODE] = (uint32_t)node; e[EO_TX] = (uint32_t)d1.w;
                 if ((d0.y & 0xffff) >= 2) {  // first fold step of a multi-predecessor row (D, F, O planes)
                     SXG_GLOBAL const uint32_t* sp = sxg_global((const uint32_t*)B.steps) + (size_t)d1.w * 3 * T + c;
 #pragma unroll
-                    for (int w3 = 0; w3 < 3; ++w3) { e[23 + 2 * w3] = sp[(size_t)w3 * T]; e[24 + 2 * w3] = sp[(size_t)w3 * T + 1]; }
+                    for (int w3 = 0; w3 < 3; ++w3) { e[EO_STEP + 2 * w3] = sp[(size_t)w3 * T]; e[EO_STEP + 1 + 2 * w3] = sp[(size_t)w3 * T + 1]; }
                 }
             }
+            wlet[lane] = (j - lane >= 1) ? (uint32_t)seq[j - lane - 1] : 255u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -624,46 +639,52 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
         }
         const uint32_t* e = win + l * TBW_STRIDE;
         const uint32_t* m = e + (lt - c0) * P16_TB_WORDS;
-        const int pb = (int)e[18], np = (int)(e[19] & 0xffffu), q0 = (int)e[20], q1 = (int)e[21], node = (int)e[22];
+        const int pb = (int)e[EO_PB], info = (int)e[EO_INFO], q0 = (int)e[EO_Q0], q1 = (int)e[EO_Q1], node = (int)e[EO_NODE];
+        const int np = info & 0xffff;
         auto pred_of = [&](int which) -> int {
             if (np == 0) return 0;
             if (np == 1) return q0;
-            const int tx = (int)e[29];
+            const int tx = (int)e[EO_TX];
             int ord = 0;
             for (int x = np - 1; x >= 2 && !ord; --x)
                 if ((sxg_global((const uint32_t*)B.steps)[((size_t)(tx + x - 1) * 3 + which) * T + lt] >> bit) & 1u) ord = x;
-            if (!ord) ord = (int)((e[23 + 2 * which + (lt - c0)] >> bit) & 1u);
+            if (!ord) ord = (int)((e[EO_STEP + 2 * which + (lt - c0)] >> bit) & 1u);
             return ord == 0 ? q0 : (ord == 1 ? q1 : sxg_global((const int32_t*)R.preds)[pb + ord]);
         };
         if (st == SRC_STOP) {
             int src;
-            if ((m[PM_STOP] >> bit) & 1u) src = SRC_STOP;
-            else if ((m[PM_GTQ] >> bit) & 1u) src = SRC_Q;
+            if ((m[PM_GTQ] >> bit) & 1u) src = SRC_Q;
             else if ((m[PM_GTE] >> bit) & 1u) src = SRC_E;
             else if ((m[PM_GTO] >> bit) & 1u) src = SRC_O;
             else if ((m[PM_GTF] >> bit) & 1u) src = SRC_F;
             else src = SRC_D;
-            if (src == SRC_STOP) break;
             if (src == SRC_D) {
                 if (lane == 0) {
                     if (PAIRS) { pair_row[n] = i; pair_pos[n] = j - 1; }
                     if (posnode) posnode[j - 1] = node;
                 }
                 ++n;
+                const unsigned wi = (unsigned)(wj - j);
+                const int letter = wi < (unsigned)TBW_ROWS ? (int)wlet[wi] : (int)seq[j - 1];
+                hv -= (letter == ((info >> 16) & 0xff)) ? S.m : S.n;
                 i = pred_of(0);
                 --j;
-            } else st = src;
+            } else { st = src; gv = hv; }
         } else if (st == SRC_F || st == SRC_O) {
-            const unsigned ext = (m[st == SRC_F ? PM_FX : PM_OX] >> bit) & 1u;
+            const bool isf = st == SRC_F;
+            const unsigned ext = (m[isf ? PM_FX : PM_OX] >> bit) & 1u;
             if (PAIRS && lane == 0) { pair_row[n] = i; pair_pos[n] = -1; }
             ++n;
-            i = pred_of(st == SRC_F ? 1 : 2);
-            if (!ext) st = SRC_STOP;
+            i = pred_of(isf ? 1 : 2);
+            if (ext) gv -= isf ? S.e : S.c;
+            else { hv = gv - (isf ? S.g : S.q); st = SRC_STOP; }
         } else {
-            const unsigned ext = (m[st == SRC_E ? PM_EX : PM_QX] >> bit) & 1u;
+            const bool ise = st == SRC_E;
+            const unsigned ext = (m[ise ? PM_EX : PM_QX] >> bit) & 1u;
             if (PAIRS && lane == 0) { pair_row[n] = 0; pair_pos[n] = j - 1; }
             ++n; --j;
-            if (!ext) st = SRC_STOP;
+            if (ext) gv -= ise ? S.e : S.c;
+            else { hv = gv - (ise ? S.g : S.q); st = SRC_STOP; }
         }
     }
     return n;

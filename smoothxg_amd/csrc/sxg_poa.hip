@@ -61,7 +61,7 @@ static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int s
     L.r_code = lay(cur, Rr); L.r_flags = lay(cur, Rr); L.r_pred_off = lay(cur, 4 * Rr);
     L.r_preds = lay(cur, 4 * C); L.r_slot = lay(cur, 4 * Rr); L.r_tbx = lay(cur, 4 * Rr);
     L.r_sseq = lay(cur, 4 * Rr); L.r_row_node = lay(cur, 4 * Rr); L.r_meta = lay(cur, 32 * Rr);
-    // traceback plane: one byte per cell, or (packed sweep) 9 mask words per lane and row
+    // traceback plane: one byte per cell, or (packed sweep) 8 mask words per lane and row
     L.tb = lay(cur, ((size_t)rows_cap + 1) * (packed ? (size_t)threads * P16_TB_WORDS * 4 : (size_t)Lpad));
     L.steps = lay(cur, (size_t)std::max(step_cap, 1) * 3 * threads * 4);
     L.pool = lay(cur, (size_t)pool_slots * Lpad * word_bytes);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                 __syncthreads();
                 PROF(2);
                 if constexpr (RM == 2) {  // wave 0 walks together (LDS window)
-                    if (t < 64 && res.bi >= 0) traceback_p16<false, W>(V.R, V.B, T, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr, smem);
+                    if (t < 64 && res.bi >= 0) traceback_p16<false, W>(V.R, V.B, S, seq, res.best, T, res.bi, res.bj, V.G.posnode, nullptr, nullptr, smem);
                 } else if (t == 0 && res.bi >= 0) traceback<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
                 score = res.bi >= 0 ? res.best : 0;
                 __syncthreads();
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
                 else dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 if constexpr (RM == 2) {
-                    if (t < 64 && res.bi >= 0) npairs = traceback_p16<true, W>(V.R, V.B, T, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos, smem);
+                    if (t < 64 && res.bi >= 0) npairs = traceback_p16<true, W>(V.R, V.B, S, A.bases + so, res.best, T, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos, smem);
                 } else if (t == 0 && res.bi >= 0) npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
                 if (t == 0 && res.bi >= 0) {
                     score = res.best;
