@@ -231,8 +231,12 @@ __host__ __device__ constexpr bool dp_park_in_lds(int Lpad, int word_bytes) {
 // packed sweep: descriptors + parked row (8 B per lane and column = 4 B per padded column) + the
 // query letters of every lane (one word per two columns, rounded up for odd strip widths)
 __host__ __device__ constexpr int dp16_let_words(int W) { return (W + 1) / 2; }
+// One- and two-wave workgroups (sequences up to ~3 kbp, the usual smoothxg block) are LDS-bound in
+// occupancy: they stage 128 row descriptors instead of 256 (and walk a 32-row traceback window),
+// 4 KB instead of 8 KB, which lets 14 instead of 10 of them share a CU.
+__host__ __device__ constexpr int dp16_meta_bytes(int T) { return T <= 128 ? LDS_META_BYTES / 2 : LDS_META_BYTES; }
 __host__ __device__ constexpr int dp16_lds_bytes(int T, int W) {
-    return LDS_CTL_BYTES + LDS_META_BYTES + T * W * 8 + T * dp16_let_words(W) * 4;
+    return LDS_CTL_BYTES + dp16_meta_bytes(T) + T * W * 8 + T * dp16_let_words(W) * 4;
 }
 __host__ __device__ constexpr int dp_lds_launch_bytes(int Lpad, int word_bytes) {
     return dp_park_in_lds(Lpad, word_bytes) ? dp_lds_bytes(Lpad, word_bytes) : LDS_CTL_BYTES + LDS_META_BYTES;

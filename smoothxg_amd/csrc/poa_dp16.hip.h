@@ -77,6 +77,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     const int T = (int)blockDim.x;
     const int NW = T >> 6;
     const int TW = T * W;           // columns of one half
+    const int MB = dp16_meta_bytes(T), CH = MB / 32;  // descriptor staging area: bytes, rows per chunk
     constexpr unsigned ALL = ((1u << W) - 1u) * 0x00010001u;
     int* lds = (int*)smem;
     const i32x4* lmeta = (const i32x4*)(smem + LDS_CTL_BYTES);
@@ -115,7 +116,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     // two wide LDS loads per row.
     // (raw LDS byte offset: the dynamic LDS starts right behind the kernel's static LDS)
     typedef __attribute__((address_space(3))) unsigned lds_u32;
-    const unsigned llet_off = (unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)(LDS_CTL_BYTES + LDS_META_BYTES + TW * 8 + t * NL * 4);
+    const unsigned llet_off = (unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)(LDS_CTL_BYTES + MB + TW * 8 + t * NL * 4);
 #pragma unroll
     for (int k2 = 0; k2 < NL; ++k2) ((lds_u32*)(size_t)llet_off)[k2] = let[k2];
 
@@ -178,15 +179,15 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         if (B.prio_board) { if ((i & 15) == 1) sxg_balance_prio(B, (unsigned long long)i * (unsigned long long)L); }
         else if ((i & 3) == 1) sxg_rotate_prio(B.prio_rank);
         const int r = i - 1;
-        if ((r & (META_CHUNK - 1)) == 0) {
+        if ((r & (CH - 1)) == 0) {
             __syncthreads();
             SXG_GLOBAL const i32x4* gm = (SXG_GLOBAL const i32x4*)(g_meta + 8 * (size_t)r);
             i32x4* lm = (i32x4*)(smem + LDS_CTL_BYTES);
-            const int nrow = min(META_CHUNK, N - r);
+            const int nrow = min(CH, N - r);
             for (int x = t; x < 2 * nrow; x += T) lm[x] = gm[x];
             __syncthreads();
         }
-        const i32x4 m0 = lmeta[2 * (r & (META_CHUNK - 1))], m1 = lmeta[2 * (r & (META_CHUNK - 1)) + 1];
+        const i32x4 m0 = lmeta[2 * (r & (CH - 1))], m1 = lmeta[2 * (r & (CH - 1)) + 1];
         const int pb = __builtin_amdgcn_readfirstlane(m0.x);
         const int info = __builtin_amdgcn_readfirstlane(m0.y);
         const int p0 = __builtin_amdgcn_readfirstlane(m0.z);
@@ -241,7 +242,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             int tp_ = t;
             asm volatile("" : "+v"(tp_));
             lds_u32x2* const lrow_t = (lds_u32x2*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() +
-                                                           (unsigned)(LDS_CTL_BYTES + LDS_META_BYTES) + (unsigned)(tp_ * W) * 8u);
+                                                           (unsigned)(LDS_CTL_BYTES + MB) + (unsigned)(tp_ * W) * 8u);
             if (park) {
 #pragma unroll
                 for (int k = 0; k < W; ++k) lrow_t[k] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
@@ -477,8 +478,8 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         // stored predecessor from here was tried: with the kernel at its 128-VGPR budget any spill
         // reload behind the request is an in-order vmcnt wait on it, and the row got slower.)
         next_sib = false;
-        if (np <= 1 && i < N && (i & (META_CHUNK - 1)) != 0) {
-            const i32x4 n0 = lmeta[2 * (i & (META_CHUNK - 1))];
+        if (np <= 1 && i < N && (i & (CH - 1)) != 0) {
+            const i32x4 n0 = lmeta[2 * (i & (CH - 1))];
             const int nnp = __builtin_amdgcn_readfirstlane(n0.y) & 0xffff, np0 = __builtin_amdgcn_readfirstlane(n0.z);
             next_sib = nnp <= 1 && np0 == p0 && np0 != i;
         }
@@ -571,6 +572,7 @@ constexpr int TBW_STRIDE = 29;  // dwords per window row (odd: conflict-free fil
 enum : int { EO_PB = 16, EO_INFO = 17, EO_Q0 = 18, EO_Q1 = 19, EO_NODE = 20, EO_STEP = 21 /* ..26 */, EO_TX = 27 };
 static_assert(2 * P16_TB_WORDS == EO_PB, "window row layout");
 static_assert((TBW_ROWS * TBW_STRIDE + TBW_ROWS) * 4 <= LDS_META_BYTES, "traceback window lives in the descriptor area");
+static_assert((TBW_ROWS / 2 * TBW_STRIDE + TBW_ROWS / 2) * 4 <= LDS_META_BYTES / 2, "... also the half-size one");
 
 // H is tracked along the walk (hv): it starts at the end cell's score and every recorded step is undone
 // -- a diagonal step subtracts the letter score, leaving a gap state subtracts the opening cost, each
@@ -589,7 +591,8 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     // rarely has an instruction ready, so top priority costs the co-residents next to nothing
     __builtin_amdgcn_s_setprio(3);
     uint32_t* win = (uint32_t*)(smem + LDS_CTL_BYTES);
-    uint32_t* wlet = win + TBW_ROWS * TBW_STRIDE;  // [64] query letters of columns jtop, jtop-1, ...
+    const int WR = dp16_meta_bytes(T) < LDS_META_BYTES ? TBW_ROWS / 2 : TBW_ROWS;  // window rows
+    uint32_t* wlet = win + WR * TBW_STRIDE;  // [WR] query letters of columns jtop, jtop-1, ...
     // first of the two lane-columns fetched for a row whose expected (half-local) column is x
     auto col0 = [&](int x) -> int { return x < W / 2 ? 0 : min((x - W / 2) / W, T - 2); };
     int n = 0, st = SRC_STOP;
@@ -608,10 +611,10 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
         const int lt = jj / W, bit = (jj - lt * W) + 16 * half;
         int l = wtop - i;
         int c0 = col0(wjj - l);
-        if (wtop < 0 || l < 0 || l >= TBW_ROWS || half != whalf || (unsigned)(lt - c0) > 1u) {
+        if (wtop < 0 || l < 0 || l >= WR || half != whalf || (unsigned)(lt - c0) > 1u) {
             wtop = i; wjj = jj; whalf = half; wj = j;
             const int row = i - lane;
-            if (row >= 1) {
+            if (row >= 1 && lane < WR) {
                 const int c = col0(jj - lane);
                 SXG_GLOBAL const uint32_t* mw = sxg_global((const uint32_t*)B.tb) + (size_t)row * P16_TB_WORDS * T + c;  // [row][word][lane]
                 uint32_t v[2 * P16_TB_WORDS];
@@ -631,7 +634,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                     for (int w3 = 0; w3 < 3; ++w3) { e[EO_STEP + 2 * w3] = sp[(size_t)w3 * T]; e[EO_STEP + 1 + 2 * w3] = sp[(size_t)w3 * T + 1]; }
                 }
             }
-            wlet[lane] = (j - lane >= 1) ? (uint32_t)seq[j - lane - 1] : 255u;
+            if (lane < WR) wlet[lane] = (j - lane >= 1) ? (uint32_t)seq[j - lane - 1] : 255u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -665,7 +668,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                 }
                 ++n;
                 const unsigned wi = (unsigned)(wj - j);
-                const int letter = wi < (unsigned)TBW_ROWS ? (int)wlet[wi] : (int)seq[j - 1];
+                const int letter = wi < (unsigned)WR ? (int)wlet[wi] : (int)seq[j - 1];
                 hv -= (letter == ((info >> 16) & 0xff)) ? S.m : S.n;
                 i = pred_of(0);
                 --j;
