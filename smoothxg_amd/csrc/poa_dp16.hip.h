@@ -581,9 +581,27 @@ static_assert((TBW_ROWS / 2 * TBW_STRIDE + TBW_ROWS / 2) * 4 <= LDS_META_BYTES /
 template <bool PAIRS, int W>
 // (views by value: a reference to the kernel's private copy trips an AMDGPU back-end assertion on
 // the private-aperture null check for some strip widths)
-__device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const Scoring S, const uint8_t* seq, const int best,
-                                          const int T, int i, int j, int32_t* posnode, int32_t* pair_row, int32_t* pair_pos,
-                                          char* smem) {
+__device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const Scoring S_, const uint8_t* seq, const int best_,
+                                          const int T_, const int slope_, int i, int j, int32_t* posnode, int32_t* pair_row,
+                                          int32_t* pair_pos, char* smem) {
+    // arguments arrive in vector registers: make the uniform ones scalar again
+    const int T = __builtin_amdgcn_readfirstlane(T_), best = __builtin_amdgcn_readfirstlane(best_);
+    // columns the alignment advances per graph row, in 1/256: a graph of N rows against L letters is
+    // walked at about L/N columns per row (rows of other branches are skipped), which is where the
+    // window is laid
+    const int slope = __builtin_amdgcn_readfirstlane(slope_);
+    i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
+    Scoring S;
+    S.m = __builtin_amdgcn_readfirstlane(S_.m); S.n = __builtin_amdgcn_readfirstlane(S_.n); S.g = __builtin_amdgcn_readfirstlane(S_.g);
+    S.e = __builtin_amdgcn_readfirstlane(S_.e); S.q = __builtin_amdgcn_readfirstlane(S_.q); S.c = __builtin_amdgcn_readfirstlane(S_.c);
+    S.sw = __builtin_amdgcn_readfirstlane(S_.sw); S.convex = S_.convex;
+    // outputs and letters through global pointers: a FLAT store also counts on lgkmcnt, and the walk
+    // waits on lgkmcnt for its LDS reads every step -- i.e. it waited for the previous step's store to
+    // reach HBM (measured: ~2 500 cycles per step)
+    SXG_GLOBAL int32_t* const g_posnode = sxg_global(posnode);
+    SXG_GLOBAL int32_t* const g_pair_row = sxg_global(pair_row);
+    SXG_GLOBAL int32_t* const g_pair_pos = sxg_global(pair_pos);
+    SXG_GLOBAL const uint8_t* const g_seq = sxg_global(seq);
     const int TW = T * W;
     const int lane = threadIdx.x & 63;
     const int sw = S.sw;
@@ -598,10 +616,16 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     int n = 0, st = SRC_STOP;
     int hv = best, gv = 0;  // H of the current cell (state H) / value of the gap state being walked
     int wtop = -1, wjj = 0, whalf = -1, wj = 0;
+#ifdef SXG_ROW_PROF
+    unsigned long long tb_steps = 0, tb_loads = 0, tb_t0 = __builtin_readcyclecounter(), tb_ld = 0;
+#endif
     for (;;) {
+#ifdef SXG_ROW_PROF
+        ++tb_steps;
+#endif
         if (i == 0) {
             if (j == 0 || sw) break;
-            if (PAIRS && lane == 0) { pair_row[n] = 0; pair_pos[n] = j - 1; }
+            if (PAIRS && lane == 0) { g_pair_row[n] = 0; g_pair_pos[n] = j - 1; }
             ++n; --j;
             continue;
         }
@@ -610,12 +634,18 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
         const int half = j >= TW ? 1 : 0, jj = j - half * TW;
         const int lt = jj / W, bit = (jj - lt * W) + 16 * half;
         int l = wtop - i;
-        int c0 = col0(wjj - l);
-        if (wtop < 0 || l < 0 || l >= WR || half != whalf || (unsigned)(lt - c0) > 1u) {
+        int c0 = col0(wjj - ((l * slope) >> 8));
+        // (the letters must come from the window as well: a global fallback load inside the step makes the
+        // compiler wait for vmcnt(0) at the merge, i.e. for the previous step's posnode store to reach HBM)
+        if (wtop < 0 || l < 0 || l >= WR || half != whalf || (unsigned)(lt - c0) > 1u || (unsigned)(wj - j) >= (unsigned)WR) {
             wtop = i; wjj = jj; whalf = half; wj = j;
+#ifdef SXG_ROW_PROF
+            ++tb_loads;
+            const unsigned long long tl0 = __builtin_readcyclecounter();
+#endif
             const int row = i - lane;
             if (row >= 1 && lane < WR) {
-                const int c = col0(jj - lane);
+                const int c = col0(jj - ((lane * slope) >> 8));
                 SXG_GLOBAL const uint32_t* mw = sxg_global((const uint32_t*)B.tb) + (size_t)row * P16_TB_WORDS * T + c;  // [row][word][lane]
                 uint32_t v[2 * P16_TB_WORDS];
 #pragma unroll
@@ -634,62 +664,76 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                     for (int w3 = 0; w3 < 3; ++w3) { e[EO_STEP + 2 * w3] = sp[(size_t)w3 * T]; e[EO_STEP + 1 + 2 * w3] = sp[(size_t)w3 * T + 1]; }
                 }
             }
-            if (lane < WR) wlet[lane] = (j - lane >= 1) ? (uint32_t)seq[j - lane - 1] : 255u;
+            if (lane < WR) wlet[lane] = (j - lane >= 1) ? (uint32_t)g_seq[j - lane - 1] : 255u;  // (letters: one per column)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             l = 0; c0 = col0(jj);
+#ifdef SXG_ROW_PROF
+            tb_ld += __builtin_readcyclecounter() - tl0;
+#endif
         }
+        // Everything the walk reads is the same for all lanes; saying so (readfirstlane) keeps its state
+        // in scalar registers and its control flow on the scalar unit instead of 64-wide selects and
+        // exec-mask juggling (measured before: ~2 700 cycles per step).
+#define TBU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
         const uint32_t* e = win + l * TBW_STRIDE;
         const uint32_t* m = e + (lt - c0) * P16_TB_WORDS;
-        const int pb = (int)e[EO_PB], info = (int)e[EO_INFO], q0 = (int)e[EO_Q0], q1 = (int)e[EO_Q1], node = (int)e[EO_NODE];
+        const int pb = (int)TBU(e[EO_PB]), info = (int)TBU(e[EO_INFO]), q0 = (int)TBU(e[EO_Q0]), q1 = (int)TBU(e[EO_Q1]), node = (int)TBU(e[EO_NODE]);
         const int np = info & 0xffff;
         auto pred_of = [&](int which) -> int {
             if (np == 0) return 0;
             if (np == 1) return q0;
-            const int tx = (int)e[EO_TX];
+            const int tx = (int)TBU(e[EO_TX]);
             int ord = 0;
             for (int x = np - 1; x >= 2 && !ord; --x)
-                if ((sxg_global((const uint32_t*)B.steps)[((size_t)(tx + x - 1) * 3 + which) * T + lt] >> bit) & 1u) ord = x;
-            if (!ord) ord = (int)((e[EO_STEP + 2 * which + (lt - c0)] >> bit) & 1u);
-            return ord == 0 ? q0 : (ord == 1 ? q1 : sxg_global((const int32_t*)R.preds)[pb + ord]);
+                if ((TBU(sxg_global((const uint32_t*)B.steps)[((size_t)(tx + x - 1) * 3 + which) * T + lt]) >> bit) & 1u) ord = x;
+            if (!ord) ord = (int)((TBU(e[EO_STEP + 2 * which + (lt - c0)]) >> bit) & 1u);
+            return ord == 0 ? q0 : (ord == 1 ? q1 : (int)TBU(sxg_global((const int32_t*)R.preds)[pb + ord]));
         };
         if (st == SRC_STOP) {
             int src;
-            if ((m[PM_GTQ] >> bit) & 1u) src = SRC_Q;
-            else if ((m[PM_GTE] >> bit) & 1u) src = SRC_E;
-            else if ((m[PM_GTO] >> bit) & 1u) src = SRC_O;
-            else if ((m[PM_GTF] >> bit) & 1u) src = SRC_F;
+            const uint32_t mq = TBU(m[PM_GTQ]), me = TBU(m[PM_GTE]), mo = TBU(m[PM_GTO]), mf = TBU(m[PM_GTF]);
+            if ((mq >> bit) & 1u) src = SRC_Q;
+            else if ((me >> bit) & 1u) src = SRC_E;
+            else if ((mo >> bit) & 1u) src = SRC_O;
+            else if ((mf >> bit) & 1u) src = SRC_F;
             else src = SRC_D;
             if (src == SRC_D) {
                 if (lane == 0) {
-                    if (PAIRS) { pair_row[n] = i; pair_pos[n] = j - 1; }
-                    if (posnode) posnode[j - 1] = node;
+                    if (PAIRS) { g_pair_row[n] = i; g_pair_pos[n] = j - 1; }
+                    if (posnode) g_posnode[j - 1] = node;
                 }
                 ++n;
-                const unsigned wi = (unsigned)(wj - j);
-                const int letter = wi < (unsigned)WR ? (int)wlet[wi] : (int)seq[j - 1];
+                const int letter = (int)TBU(wlet[wj - j]);
                 hv -= (letter == ((info >> 16) & 0xff)) ? S.m : S.n;
                 i = pred_of(0);
                 --j;
             } else { st = src; gv = hv; }
         } else if (st == SRC_F || st == SRC_O) {
             const bool isf = st == SRC_F;
-            const unsigned ext = (m[isf ? PM_FX : PM_OX] >> bit) & 1u;
-            if (PAIRS && lane == 0) { pair_row[n] = i; pair_pos[n] = -1; }
+            const unsigned ext = (TBU(m[isf ? PM_FX : PM_OX]) >> bit) & 1u;
+            if (PAIRS && lane == 0) { g_pair_row[n] = i; g_pair_pos[n] = -1; }
             ++n;
             i = pred_of(isf ? 1 : 2);
             if (ext) gv -= isf ? S.e : S.c;
             else { hv = gv - (isf ? S.g : S.q); st = SRC_STOP; }
         } else {
             const bool ise = st == SRC_E;
-            const unsigned ext = (m[ise ? PM_EX : PM_QX] >> bit) & 1u;
-            if (PAIRS && lane == 0) { pair_row[n] = 0; pair_pos[n] = j - 1; }
+            const unsigned ext = (TBU(m[ise ? PM_EX : PM_QX]) >> bit) & 1u;
+            if (PAIRS && lane == 0) { g_pair_row[n] = 0; g_pair_pos[n] = j - 1; }
             ++n; --j;
             if (ext) gv -= ise ? S.e : S.c;
             else { hv = gv - (ise ? S.g : S.q); st = SRC_STOP; }
         }
     }
+#undef TBU
+#ifdef SXG_ROW_PROF
+    if (lane == 0 && B.row_prof) {
+        B.row_prof[8] += tb_steps; B.row_prof[9] += tb_loads;
+        B.row_prof[10] += __builtin_readcyclecounter() - tb_t0; B.row_prof[11] += tb_ld;
+    }
+#endif
     return n;
 }
 

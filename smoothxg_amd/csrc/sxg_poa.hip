@@ -215,7 +215,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                 __syncthreads();
                 PROF(2);
                 if constexpr (RM == 2) {  // wave 0 walks together (LDS window)
-                    if (t < 64 && res.bi >= 0) traceback_p16<false, W>(V.R, V.B, S, seq, res.best, T, res.bi, res.bj, V.G.posnode, nullptr, nullptr, smem);
+                    if (t < 64 && res.bi >= 0) traceback_p16<false, W>(V.R, V.B, S, seq, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj, V.G.posnode, nullptr, nullptr, smem);
                 } else if (t == 0 && res.bi >= 0) traceback<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
                 score = res.bi >= 0 ? res.best : 0;
                 __syncthreads();
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
                 else dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 if constexpr (RM == 2) {
-                    if (t < 64 && res.bi >= 0) npairs = traceback_p16<true, W>(V.R, V.B, S, A.bases + so, res.best, T, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos, smem);
+                    if (t < 64 && res.bi >= 0) npairs = traceback_p16<true, W>(V.R, V.B, S, A.bases + so, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj, nullptr, V.pair_row, V.pair_pos, smem);
                 } else if (t == 0 && res.bi >= 0) npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
                 if (t == 0 && res.bi >= 0) {
                     score = res.best;
@@ -815,11 +815,11 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
     }
 #ifdef SXG_ROW_PROF
     {
-        unsigned long long ra[8] = {0};
+        unsigned long long ra[12] = {0};
         for (int64_t sl = 0; sl < P.n_slots; ++sl) {
-            unsigned long long one[8];
+            unsigned long long one[12];
             HIPCHK(hipMemcpy(one, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64 + 28 * 8, sizeof(one), hipMemcpyDeviceToHost));
-            for (int k = 0; k < 8; ++k) ra[k] += one[k];
+            for (int k = 0; k < 12; ++k) ra[k] += one[k];
         }
         double rt = 1e-9;
         for (int k = 0; k < 8; ++k) rt += (double)ra[k];
@@ -827,6 +827,9 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
         fprintf(stderr, "[sxg]   row profile:");
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", seg[k], 100.0 * (double)ra[k] / rt);
         fprintf(stderr, "\n");
+        fprintf(stderr, "[sxg]   traceback: %.3g steps, %.1f steps per window load, %.0f cycles per step of which %.0f waiting for window loads\n",
+                (double)ra[8], (double)ra[8] / std::max<double>((double)ra[9], 1), (double)ra[10] / std::max<double>((double)ra[8], 1),
+                (double)ra[11] / std::max<double>((double)ra[8], 1));
     }
 #endif
     double tot = 1e-9;
