@@ -18,8 +18,8 @@
 
 namespace sxg {
 
-template <class Ctx, class F>
-SXG_HD int array_excl_sum(Ctx& c, int n, F get, int32_t* out) {
+template <class Ctx, class F, class P>
+SXG_HD int array_excl_sum(Ctx& c, int n, F get, P out) {
     const int T = c.nthreads(), t = c.tid();
     int carry = 0;
     for (int base = 0; base < n; base += T) {
@@ -34,8 +34,8 @@ SXG_HD int array_excl_sum(Ctx& c, int n, F get, int32_t* out) {
 }
 
 // out[i] = max_{x<=i} get(x)
-template <class Ctx, class F>
-SXG_HD void array_incl_max(Ctx& c, int n, F get, int32_t* out) {
+template <class Ctx, class F, class P>
+SXG_HD void array_incl_max(Ctx& c, int n, F get, P out) {
     const int T = c.nthreads(), t = c.tid();
     int carry = -0x7fffffff;
     for (int base = 0; base < n; base += T) {
@@ -49,8 +49,8 @@ SXG_HD void array_incl_max(Ctx& c, int n, F get, int32_t* out) {
 }
 
 // out[i] = min_{x>=i} get(x)
-template <class Ctx, class F>
-SXG_HD void array_suffix_min(Ctx& c, int n, F get, int32_t* out) {
+template <class Ctx, class F, class P>
+SXG_HD void array_suffix_min(Ctx& c, int n, F get, P out) {
     const int T = c.nthreads(), t = c.tid();
     int carry = -0x7fffffff;
     for (int base = 0; base < n; base += T) {
@@ -85,8 +85,10 @@ SXG_HD int group_end(const GraphView& G, int leader, int n_old) {
 // path_out[0..len) receives the node id of every base (replaces spoa's per-edge labels /
 // Node::Successor walk used at src/smooth.cpp:2604-2610).
 template <class Ctx>
-SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq, int len,
-                          uint32_t weight, int32_t* path_out) {
+SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq_, int len,
+                          uint32_t weight, int32_t* path_out_) {
+    SXG_GP const uint8_t* const seq = (SXG_GP const uint8_t*)seq_;   // both live in HBM
+    SXG_GP int32_t* const path_out = (SXG_GP int32_t*)path_out_;
     const int T = c.nthreads(), t = c.tid();
     const int n_old = *G.n_nodes, e_old = *G.n_edges;
     const int BIG = 0x3fffffff;

@@ -52,32 +52,41 @@ struct Scoring {
     int convex;            // 0 = O/Q states are copies of F/E and are skipped
 };
 
+// Pointer members of the views are global-address-space pointers in device code: read back from a
+// struct, a plain pointer is "flat" to the compiler, and flat accesses count on lgkmcnt as well as
+// vmcnt, so every LDS wait of the block-wide scans also waited for HBM.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SXG_GP __attribute__((address_space(1)))
+#else
+#define SXG_GP
+#endif
+
 // Graph of ONE block, slot-private working set.  Capacities: nodes/edges <= sum of the
 // block's sequence lengths.
 struct GraphView {
-    int32_t *n_nodes, *n_edges;  // scalars in global memory (slot header)
-    uint8_t *code;
-    int32_t *rank, *order, *order_tmp, *leader, *gmem;
-    int32_t *in_head, *in_tail, *out_head, *out_tail, *in_deg, *out_deg;
-    int32_t *e_tail, *e_head, *e_next_in, *e_next_out;
-    uint32_t *e_w;
+    SXG_GP int32_t *n_nodes, *n_edges;  // scalars in global memory (slot header)
+    SXG_GP uint8_t *code;
+    SXG_GP int32_t *rank, *order, *order_tmp, *leader, *gmem;
+    SXG_GP int32_t *in_head, *in_tail, *out_head, *out_tail, *in_deg, *out_deg;
+    SXG_GP int32_t *e_tail, *e_head, *e_next_in, *e_next_out;
+    SXG_GP uint32_t *e_w;
     // scratch for add_alignment (length >= max sequence length / max nodes + 1)
-    int32_t *posnode, *target, *newidx, *nexta, *preva, *slotadd;
-    int8_t *kind;
+    SXG_GP int32_t *posnode, *target, *newidx, *nexta, *preva, *slotadd;
+    SXG_GP int8_t *kind;
 };
 
 // Row structures of the current graph in rank space, rebuilt before every alignment.
 struct RowsView {
-    uint8_t *code;       // [N]
-    uint8_t *flags;      // [N]
-    int32_t *pred_off;   // [N+1]
-    int32_t *preds;      // [E] row indices (rank+1), in-edge insertion order
-    int32_t *slot;       // [N] row-pool slot of stored rows
-    int32_t *tbx;        // [N] first fold step of a multi-pred row in the step-mask plane
+    SXG_GP uint8_t *code;       // [N]
+    SXG_GP uint8_t *flags;      // [N]
+    SXG_GP int32_t *pred_off;   // [N+1]
+    SXG_GP int32_t *preds;      // [E] row indices (rank+1), in-edge insertion order
+    SXG_GP int32_t *slot;       // [N] row-pool slot of stored rows
+    SXG_GP int32_t *tbx;        // [N] first fold step of a multi-pred row in the step-mask plane
                          //      (row with np preds owns np-1 steps); -1: single-pred row
-    int32_t *sseq;       // [N+1] exclusive count of stored rows (scratch)
-    int32_t *row_node;   // [N] node id at rank
-    int32_t *meta;       // [N*8] per-row DP descriptor, see RowMeta
+    SXG_GP int32_t *sseq;       // [N+1] exclusive count of stored rows (scratch)
+    SXG_GP int32_t *row_node;   // [N] node id at rank
+    SXG_GP int32_t *meta;       // [N*8] per-row DP descriptor, see RowMeta
 };
 
 // What the DP needs to start a row, gathered into 32 bytes so the sweep reads it from an

@@ -84,24 +84,24 @@ struct SlotViews {
 
 __device__ static SlotViews slot_views(uint8_t* base, const SlotLayout& L) {
     SlotViews V;
-    int32_t* hdr = (int32_t*)(base + L.hdr);
+    SXG_GP int32_t* hdr = (SXG_GP int32_t*)(base + L.hdr);
     V.G.n_nodes = hdr; V.G.n_edges = hdr + 1;
-    V.G.code = base + L.code;
-#define P32(f) (int32_t*)(base + L.f)
+    V.G.code = (SXG_GP uint8_t*)(base + L.code);
+#define P32(f) (SXG_GP int32_t*)(base + L.f)
     V.G.rank = P32(rank); V.G.order = P32(order); V.G.order_tmp = P32(order_tmp); V.G.leader = P32(leader);
     V.G.gmem = P32(gmem); V.G.in_head = P32(in_head); V.G.in_tail = P32(in_tail); V.G.out_head = P32(out_head);
     V.G.out_tail = P32(out_tail); V.G.in_deg = P32(in_deg); V.G.out_deg = P32(out_deg);
     V.G.e_tail = P32(e_tail); V.G.e_head = P32(e_head); V.G.e_next_in = P32(e_next_in);
-    V.G.e_next_out = P32(e_next_out); V.G.e_w = (uint32_t*)(base + L.e_w);
+    V.G.e_next_out = P32(e_next_out); V.G.e_w = (SXG_GP uint32_t*)(base + L.e_w);
     V.G.posnode = P32(posnode); V.G.target = P32(target); V.G.newidx = P32(newidx); V.G.nexta = P32(nexta);
-    V.G.preva = P32(preva); V.G.slotadd = P32(slotadd); V.G.kind = (int8_t*)(base + L.kind);
-    V.R.code = base + L.r_code; V.R.flags = base + L.r_flags; V.R.pred_off = P32(r_pred_off);
+    V.G.preva = P32(preva); V.G.slotadd = P32(slotadd); V.G.kind = (SXG_GP int8_t*)(base + L.kind);
+    V.R.code = (SXG_GP uint8_t*)(base + L.r_code); V.R.flags = (SXG_GP uint8_t*)(base + L.r_flags); V.R.pred_off = P32(r_pred_off);
     V.R.preds = P32(r_preds); V.R.slot = P32(r_slot); V.R.tbx = P32(r_tbx); V.R.sseq = P32(r_sseq);
     V.R.row_node = P32(r_row_node); V.R.meta = P32(r_meta);
     V.B.tb = base + L.tb; V.B.steps = (uint32_t*)(base + L.steps);
     V.B.pool = base + L.pool; V.B.row0 = base + L.row0; V.B.park = base + L.park;
-    V.cons_sc = (int64_t*)(base + L.cons_sc); V.cons_pr = P32(cons_pr);
-    V.pair_row = P32(pair_row); V.pair_pos = P32(pair_pos);
+    V.cons_sc = (int64_t*)(base + L.cons_sc); V.cons_pr = (int32_t*)(base + L.cons_pr);
+    V.pair_row = (int32_t*)(base + L.pair_row); V.pair_pos = (int32_t*)(base + L.pair_pos);
 #undef P32
     return V;
 }
