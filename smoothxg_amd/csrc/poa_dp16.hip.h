@@ -217,7 +217,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 // words of the stored row of predecessor p_ (slot sl_) and the column to their left
 #define P16_FETCH(p_, sl_, wr_, hl_)                                                                        \
     do {                                                                                                    \
-        SXG_GLOBAL const u32x2* base_ = ((p_) == 0) ? g_row0 : g_pool + (size_t)(sl_) * TW;                \
+        SXG_GLOBAL const u32x2* base_ = sxg_uniform(((p_) == 0) ? (SXG_GLOBAL const u32x2*)g_row0 : g_pool + (size_t)(sl_) * TW); \
         _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = (base_ + k * T)[ut];                         \
         P16_LOAD_LEFT(base_, hl_);                                                                          \
     } while (0)
