@@ -254,3 +254,23 @@ def test_global_alignment_outgrows_the_packed_range_and_is_rerun_wider(engine, o
     res2 = engine.run_blocks([calm], gparams("affine_4param", 1))
     assert engine.stats()["dom_row_mode"] == 2 and engine.stats()["retries"] == 0
     assert_block_equal(res2[0], g2, sc2, cells2, label="range-ok")
+
+
+def test_per_block_scores_and_modes_in_one_batch(engine, oracle):
+    """per_block_params: every block of one batch brings its own scores AND alignment type -- five
+    score sets x local/global x two lengths, so packed and 32-bit sweeps, linear/affine/convex kernels
+    and several geometries run side by side in one call."""
+    rng = np.random.default_rng(91)
+    blocks, gp, op = [], [], []
+    for L in (300, 1400):
+        for pname in PARAM_SETS:
+            for mode in (0, 1):
+                blocks.append(random_block(rng, 5, L, div=0.04))
+                gp.append(gparams(pname, mode))
+                op.append(oparams(pname, mode))
+    res = engine.run_blocks(blocks, gp, want_consensus=True)
+    assert len(res) == len(blocks) == 20
+    for b, seqs in enumerate(blocks):
+        g, sc, cells = oracle.block_run(seqs, None, op[b])
+        assert_block_equal(res[b], g, sc, cells, label=f"per-block {b}")
+        assert (res[b].consensus == g.consensus()).all()
