@@ -165,9 +165,13 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
     V.B.prio_rank = (int)(blockIdx.x / (unsigned)A.num_cu) & (PRIO_BOARD_SLOTS - 1);
     V.B.prio_board = A.prio_board ? A.prio_board + (size_t)(__smid() & (PRIO_BOARD_CUS - 1)) * PRIO_BOARD_SLOTS : nullptr;
     const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap};
+    // the first item of a slot is fixed (work[blockIdx]: the host orders the list by where the slot will
+    // run, see launch_plan), the rest comes from the queue
+    bool first = true;
     for (;;) {
         __syncthreads();
-        if (t == 0) s_work = atomicAdd(A.queue, 1);
+        if (t == 0) s_work = first ? (int)blockIdx.x : (int)gridDim.x + atomicAdd(A.queue, 1);
+        first = false;
         __syncthreads();
         const int wi = s_work;
         if (wi >= A.n_work) break;
@@ -752,6 +756,22 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
     int rc;
     if (!P.kern) return fail(SXG_E_INVALID, "no kernel class built for this geometry");
     if ((rc = R.arena.ensure((size_t)P.n_slots * P.lay.total))) return rc;
+    // Workgroup k runs on CU k mod #CU (measured, profiles/tools/slot_report.py): when the slots do not
+    // divide evenly, the CUs with one workgroup less run theirs faster -- they get the costliest blocks, so
+    // that those are not what the launch ends on.  P.work arrives sorted by cost, largest first.
+    {
+        const int64_t ns = P.n_slots, ncu = std::max(h->num_cu, 1);
+        const int64_t rem = ns % ncu, full = ns / ncu;
+        if (rem > 0 && full >= 1 && (int64_t)P.work.size() >= ns) {
+            std::vector<int32_t> first((size_t)ns, -1);
+            size_t next = 0;
+            for (int64_t p = 0; p < ns; ++p)          // light CUs first
+                if (p % ncu >= rem && p / ncu < full) first[(size_t)p] = P.work[next++];
+            for (int64_t p = 0; p < ns; ++p)
+                if (first[(size_t)p] < 0) first[(size_t)p] = P.work[next++];
+            std::copy(first.begin(), first.end(), P.work.begin());
+        }
+    }
     const size_t board_bytes = (size_t)PRIO_BOARD_CUS * PRIO_BOARD_SLOTS * 4;
     if ((rc = R.work.ensure(4 * P.work.size())) || (rc = R.queue.ensure(256 + board_bytes)) || (rc = R.est.ensure(8 * P.work.size()))) return rc;
     HIPCHK(hipMemcpyAsync(R.work.p, P.work.data(), 4 * P.work.size(), hipMemcpyHostToDevice, R.stream));
