@@ -767,8 +767,13 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
             size_t next = 0;
             for (int64_t p = 0; p < ns; ++p)          // light CUs first
                 if (p % ncu >= rem && p / ncu < full) first[(size_t)p] = P.work[next++];
-            for (int64_t p = 0; p < ns; ++p)
-                if (first[(size_t)p] < 0) first[(size_t)p] = P.work[next++];
+            // the crowded CUs are dealt the rest in snake order (round 0 left to right, round 1 right to
+            // left, ...), which evens out the sum of costs per CU
+            for (int64_t round = 0; round <= full; ++round)
+                for (int64_t c = 0; c < rem; ++c) {
+                    const int64_t cu = (round & 1) ? rem - 1 - c : c, p = round * ncu + cu;
+                    if (p < ns && first[(size_t)p] < 0) first[(size_t)p] = P.work[next++];
+                }
             std::copy(first.begin(), first.end(), P.work.begin());
         }
     }
