@@ -274,3 +274,20 @@ def test_per_block_scores_and_modes_in_one_batch(engine, oracle):
         g, sc, cells = oracle.block_run(seqs, None, op[b])
         assert_block_equal(res[b], g, sc, cells, label=f"per-block {b}")
         assert (res[b].consensus == g.consensus()).all()
+
+
+def test_small_memory_budget_runs_blocks_through_few_slots(engine, oracle):
+    """sxg_poa_set_memory_budget: with room for a handful of slot arenas, 40 blocks go through the
+    work queue of a few persistent workgroups (first item fixed per slot, the rest pulled) -- same results."""
+    rng = np.random.default_rng(123)
+    blocks = [random_block(rng, 6, 500 + 40 * (b % 7), div=0.04) for b in range(40)]
+    try:
+        engine.set_memory_budget(64 << 20)
+        res = engine.run_blocks(blocks, gparams("convex_default", 0))
+        st = engine.stats()
+        assert 1 <= st["n_slots"] < len(blocks)
+    finally:
+        engine.set_memory_budget(0)
+    for b, seqs in enumerate(blocks):
+        g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
+        assert_block_equal(res[b], g, sc, cells, label=f"budget {b}")
