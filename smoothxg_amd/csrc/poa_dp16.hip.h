@@ -177,7 +177,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 #endif
     for (int i = 1; i <= N; ++i) {
         if (B.prio_board) { if ((i & 127) == 1) sxg_balance_prio(B, (unsigned long long)i * (unsigned long long)L); }
-        else if ((i & 3) == 1) sxg_rotate_prio(B.prio_rank);
+        else if ((i & 63) == 1) sxg_rotate_prio(B.prio_rank);
         const int r = i - 1;
         if ((r & (CH - 1)) == 0) {
             __syncthreads();
