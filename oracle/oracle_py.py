@@ -19,8 +19,8 @@ class Params(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "poa_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("poa_oracle.c", "poa_vtb.c", "poa_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -43,6 +43,7 @@ def lib():
         L.poa_align.argtypes = [vp, u8p, C.c_int, C.POINTER(Params), i32p, i32p, i32p, u64p]
         L.poa_align_csr.argtypes = [C.c_int, u8p, i32p, i32p, u8p, u8p, C.c_int, C.POINTER(Params),
                                     i32p, i32p, i32p]
+        L.poa_align_csr_vtb.argtypes = L.poa_align_csr.argtypes
         L.poa_add_alignment.argtypes = [vp, i32p, i32p, C.c_int, u8p, C.c_int, C.c_uint32]
         L.poa_graph_nodes.argtypes = [vp, u8p, i32p, i32p]
         L.poa_graph_edges.argtypes = [vp, i32p, i32p, u32p]
@@ -167,7 +168,7 @@ class Graph:
         return [raw[i * ncol:(i + 1) * ncol].decode() for i in range(rows)]
 
 
-def align_csr(codes, off, pred, sink, seq, params):
+def align_csr(codes, off, pred, sink, seq, params, vtb=False):
     codes = np.ascontiguousarray(codes, np.uint8)
     off = np.ascontiguousarray(off, np.int32)
     pred = np.ascontiguousarray(pred if len(pred) else np.zeros(1), np.int32)
@@ -178,7 +179,7 @@ def align_csr(codes, off, pred, sink, seq, params):
     an = np.empty(cap, np.int32)
     ap = np.empty(cap, np.int32)
     sc = C.c_int32(0)
-    k = lib().poa_align_csr(n, _p(codes, C.c_uint8), _p(off, C.c_int32), _p(pred, C.c_int32),
+    k = (lib().poa_align_csr_vtb if vtb else lib().poa_align_csr)(n, _p(codes, C.c_uint8), _p(off, C.c_int32), _p(pred, C.c_int32),
                             _p(sink, C.c_uint8), _p(seq, C.c_uint8), len(seq), C.byref(params),
                             _p(an, C.c_int32), _p(ap, C.c_int32), C.byref(sc))
     return an[:k].copy(), ap[:k].copy(), sc.value

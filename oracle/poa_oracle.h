@@ -60,6 +60,12 @@ int poa_align_csr(int n_rows, const uint8_t *codes, const int32_t *off, const in
                   const uint8_t *sink, const uint8_t *seq, int len, const poa_params_t *p,
                   int32_t *out_node, int32_t *out_pos, int32_t *score);
 
+/* Same contract as poa_align_csr, second restatement (poa_vtb.c): nothing is recorded during the fill,
+ * the alignment is derived from the stored values H / oF / oO by re-applying the tie rules S3.        */
+int poa_align_csr_vtb(int n_rows, const uint8_t *codes, const int32_t *off, const int32_t *pred,
+                      const uint8_t *sink, const uint8_t *seq, int len, const poa_params_t *p,
+                      int32_t *out_node, int32_t *out_pos, int32_t *score);
+
 /* Fuse an alignment into the graph (spoa Graph::AddAlignment semantics, see .c).       */
 void poa_add_alignment(poa_graph_t *g, const int32_t *aln_node, const int32_t *aln_pos,
                        int n_pairs, const uint8_t *seq, int len, uint32_t weight);

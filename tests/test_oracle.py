@@ -206,3 +206,68 @@ def test_golden_self_oracle_fixtures(oracle):
         assert g.n_nodes == case["n_nodes"] and g.n_edges == case["n_edges"]
         assert synth.decode(g.nodes()[0][g.consensus()]) == case["consensus"]
         assert g.msa(True) == case["msa"]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+def test_derived_traceback_equals_recorded_traceback(oracle, mode, pname):
+    """poa_vtb.c derives the alignment from the stored values (H, oF, oO) by re-applying the tie
+    rules; poa_oracle.c replays recorded choices.  Two independent statements of S3/S5 must give the
+    same pairs on graphs with many ties (2-letter alphabet), deep bubbles and N letters."""
+    rng = np.random.default_rng(11 + mode)
+    p = oparams(pname, mode)
+    for trial in range(60):
+        S = int(rng.integers(2, 10))
+        L = int(rng.integers(3, 120))
+        alpha = (2, 4, 5)[trial % 3]
+        seqs = random_block(rng, S, L, div=(0.05, 0.15, 0.3)[trial % 3 if trial % 7 else 2], alphabet=alpha)
+        g, _, _ = oracle.block_run(seqs[:-1], None, p)
+        codes, off, pred, sink, _ = g.rows()
+        q = seqs[-1] if trial % 5 else rng.integers(0, alpha, int(rng.integers(1, 2 * L)), dtype=np.uint8)
+        a = oracle.align_csr(codes, off, pred, sink, q, p)
+        b = oracle.align_csr(codes, off, pred, sink, q, p, vtb=True)
+        assert a[2] == b[2], f"trial {trial}: score {a[2]} != {b[2]}"
+        assert len(a[0]) == len(b[0]) and (a[0] == b[0]).all() and (a[1] == b[1]).all(), f"trial {trial}: pairs differ"
+
+
+def test_derived_traceback_long_gaps(oracle):
+    """Structural variants: gaps long enough for the second convex piece (Q / O states) in both
+    directions, where E-versus-Q is decided by the bounded scan of poa_vtb.c."""
+    rng = np.random.default_rng(5)
+    for pname in ("convex_default", "convex_heavy", "adaptive_tier"):
+        for mode in (0, 1):
+            p = oparams(pname, mode)
+            anc = rng.integers(0, 4, 400, dtype=np.uint8)
+            ins = rng.integers(0, 4, 90, dtype=np.uint8)
+            a = anc
+            b = np.concatenate([anc[:150], ins, anc[150:]])      # insertion
+            c = np.concatenate([anc[:220], anc[300:]])           # deletion
+            d = np.concatenate([anc[:100], ins[:35], anc[100:260], anc[290:]])
+            for order in ([a, b, c, d], [b, a, d, c], [c, d, b, a]):
+                g, _, _ = oracle.block_run(order[:-1], None, p)
+                codes, off, pred, sink, _ = g.rows()
+                x = oracle.align_csr(codes, off, pred, sink, order[-1], p)
+                y = oracle.align_csr(codes, off, pred, sink, order[-1], p, vtb=True)
+                assert x[2] == y[2] and len(x[0]) == len(y[0])
+                assert (x[0] == y[0]).all() and (x[1] == y[1]).all()
+
+
+def test_fullshape_fixture_is_reproducible_on_its_small_cases(oracle):
+    """tests/golden/fullshape_oracle.json: the cheap cases (config 2, config 4's smallest block) are
+    recomputed here, which pins generator + oracle + digest code to the committed file; the 64 x 5 kbp
+    and 128 x 10 kbp cases cost minutes and are only checked on the GPU side."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_fullshape as MF
+    with open(os.path.join(here, "golden", "fullshape_oracle.json")) as f:
+        cases = json.load(f)["cases"]
+    names = {c["name"] for c in cases}
+    assert {"ns_sw", "ns_nw", "c3", "c2", "c4_max", "c4_min"} <= names
+    for c in cases:
+        assert len(c["scores"]) == c["n_seqs"] and len(c["seq_lens"]) == c["n_seqs"]
+        if c["name"] not in ("c2", "c4_min"):
+            continue
+        again = MF.run_case((c["name"], c["block_id"], c["n_seqs"], c["length"], tuple(c["params"]), c["mode"]))
+        for k in ("scores", "cells", "n_nodes", "n_edges", "digests", "seq_lens"):
+            assert again[k] == c[k], (c["name"], k)
