@@ -51,6 +51,7 @@ extern "C" {
 #define SXG_ST_NODES_OVERFLOW 4
 #define SXG_ST_TOO_LONG 5 /* a sequence exceeds SXG_POA_MAX_SEQ_LEN */
 #define SXG_ST_RANGE_OVERFLOW 6 /* internal: scores left the narrow sweep's range; the engine re-runs the block wider */
+#define SXG_ST_BAND_MISS 7      /* internal: the packed sweep's traceback left its band of kept cells; re-run wider */
 
 #define SXG_POA_MAX_SEQ_LEN 12287
 

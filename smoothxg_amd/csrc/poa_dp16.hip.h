@@ -1,4 +1,5 @@
-// poa_dp16.hip.h -- packed-int16 DP sweep (gfx950 v_pk_add_i16 / v_pk_max_i16 / v_pk_sub_i16).
+// poa_dp16.hip.h -- packed-int16 DP sweep (gfx950 v_pk_add_i16 / v_pk_max_i16 / v_pk_sub_i16) and the
+// traceback that DERIVES the alignment from stored values.
 //
 // Same semantics (S1-S5) and the same row-uniform structure as poa_dp.hip.h, but every VGPR
 // holds TWO cells: lane t owns strip "lo" = columns [t*W, (t+1)*W) and strip "hi" = columns
@@ -7,15 +8,22 @@
 // integer VALU instruction issues every 4 cycles whether it is 32-bit or packed 16-bit, and the
 // 32-bit sweep is bound by exactly that issue rate -- packing is the lever.
 //
-// What changes with packing:
-//  * no packed compare exists, so every "which candidate won" bit is the SIGN of a packed
-//    difference, shifted into bit k (lo strip) / bit 16+k (hi strip) of a per-row mask word;
-//  * the traceback plane stores those mask words (8 per lane per row) instead of one byte per
-//    cell; the 6-way source of H is resolved from "strictly beat the running maximum" bits in
-//    priority order Q > E > O > F > D at traceback time;
-//  * rows carry OUTGOING gap candidates (max(H+g, F+e), max(H+q, O+c)) instead of F and O: computed
-//    once at the end of a row, consumed for free by a register successor and with an unpack by a
-//    stored one; stored rows hold packed H plus the two 8-bit distances to the candidates;
+// Round 2: the sweep records NO decisions.  No packed compare exists on gfx950, so every "which
+// candidate won" bit used to be the sign of a packed difference shifted into a mask word (3 VALU
+// instructions per decision, 8 decisions per packed column: a third of the row) and the mask plane was
+// 40 % of the kernel's HBM writes -- for a walk that visits ~10^4 of 2.7*10^7 cells.  Now:
+//  * rows carry OUTGOING gap candidates oF = max(H+g, F+e), oO = max(H+q, O+c) instead of F and O:
+//    computed once at the end of a row, consumed for free by a register successor and with an unpack
+//    by a stored one; a row word is packed H plus the two 8-bit distances H-oF, H-oO;
+//  * every row additionally writes those words for a BAND of strips around the column where its node
+//    is expected to align (the node's backbone coordinate, kept by add_alignment) to the traceback
+//    plane, one dword per cell: H int16 | dF << 16 | dO << 24;
+//  * the traceback re-applies the tie rules S3 to the candidates of each visited cell (executable
+//    specification: oracle/poa_vtb.c, checked against the recorded-choice oracle): D from the
+//    predecessors' H, F / O from their outgoing candidates, E / Q from a leftward scan of the row's own
+//    H; the walk carries the value of the state it is in, so OPEN-versus-EXTEND is one equality test.
+//    A cell outside the band is a BAND MISS: the hints of the rows above are shifted and the alignment's
+//    sweep is repeated (rare: the band is ~1100 columns wide; see poa_block_kernel).
 //  * the end cell of a local alignment is found with a packed running maximum per row and a
 //    wave-uniform search of the column only in rows that improve it.
 // Applicability: every reachable score and intermediate fits +-15800 (host check); otherwise the
@@ -30,31 +38,19 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NEGP = -16384;  // "minus infinity" of the packed sweep
-constexpr int P16_TB_WORDS = 8;
-// mask words of one lane and row in the packed traceback plane
-// (no STOP word: a local alignment stops where H is 0, and the traceback knows H of every cell it visits
-// -- it starts from the best score and undoes one recorded step at a time)
-enum : int { PM_GTF = 0, PM_GTO = 1, PM_GTE = 2, PM_GTQ = 3, PM_FX = 4, PM_OX = 5, PM_EX = 6, PM_QX = 7 };
 
 __device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b))); }
 __device__ __forceinline__ int pk_sub(int a, int b) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); }
 __device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
-__device__ __forceinline__ int pk_minu(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
 __device__ __forceinline__ int pk_mad(int a, int b, int c) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) * __builtin_bit_cast(s16x2, b) + __builtin_bit_cast(s16x2, c))); }
 __device__ __forceinline__ int pk2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
-__device__ __forceinline__ int pk2s(int x) { return (x & 0xffff) | (x << 16); }  // both halves = x
 __device__ __forceinline__ int pk_lo(int v) { return (int)(short)(v & 0xffff); }
 __device__ __forceinline__ int pk_hi(int v) { return v >> 16; }
-// bit k (lo) / 16+k (hi) <- sign bits of the packed difference d
-#define SXG_SIGN_TO(mask, d, k) mask |= (((unsigned)(d)) >> (15 - (k))) & (0x00010001u << (k))
-
-constexpr int LDS16_X = 64;  // ints of exchange scratch after the four [16] arrays of dp_fill
 
 // Row words of the packed ring, per lane and column: packed H, and the distances H - oF, H - oO
 // to the row's OUTGOING gap candidates oF = max(H + g, F + e), oO = max(H + q, O + c) -- what every
 // successor takes as its F / O.  H >= F and g <= e < 0 bound the distances to [-e, -g] and [-c, -q]:
-// one byte each, never clamped (host check: |g|, |q| <= 120).  The EXTEND bit of a candidate is
-// implicit: extend won iff oF > H + g iff the distance is below -g.
+// one byte each, never clamped (host check: |g|, |q| <= 120).
 template <bool CVX>
 __device__ __forceinline__ u32x2 p16_pack_row(int h, int of, int oo) {
     const int df = pk_sub(h, of);
@@ -65,20 +61,28 @@ __device__ __forceinline__ void p16_unpack_row(u32x2 w, int& h, int& of, int& oo
     of = pk_sub(h, (int)(w.y & 0x00ff00ffu));
     oo = pk_sub(h, (int)((w.y >> 8) & 0x00ff00ffu));
 }
-// bit k (lo) / 16+k (hi) <- bit 7 / 23 of v
-#define SXG_BIT7_TO(mask, v, k) \
-    mask |= ((((unsigned)(v)) >> ((k) <= 7 ? 7 - (k) : 0)) << ((k) > 7 ? (k) - 7 : 0)) & (0x00010001u << (k))
+
+// ---- the traceback plane of the packed sweep: a band of strips per row -------------------------
+// Strip s = columns [s*W, (s+1)*W) (s < T: lo strips, s >= T: hi strips).  Row r keeps the BS strips
+// starting at band_first_strip(hint of r); cell (r, column j) is the dword
+//     plane[(r * W + j % W) * BS + (j / W - first strip)]  =  H int16 | (H - oF) << 16 | (H - oO) << 24.
+__host__ __device__ constexpr int p16_band_strips(int T, int W) {
+    return (1100 + W - 1) / W < 2 * T ? (1100 + W - 1) / W : 2 * T;
+}
+__device__ __forceinline__ int band_first_strip(const int hint_col, const int W, const int BS, const int T) {
+    const int c = hint_col / W - (BS >> 1);
+    return min(max(c, 0), 2 * T - BS);
+}
 
 template <int W, bool CVX, bool SW>
 __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R, const int N,
                                             const uint8_t* __restrict__ seq, const int L, const DpBuffers& B,
                                             char* smem, DpResult& res) {
-    static_assert(W >= 4 && W <= 15, "mask words hold W bits per strip plus the hand-over bit");
+    static_assert(W >= 4 && W <= 15, "strip width");
     const int T = (int)blockDim.x;
     const int NW = T >> 6;
     const int TW = T * W;           // columns of one half
     const int MB = dp16_meta_bytes(T), CH = MB / 32;  // descriptor staging area: bytes, rows per chunk
-    constexpr unsigned ALL = ((1u << W) - 1u) * 0x00010001u;
     int* lds = (int*)smem;
     const i32x4* lmeta = (const i32x4*)(smem + LDS_CTL_BYTES);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -90,10 +94,9 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     const int sm = __builtin_amdgcn_readfirstlane(S.m), sn = __builtin_amdgcn_readfirstlane(S.n);
     const int MN2 = pk2(sn - sm, sn - sm), M2 = pk2(sm, sm), ONE2 = 0x00010001, NEG2 = pk2(NEGP, NEGP);
     const int We = W * e, Wc = W * c;
-    // distance + CB sets bit 7 of a byte iff the distance reached -g (-q): the candidate was an OPEN
-    const unsigned CB = ((unsigned)(128 + g) & 0xffu) * 0x00010001u | ((unsigned)(128 + q) & 0xffu) * 0x01000100u;
+    const int BS = __builtin_amdgcn_readfirstlane(B.band_strips);
     int* tot = lds;            // [4][16]: a_lo, a_hi, b_lo, b_hi inclusive totals per wave
-    int* xch = lds + 64;       // [16][2]: (Hc[W-1] packed, ext bits) of every wave's last lane
+    int* xch = lds + 64;       // [16]: Hc[W-1] (packed) of every wave's last lane
 
     // query letters, one byte per (strip, column): register c2 holds (lo_k, hi_k, lo_k+1, hi_k+1)
     constexpr int NL = (W + 1) / 2;
@@ -112,7 +115,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     }
     // The letters live in LDS, not in registers: six loop-invariant VGPRs less, which is what the
     // allocator otherwise evicts to scratch around the multi-predecessor path -- and a scratch reload
-    // is an in-order vmcnt wait behind the fold-step stores just issued.  Lane-major, read back with
+    // is an in-order vmcnt wait behind the stores just issued.  Lane-major, read back with
     // two wide LDS loads per row.
     // (raw LDS byte offset: the dynamic LDS starts right behind the kernel's static LDS)
     typedef __attribute__((address_space(3))) unsigned lds_u32;
@@ -120,16 +123,14 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 #pragma unroll
     for (int k2 = 0; k2 < NL; ++k2) ((lds_u32*)(size_t)llet_off)[k2] = let[k2];
 
-    // Rows in HBM (ring, row 0) are laid out [column-in-strip][lane] and the mask plane
-    // [row][word][lane]: a load/store instruction then covers 64 consecutive words of a wave
-    // instead of 64 different cache lines (the lane-major layout kept the texture-address unit
-    // busier than the VALU).  Every access is "uniform pointer"[ut]: scalar base, one loop-invariant
-    // lane offset register, no per-access address arithmetic.
+    // Rows in HBM (ring, row 0) are laid out [column-in-strip][lane] and the plane
+    // [row][column-in-strip][strip of the band]: a load/store instruction then covers consecutive words of
+    // a wave instead of 64 different cache lines.  Every access is "uniform pointer"[lane offset]: scalar
+    // base, one loop-invariant lane offset register, no per-access address arithmetic.
     const unsigned ut = (unsigned)t;
     SXG_GLOBAL u32x2* const g_row0 = sxg_uniform(sxg_global((u32x2*)B.row0));
     SXG_GLOBAL u32x2* const g_pool = sxg_uniform(sxg_global((u32x2*)B.pool));
     SXG_GLOBAL uint32_t* const g_tb = sxg_uniform(sxg_global((uint32_t*)B.tb));
-    SXG_GLOBAL uint32_t* const g_steps = sxg_uniform(sxg_global(B.steps));
     SXG_GLOBAL const int32_t* const g_meta = sxg_uniform(sxg_global((const int32_t*)R.meta));
     SXG_GLOBAL const int32_t* const g_preds = sxg_uniform(sxg_global((const int32_t*)R.preds));
     SXG_GLOBAL const int32_t* const g_slot = sxg_uniform(sxg_global((const int32_t*)R.slot));
@@ -167,8 +168,11 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     int best_lo = SW ? 0 : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;
     const int kL_lo = L - j0, kL_hi = L - TW - j0;  // strip-local index of the end column L
 
-    unsigned fxm = 0, oxm = 0;  // EXTEND bits that go with Fp / Op
     bool next_sib = false;      // decided at the end of a row for its successor
+    // (B lives in the kernel's private memory: testing B.prio_board per row was a scratch load plus an
+    // in-order vmcnt(0) -- a wait for every store of the previous row -- at the top of EVERY row)
+    const bool has_board = __builtin_amdgcn_readfirstlane((int)(B.prio_board != nullptr)) != 0;
+    const int prio_rank = __builtin_amdgcn_readfirstlane(B.prio_rank);
 #ifdef SXG_ROW_PROF
     unsigned long long racc[8] = {0};  // per row segment; scalar registers (s_memtime deltas)
 #define RP_MARK(seg) do { const unsigned long long tn_ = __builtin_readcyclecounter(); racc[seg] += tn_ - rt_; rt_ = tn_; } while (0)
@@ -176,8 +180,8 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 #define RP_MARK(seg) do { } while (0)
 #endif
     for (int i = 1; i <= N; ++i) {
-        if (B.prio_board) { if ((i & 127) == 1) sxg_balance_prio(B, (unsigned long long)i * (unsigned long long)L); }
-        else if ((i & 63) == 1) sxg_rotate_prio(B.prio_rank);
+        if (has_board) { if ((i & 127) == 1) sxg_balance_prio(B, (unsigned long long)i * (unsigned long long)L); }
+        else if ((i & 63) == 1) sxg_rotate_prio(prio_rank);
         const int r = i - 1;
         if ((r & (CH - 1)) == 0) {
             __syncthreads();
@@ -195,7 +199,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         const int p1 = __builtin_amdgcn_readfirstlane(m1.x);
         const int s1 = __builtin_amdgcn_readfirstlane(m1.y);
         const int myslot = __builtin_amdgcn_readfirstlane(m1.z);
-        const int tx = __builtin_amdgcn_readfirstlane(m1.w);
+        const int hint = __builtin_amdgcn_readfirstlane(m1.w);
         const int np = info & 0xffff, code = (info >> 16) & 0xff, flags = (info >> 24) & 0xff;
         const unsigned CODE4 = (unsigned)code * 0x01010101u;
 
@@ -203,7 +207,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         unsigned long long rt_ = __builtin_readcyclecounter();
 #endif
         int Hc[W];
-        // Fp/Op/fxm/oxm arrive holding the previous row's OUTGOING candidates -- or, when the previous
+        // Fp/Op arrive holding the previous row's OUTGOING candidates -- or, when the previous
         // row announced this one as its sibling (an alternative allele: the same single predecessor),
         // that row's own F/O, which are this row's too.
         const bool sib = next_sib;
@@ -234,6 +238,8 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 #pragma unroll
             for (int k = 1; k < W; ++k) Hc[k] = (int)wr[k - 1].x;
         } else {
+            // Several predecessors: D, F and O are plain maxima over them (which predecessor won is
+            // re-derived by the traceback), so the fold order is free: the register row first.
             const bool reg0 = (p0 == i - 1), reg1 = (np == 2 && p1 == i - 1);
             const bool park = np >= 3;
             // my slice of the parked row, as a raw LDS offset rebuilt from an opaque t (one loop-invariant
@@ -247,13 +253,9 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 #pragma unroll
                 for (int k = 0; k < W; ++k) lrow_t[k] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
             }
-            const int ge = reg1 ? 1 : 0;
-            const int GE2 = ge ? ONE2 : 0;
-            unsigned nfx = 0, nox = 0;  // OPEN (= not EXTEND) bits while the predecessors are folded
             if ((reg0 || reg1) && !park) {
 #pragma unroll
                 for (int k = 0; k < W; ++k) Hc[k] = k ? Hp[k - 1] : Hleft;
-                nfx = ~fxm; nox = ~oxm;
             } else {
                 u32x2 wr[W];
                 int hl = Hleft;
@@ -265,12 +267,9 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                 for (int k = 0; k < W; ++k) {
                     int hs;
                     p16_unpack_row(wr[k], hs, Fp[k], Op[k]);
-                    const unsigned tn = wr[k].y + CB;
-                    SXG_BIT7_TO(nfx, tn, k);
-                    if (CVX) SXG_SIGN_TO(nox, tn, k);
                     Hc[k] = hl;
                     hl = hs;
-                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(nfx), "+v"(nox), "+v"(hl));
+                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));
                 }
             }
             for (int x = 1; x < np; ++x) {
@@ -286,44 +285,17 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
 #pragma unroll
                     for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];
                 } else P16_FETCH(p, sl, wr, hl);
-                // take-over test "cand + ge > cur" = sign of (cur - cand - ge); the value is the max
-                // either way (on a tie both are equal); masks: xor as in the 32-bit sweep
-                unsigned dm = ge ? ALL : 0u, fmk = dm, omk = CVX ? dm : 0u;
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     int hs, fs, os;
                     p16_unpack_row(wr[k], hs, fs, os);
-                    const unsigned bit = 0x00010001u << k;
-                    const unsigned tn = wr[k].y + CB;
-                    {
-                        unsigned n1 = 0;
-                        SXG_BIT7_TO(n1, tn, k);
-                        const unsigned rf = (((unsigned)pk_sub(pk_sub(Fp[k], fs), GE2)) >> (15 - k)) & bit;
-                        Fp[k] = pk_max(Fp[k], fs);
-                        nfx = (nfx & ~rf) | (rf & n1);
-                        fmk ^= rf;
-                    }
-                    if (CVX) {
-                        unsigned n2 = 0;
-                        SXG_SIGN_TO(n2, tn, k);
-                        const unsigned ro = (((unsigned)pk_sub(pk_sub(Op[k], os), GE2)) >> (15 - k)) & bit;
-                        Op[k] = pk_max(Op[k], os);
-                        nox = (nox & ~ro) | (ro & n2);
-                        omk ^= ro;
-                    }
-                    {
-                        const unsigned rd = (((unsigned)pk_sub(pk_sub(Hc[k], hl), GE2)) >> (15 - k)) & bit;
-                        Hc[k] = pk_max(Hc[k], hl);
-                        dm ^= rd;
-                    }
+                    Fp[k] = pk_max(Fp[k], fs);
+                    if (CVX) Op[k] = pk_max(Op[k], os);
+                    Hc[k] = pk_max(Hc[k], hl);
                     hl = hs;
-                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(nfx), "+v"(nox), "+v"(dm), "+v"(fmk), "+v"(omk), "+v"(hl));
+                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));
                 }
-                SXG_GLOBAL uint32_t* st = g_steps + ((size_t)(tx + x - 1) * 3) * T;
-                st[ut] = dm; (st + T)[ut] = fmk; (st + 2 * T)[ut] = omk;
             }
-            fxm = ~nfx & ALL;
-            oxm = CVX ? ~nox & ALL : 0u;
         }
 #undef P16_FETCH
 #undef P16_LOAD_LEFT
@@ -340,7 +312,6 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             for (int k2 = 0; k2 < NL; ++k2) let[k2] = ((lds_u32*)(size_t)lo_)[k2];
         }
         // ---- pass 1: H before the in-row gaps, strip-local carries
-        unsigned gtf = 0, gto = 0;  // F / O strictly beat the running maximum
         int a = NEG2, b = NEG2;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
@@ -352,15 +323,14 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             int nm;
             asm("v_pk_min_u16 %0, %1, %2" : "=v"(nm) : "v"(lp), "v"(ONE2));
             int h = pk_mad(nm, MN2, pk_add(Hc[k], M2));    // diagonal + (match ? m : n)
-            SXG_SIGN_TO(gtf, pk_sub(h, Fp[k]), k);
             h = pk_max(h, Fp[k]);
-            if (CVX) { SXG_SIGN_TO(gto, pk_sub(h, Op[k]), k); h = pk_max(h, Op[k]); }
+            if (CVX) h = pk_max(h, Op[k]);
             Hc[k] = h;
             // a' = max_k (h_k + (W-1-k) e) as a running "extend, or restart here"; the opening cost
             // and the local-alignment clamp (whose best term is k = W-1) are applied once per row below
             a = pk_max(pk_add(a, E2), h);
             if (CVX) b = pk_max(pk_add(b, C2), h);
-            SXG_PIN("+v"(Hc[k]), "+v"(gtf), "+v"(gto), "+v"(a), "+v"(b));
+            SXG_PIN("+v"(Hc[k]), "+v"(a), "+v"(b));
         }
         if (SW) { a = pk_max(a, 0); if (CVX) b = pk_max(b, 0); }
         a = pk_add(a, G2);
@@ -399,50 +369,30 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         const int Qin_hi = !CVX ? NEGP : max(yb_hi + tWc + (T - 1) * Wc, NEGP);
         int E = pk2(Ein_lo, Ein_hi), Q = pk2(Qin_lo, Qin_hi);
 
-        // ---- pass 2: final H and the remaining decision bits
-        // exm/qxm: EXTEND bit of E/Q of column k; the decision made at column k belongs to column
-        // k+1, so it goes straight to bit k+1 (bit W = the hand-over to the next lane)
-        unsigned gte = 0, gtq = 0, exm = 0, qxm = 0;
+        // ---- pass 2: final H
         int rowmax = SW ? 0 : NEG2;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            int h = Hc[k];
-            SXG_SIGN_TO(gte, pk_sub(h, E), k);
-            h = pk_max(h, E);
-            if (CVX) { SXG_SIGN_TO(gtq, pk_sub(h, Q), k); h = pk_max(h, Q); }
+            int h = pk_max(Hc[k], E);
+            if (CVX) h = pk_max(h, Q);
             if (SW) h = pk_max(h, 0);
             Hc[k] = h;
             rowmax = pk_max(rowmax, h);
-            const int c1 = pk_add(h, G2), c2 = pk_add(E, E2);
-            SXG_SIGN_TO(exm, pk_sub(c1, c2), k + 1);
-            E = pk_max(c1, c2);
-            if (CVX) {
-                const int d1 = pk_add(h, Q2), d2 = pk_add(Q, C2);
-                SXG_SIGN_TO(qxm, pk_sub(d1, d2), k + 1);
-                Q = pk_max(d1, d2);
-            }
-            SXG_PIN("+v"(Hc[k]), "+v"(gte), "+v"(gtq), "+v"(exm), "+v"(qxm), "+v"(E), "+v"(Q), "+v"(rowmax));
+            E = pk_max(pk_add(h, G2), pk_add(E, E2));
+            if (CVX) Q = pk_max(pk_add(h, Q2), pk_add(Q, C2));
+            SXG_PIN("+v"(Hc[k]), "+v"(E), "+v"(Q), "+v"(rowmax));
         }
-        // hand my last column and the ext bits of the next column to the right neighbour; the lo
-        // half's last lane feeds lane 0's hi strip
+        // hand my last column to the right neighbour; the lo half's last lane feeds lane 0's hi strip
         const int xh = Hc[W - 1];
-        const int xb = (int)(((exm >> W) & 0x00010001u) | (((qxm >> W) & 0x00010001u) << 1));  // bits 0,1 (lo strip), 16,17 (hi strip)
-        exm &= ALL; qxm &= ALL;
-        int lh = sxg_wave_shr1(xh, 0), lb = sxg_wave_shr1(xb, 0);
-        if (lane == 63) { xch[2 * wv] = xh; xch[2 * wv + 1] = xb; }
+        int lh = sxg_wave_shr1(xh, 0);
+        if (lane == 63) xch[wv] = xh;
         RP_MARK(3);  // carry combine + pass 2
         SXG_ROW_BARRIER();  // B2
         RP_MARK(4);  // waiting at B2
         if (lane == 0) {
-            if (wv > 0) { lh = xch[2 * (wv - 1)]; lb = xch[2 * (wv - 1) + 1]; }
-            else {
-                const int th = xch[2 * (NW - 1)], tb_ = xch[2 * (NW - 1) + 1];  // lane T-1
-                lh = pk2(NEGP, pk_lo(th));
-                lb = (tb_ & 3) << 16;  // its lo-strip bits become my hi-strip bits; my lo strip starts the row
-            }
+            if (wv > 0) lh = xch[wv - 1];
+            else lh = pk2(NEGP, pk_lo(xch[NW - 1]));  // lane T-1's lo strip ends where my hi strip begins
         }
-        exm |= ((unsigned)lb & 0x00010001u);
-        if (CVX) qxm |= (((unsigned)lb >> 1) & 0x00010001u);
 
         // ---- end cell bookkeeping
         if (SW) {
@@ -465,57 +415,44 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         }
 
         RP_MARK(5);  // hand-over + end-cell bookkeeping
-        // ---- stores
-        {
-            SXG_GLOBAL uint32_t* dst = g_tb + (size_t)i * P16_TB_WORDS * T;  // [row][word][lane]
-            (dst + PM_GTF * T)[ut] = gtf; (dst + PM_GTO * T)[ut] = gto;
-            (dst + PM_GTE * T)[ut] = gte; (dst + PM_GTQ * T)[ut] = gtq; (dst + PM_FX * T)[ut] = fxm;
-            (dst + PM_OX * T)[ut] = oxm; (dst + PM_EX * T)[ut] = exm; (dst + PM_QX * T)[ut] = qxm;
-        }
-        RP_MARK(6);  // mask-plane stores
-        // ---- outgoing candidates (see p16_pack_row).  A sibling successor -- single predecessor, the
-        // same as mine, not me -- wants my own F/O left in place instead.  (Requesting the next row's
-        // stored predecessor from here was tried: with the kernel at its 128-VGPR budget any spill
-        // reload behind the request is an in-order vmcnt wait on it, and the row got slower.)
+        // ---- outgoing candidates (see p16_pack_row), ring store, band store.  A sibling successor --
+        // single predecessor, the same as mine, not me -- wants my own F/O left in place instead.
         next_sib = false;
         if (np <= 1 && i < N && (i & (CH - 1)) != 0) {
             const i32x4 n0 = lmeta[2 * (i & (CH - 1))];
             const int nnp = __builtin_amdgcn_readfirstlane(n0.y) & 0xffff, np0 = __builtin_amdgcn_readfirstlane(n0.z);
             next_sib = nnp <= 1 && np0 == p0 && np0 != i;
         }
+        // band of this row: strips [bs0, bs0 + BS); my wave covers lo strips [64 wv, 64 wv + 64) and the
+        // hi strips T further on.  (wave-uniform tests; the lane test is an exec mask around the stores)
+        const int bs0 = band_first_strip(hint, W, BS, T);
+        const int w0 = wv << 6;
+        const bool band_lo = (w0 + 63 >= bs0) && (w0 < bs0 + BS);
+        const bool band_hi = (T + w0 + 63 >= bs0) && (T + w0 < bs0 + BS);
+        const bool ring = (flags & ROW_STORE) != 0;
         SXG_GLOBAL u32x2* const rdst = g_pool + (size_t)myslot * TW;
-        if (next_sib) {
-            if (flags & ROW_STORE) {
-#pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    const int tf = pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2));
-                    const int to = CVX ? pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2)) : NEG2;
-                    (rdst + k * T)[ut] = p16_pack_row<CVX>(Hc[k], tf, to);
-                }
-            }
-        } else {
-            fxm = 0; oxm = 0;
+        SXG_GLOBAL uint32_t* const pdst = g_tb + (size_t)i * (size_t)(W * BS);
+        const int sb_lo = tt - bs0, sb_hi = T + tt - bs0;
+        const bool in_lo = (unsigned)sb_lo < (unsigned)BS, in_hi = (unsigned)sb_hi < (unsigned)BS;
+        if (ring || band_lo || band_hi || !next_sib) {
 #pragma unroll
             for (int k = 0; k < W; ++k) {
-                const int c1 = pk_add(Hc[k], G2), c2 = pk_add(Fp[k], E2);
-                Fp[k] = pk_max(c1, c2);
-                SXG_SIGN_TO(fxm, pk_sub(c1, c2), k);
-                if (CVX) {
-                    const int d1 = pk_add(Hc[k], Q2), d2 = pk_add(Op[k], C2);
-                    Op[k] = pk_max(d1, d2);
-                    SXG_SIGN_TO(oxm, pk_sub(d1, d2), k);
+                const int tf = pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2));
+                const int to = CVX ? pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2)) : NEG2;
+                if (ring || band_lo || band_hi) {
+                    const u32x2 w = p16_pack_row<CVX>(Hc[k], tf, to);
+                    if (ring) (rdst + k * T)[ut] = w;
+                    if (band_lo && in_lo) (pdst + k * BS)[sb_lo] = __builtin_amdgcn_perm(w.y, w.x, 0x05040100u);
+                    if (band_hi && in_hi) (pdst + k * BS)[sb_hi] = __builtin_amdgcn_perm(w.y, w.x, 0x07060302u);
                 }
-                SXG_PIN("+v"(Fp[k]), "+v"(Op[k]), "+v"(fxm), "+v"(oxm));
-            }
-            if (flags & ROW_STORE) {
-#pragma unroll
-                for (int k = 0; k < W; ++k) (rdst + k * T)[ut] = p16_pack_row<CVX>(Hc[k], Fp[k], Op[k]);
+                if (!next_sib) { Fp[k] = tf; Op[k] = to; }
+                SXG_PIN("+v"(Fp[k]), "+v"(Op[k]));
             }
         }
 #pragma unroll
         for (int k = 0; k < W; ++k) Hp[k] = Hc[k];
         Hleft = lh;
-        RP_MARK(7);  // outgoing candidates + row store
+        RP_MARK(7);  // outgoing candidates + stores
     }
 #ifdef SXG_ROW_PROF
     if (t == 0 && B.row_prof)
@@ -554,72 +491,103 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     }
 }
 
-// Traceback over the packed mask plane (S5).  The source of H is the LAST candidate in the order
-// D, F, O, E, Q that strictly beat the running maximum (first-wins priority D > F > O > E > Q),
-// unless the cell is a STOP.
-// Windowed walk.  The replay is a chain of dependent reads, so one lane chasing HBM (the first
-// version) paid a full memory round trip per step -- 18 % of the slot time on the headline
-// workload.  Here the whole of wave 0 takes part: lane l fetches, in ONE round trip, everything a
-// step through row (top - l) can need -- the mask words of the two lane-columns around the
-// diagonal through the current cell, the row descriptor and the node id -- into an LDS window of 64
-// rows; the walk itself then runs out of LDS (every lane executes it redundantly, lane 0 writes)
-// and only returns to HBM when it leaves the window (an indel run wider than half a strip, a
-// predecessor far up the order, the hi -> lo half crossing) or needs a fold-step plane of a
-// multi-predecessor row.
+// ---------------------------------------------------------------------------------------------------
+// Traceback of the packed sweep: the alignment is DERIVED from the plane's values (rules: header of this
+// file and oracle/poa_vtb.c).  The walk is a chain of dependent reads, so the whole of wave 0 takes part:
+// lane l fetches, in two round trips, what a step through row (top - l) can need -- the row descriptor,
+// the node id and the plane cells of 8 columns around the column where the alignment is expected to cross
+// that row (L/N columns per graph row) -- into an LDS window of 64 rows; the walk itself runs out of LDS on
+// the scalar unit (every lane executes it redundantly, lane 0 writes) and returns to HBM only for a cell
+// the window does not hold (an indel run, a predecessor far up the order) and for the leftward scans that
+// resolve a gap in the graph (E/Q), which all 64 lanes do together, 64 columns per round trip.
 constexpr int TBW_ROWS = 64;
-constexpr int TBW_STRIDE = 29;  // dwords per window row (odd: conflict-free fills)
-// window row: 2 x P16_TB_WORDS mask words, then
-enum : int { EO_PB = 16, EO_INFO = 17, EO_Q0 = 18, EO_Q1 = 19, EO_NODE = 20, EO_STEP = 21 /* ..26 */, EO_TX = 27 };
-static_assert(2 * P16_TB_WORDS == EO_PB, "window row layout");
-static_assert((TBW_ROWS * TBW_STRIDE + TBW_ROWS) * 4 <= LDS_META_BYTES, "traceback window lives in the descriptor area");
-static_assert((TBW_ROWS / 2 * TBW_STRIDE + TBW_ROWS / 2) * 4 <= LDS_META_BYTES / 2, "... also the half-size one");
+constexpr int TBW_STRIDE = 13;  // dwords per window row (odd: conflict-free fills)
+constexpr int TBW_COLS = 8;     // plane cells per window row
+// window row: TBW_COLS cells, then
+enum : int { EO_PB = 8, EO_INFO = 9, EO_Q0 = 10, EO_Q1 = 11, EO_NODE = 12 /* node | valid-cell mask << 24 */ };
+constexpr int TBW_LET = 128;    // query letters of columns jtop, jtop-1, ... kept beside the window
+static_assert((TBW_ROWS * TBW_STRIDE + TBW_LET) * 4 <= LDS_META_BYTES / 2, "traceback window lives in the descriptor area");
 
-// H is tracked along the walk (hv): it starts at the end cell's score and every recorded step is undone
-// -- a diagonal step subtracts the letter score, leaving a gap state subtracts the opening cost, each
-// extension the extension cost.  A local alignment ends at the first H = 0 (STOP has top priority, S5), so
-// the sweep records no STOP bit.  The query letters of the window's diagonal ride along in the window.
-template <bool PAIRS, int W>
+// words of LDS (control area) through which the walk reports a band miss to the workgroup
+enum : int { TBM_FLAG = 208, TBM_ROW = 209, TBM_DELTA = 210 };
+
+template <bool PAIRS, int W, bool CVX>
 // (views by value: a reference to the kernel's private copy trips an AMDGPU back-end assertion on
 // the private-aperture null check for some strip widths)
-__device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const Scoring S_, const uint8_t* seq, const int best_,
-                                          const int T_, const int slope_, int i, int j, int32_t* posnode, int32_t* pair_row,
-                                          int32_t* pair_pos, char* smem) {
+__device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const Scoring S_, const uint8_t* seq, const int L_,
+                                          const int best_, const int T_, const int slope_, int i, int j, int32_t* posnode,
+                                          int32_t* pair_row, int32_t* pair_pos, char* smem) {
     // arguments arrive in vector registers: make the uniform ones scalar again
     const int T = __builtin_amdgcn_readfirstlane(T_), best = __builtin_amdgcn_readfirstlane(best_);
+    const int L = __builtin_amdgcn_readfirstlane(L_);
     // columns the alignment advances per graph row, in 1/256: a graph of N rows against L letters is
     // walked at about L/N columns per row (rows of other branches are skipped), which is where the
     // window is laid
     const int slope = __builtin_amdgcn_readfirstlane(slope_);
     i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
-    Scoring S;
-    S.m = __builtin_amdgcn_readfirstlane(S_.m); S.n = __builtin_amdgcn_readfirstlane(S_.n); S.g = __builtin_amdgcn_readfirstlane(S_.g);
-    S.e = __builtin_amdgcn_readfirstlane(S_.e); S.q = __builtin_amdgcn_readfirstlane(S_.q); S.c = __builtin_amdgcn_readfirstlane(S_.c);
-    S.sw = __builtin_amdgcn_readfirstlane(S_.sw); S.convex = S_.convex;
+    const int sm = __builtin_amdgcn_readfirstlane(S_.m), sn = __builtin_amdgcn_readfirstlane(S_.n);
+    const int g = __builtin_amdgcn_readfirstlane(S_.g), e = __builtin_amdgcn_readfirstlane(S_.e);
+    const int q = __builtin_amdgcn_readfirstlane(S_.q), c = __builtin_amdgcn_readfirstlane(S_.c);
+    const int sw = __builtin_amdgcn_readfirstlane(S_.sw);
+    const int BS = __builtin_amdgcn_readfirstlane(B.band_strips);
     // outputs and letters through global pointers: a FLAT store also counts on lgkmcnt, and the walk
-    // waits on lgkmcnt for its LDS reads every step -- i.e. it waited for the previous step's store to
-    // reach HBM (measured: ~2 500 cycles per step)
+    // waits on lgkmcnt for its LDS reads every step -- i.e. it would wait for the previous step's store to
+    // reach HBM
     SXG_GLOBAL int32_t* const g_posnode = sxg_global(posnode);
     SXG_GLOBAL int32_t* const g_pair_row = sxg_global(pair_row);
     SXG_GLOBAL int32_t* const g_pair_pos = sxg_global(pair_pos);
     SXG_GLOBAL const uint8_t* const g_seq = sxg_global(seq);
-    const int TW = T * W;
+    SXG_GLOBAL const uint32_t* const g_plane = sxg_global((const uint32_t*)B.tb);
+    SXG_GLOBAL const int32_t* const g_meta = sxg_global((const int32_t*)R.meta);
+    SXG_GLOBAL const int32_t* const g_preds = sxg_global((const int32_t*)R.preds);
+    SXG_GLOBAL const int32_t* const g_row_node = sxg_global((const int32_t*)R.row_node);
     const int lane = threadIdx.x & 63;
-    const int sw = S.sw;
-    // the block's only serial phase (three waves wait for this one): a dependent-read chain that
+    int* ctl = (int*)smem;
+    // the block's only serial phase (the other waves wait for this one): a dependent-read chain that
     // rarely has an instruction ready, so top priority costs the co-residents next to nothing
     __builtin_amdgcn_s_setprio(3);
     uint32_t* win = (uint32_t*)(smem + LDS_CTL_BYTES);
-    const int WR = dp16_meta_bytes(T) < LDS_META_BYTES ? TBW_ROWS / 2 : TBW_ROWS;  // window rows
-    uint32_t* wlet = win + WR * TBW_STRIDE;  // [WR] query letters of columns jtop, jtop-1, ...
-    // first of the two lane-columns fetched for a row whose expected (half-local) column is x
-    auto col0 = [&](int x) -> int { return x < W / 2 ? 0 : min((x - W / 2) / W, T - 2); };
-    int n = 0, st = SRC_STOP;
-    int hv = best, gv = 0;  // H of the current cell (state H) / value of the gap state being walked
-    int wtop = -1, wjj = 0, whalf = -1, wj = 0;
+    const int WR = TBW_ROWS;  // window rows
+    uint32_t* wlet = win + TBW_ROWS * TBW_STRIDE;  // [TBW_LET] query letters of columns jtop, jtop-1, ...
+    const int kmax_e = CVX ? 1 + (g - q) / (c - e) : 0x7fffffff;  // longest gap the first piece can win (poa_vtb.c)
+#define TBU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+    // H of the virtual row 0
+    auto h_row0 = [&](int col) -> int {
+        if (sw || col <= 0) return 0;
+        const int a = g + (col - 1) * e, b = q + (col - 1) * c;
+        return max(a > b ? a : b, NEGP);
+    };
+    int wtop = -1, wj = 0;
+    bool miss = false;
+    int miss_row = 0, miss_delta = 0;
+    // plane cell (row p >= 1, column col) straight from HBM; a cell outside the row's band is a miss
+    auto gcell = [&](int p, int col) -> uint32_t {
+        const int hint = (int)TBU(g_meta[8 * (size_t)(p - 1) + 7]);
+        const int s = col / W, k = col - s * W, sb = s - band_first_strip(hint, W, BS, T);
+        if ((unsigned)sb >= (unsigned)BS) {
+            if (!miss) { miss = true; miss_row = p; miss_delta = col - hint; }
+            return 0u;
+        }
+        return TBU(g_plane[((size_t)p * W + k) * BS + sb]);
+    };
+    auto wcol0 = [&](int l) -> int { return wj - ((l * slope) >> 8) - (TBW_COLS - 3); };  // first column the window holds of row wtop-l
+    auto cell = [&](int p, int col) -> uint32_t {
+        const int l = wtop - p;
+        if (wtop >= 0 && (unsigned)l < (unsigned)WR) {
+            const int x = col - wcol0(l);
+            if ((unsigned)x < (unsigned)TBW_COLS && ((TBU(win[l * TBW_STRIDE + EO_NODE]) >> (24 + x)) & 1u))
+                return TBU(win[l * TBW_STRIDE + x]);
+        }
+        return gcell(p, col);
+    };
+    auto sext = [](uint32_t w) -> int { return (int)(short)(w & 0xffffu); };
+    int n = 0;
+    int st = SRC_STOP;           // SRC_STOP = "in H", SRC_F / SRC_O = walking up a gap in the sequence
+    int hv = best, gv = 0;       // H of the current cell / value of the gap state being walked
 #ifdef SXG_ROW_PROF
     unsigned long long tb_steps = 0, tb_loads = 0, tb_t0 = __builtin_readcyclecounter(), tb_ld = 0;
 #endif
-    for (;;) {
+    while (!miss) {
 #ifdef SXG_ROW_PROF
         ++tb_steps;
 #endif
@@ -630,110 +598,163 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             continue;
         }
         if (sw && st == SRC_STOP && hv == 0) break;
-        const int r = i - 1;
-        const int half = j >= TW ? 1 : 0, jj = j - half * TW;
-        const int lt = jj / W, bit = (jj - lt * W) + 16 * half;
-        int l = wtop - i;
-        int c0 = col0(wjj - ((l * slope) >> 8));
-        // (the letters must come from the window as well: a global fallback load inside the step makes the
-        // compiler wait for vmcnt(0) at the merge, i.e. for the previous step's posnode store to reach HBM)
-        if (wtop < 0 || l < 0 || l >= WR || half != whalf || (unsigned)(lt - c0) > 1u || (unsigned)(wj - j) >= (unsigned)WR) {
-            wtop = i; wjj = jj; whalf = half; wj = j;
+        {   // (re)fill the window when row i or column j leave it
+            const int l = wtop - i;
+            const int x = j - wcol0(l);
+            if (wtop < 0 || l < 0 || l > WR - 3 || x < 2 || x >= TBW_COLS) {
+                wtop = i; wj = j;
 #ifdef SXG_ROW_PROF
-            ++tb_loads;
-            const unsigned long long tl0 = __builtin_readcyclecounter();
+                ++tb_loads;
+                const unsigned long long tl0 = __builtin_readcyclecounter();
 #endif
-            const int row = i - lane;
-            if (row >= 1 && lane < WR) {
-                const int c = col0(jj - ((lane * slope) >> 8));
-                SXG_GLOBAL const uint32_t* mw = sxg_global((const uint32_t*)B.tb) + (size_t)row * P16_TB_WORDS * T + c;  // [row][word][lane]
-                uint32_t v[2 * P16_TB_WORDS];
+                const int row = i - lane;
+                if (row >= 1 && lane < WR) {
+                    SXG_GLOBAL const i32x4* dm = (SXG_GLOBAL const i32x4*)(g_meta + 8 * (size_t)(row - 1));
+                    const i32x4 d0 = dm[0], d1 = dm[1];
+                    const int node = g_row_node[row - 1];
+                    const int bs0 = band_first_strip(d1.w, W, BS, T);
+                    const int c0 = wcol0(lane);
+                    uint32_t v[TBW_COLS], valid = 0;
 #pragma unroll
-                for (int x = 0; x < P16_TB_WORDS; ++x) { v[x] = mw[(size_t)x * T]; v[P16_TB_WORDS + x] = mw[(size_t)x * T + 1]; }
-                SXG_GLOBAL const i32x4* dm = (SXG_GLOBAL const i32x4*)(sxg_global((const int32_t*)R.meta) + 8 * (size_t)(row - 1));
-                const i32x4 d0 = dm[0], d1 = dm[1];
-                const int node = sxg_global((const int32_t*)R.row_node)[row - 1];
-                uint32_t* e = win + lane * TBW_STRIDE;
+                    for (int x2 = 0; x2 < TBW_COLS; ++x2) {
+                        const int col = c0 + x2;
+                        const int s = col / W, k = col - s * W, sb = s - bs0;
+                        v[x2] = 0;
+                        if (col >= 0 && col <= L && (unsigned)sb < (unsigned)BS) {
+                            v[x2] = g_plane[((size_t)row * W + k) * BS + sb];
+                            valid |= 1u << x2;
+                        }
+                    }
+                    uint32_t* en = win + lane * TBW_STRIDE;
 #pragma unroll
-                for (int x = 0; x < 2 * P16_TB_WORDS; ++x) e[x] = v[x];
-                e[EO_PB] = (uint32_t)d0.x; e[EO_INFO] = (uint32_t)d0.y; e[EO_Q0] = (uint32_t)d0.z; e[EO_Q1] = (uint32_t)d1.x;
-                e[EO_NODE] = (uint32_t)node; e[EO_TX] = (uint32_t)d1.w;
-                if ((d0.y & 0xffff) >= 2) {  // first fold step of a multi-predecessor row (D, F, O planes)
-                    SXG_GLOBAL const uint32_t* sp = sxg_global((const uint32_t*)B.steps) + (size_t)d1.w * 3 * T + c;
-#pragma unroll
-                    for (int w3 = 0; w3 < 3; ++w3) { e[EO_STEP + 2 * w3] = sp[(size_t)w3 * T]; e[EO_STEP + 1 + 2 * w3] = sp[(size_t)w3 * T + 1]; }
+                    for (int x2 = 0; x2 < TBW_COLS; ++x2) en[x2] = v[x2];
+                    en[EO_PB] = (uint32_t)d0.x; en[EO_INFO] = (uint32_t)d0.y; en[EO_Q0] = (uint32_t)d0.z; en[EO_Q1] = (uint32_t)d1.x;
+                    en[EO_NODE] = (uint32_t)node | (valid << 24);
                 }
-            }
-            if (lane < WR) wlet[lane] = (j - lane >= 1) ? (uint32_t)g_seq[j - lane - 1] : 255u;  // (letters: one per column)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            l = 0; c0 = col0(jj);
+                // (letters: one per column; the walk never reads them from HBM -- a global load inside a step
+                // makes the compiler wait for vmcnt(0) there, i.e. for the previous step's output store)
+                wlet[lane] = (j - lane >= 1) ? (uint32_t)g_seq[j - lane - 1] : 255u;
+                wlet[64 + lane] = (j - 64 - lane >= 1) ? (uint32_t)g_seq[j - 64 - lane - 1] : 255u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef SXG_ROW_PROF
-            tb_ld += __builtin_readcyclecounter() - tl0;
+                tb_ld += __builtin_readcyclecounter() - tl0;
 #endif
+            }
         }
         // Everything the walk reads is the same for all lanes; saying so (readfirstlane) keeps its state
         // in scalar registers and its control flow on the scalar unit instead of 64-wide selects and
-        // exec-mask juggling (measured before: ~2 700 cycles per step).
-#define TBU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-        const uint32_t* e = win + l * TBW_STRIDE;
-        const uint32_t* m = e + (lt - c0) * P16_TB_WORDS;
-        const int pb = (int)TBU(e[EO_PB]), info = (int)TBU(e[EO_INFO]), q0 = (int)TBU(e[EO_Q0]), q1 = (int)TBU(e[EO_Q1]), node = (int)TBU(e[EO_NODE]);
-        const int np = info & 0xffff;
-        auto pred_of = [&](int which) -> int {
+        // exec-mask juggling.
+        const uint32_t* en = win + (wtop - i) * TBW_STRIDE;
+        const int pb = (int)TBU(en[EO_PB]), info = (int)TBU(en[EO_INFO]), q0 = (int)TBU(en[EO_Q0]), q1 = (int)TBU(en[EO_Q1]);
+        const int node = (int)(TBU(en[EO_NODE]) & 0x00ffffffu);
+        const int np = info & 0xffff, npe = np > 0 ? np : 1;
+        auto pred_at = [&](int x) -> int {
             if (np == 0) return 0;
-            if (np == 1) return q0;
-            const int tx = (int)TBU(e[EO_TX]);
-            int ord = 0;
-            for (int x = np - 1; x >= 2 && !ord; --x)
-                if ((TBU(sxg_global((const uint32_t*)B.steps)[((size_t)(tx + x - 1) * 3 + which) * T + lt]) >> bit) & 1u) ord = x;
-            if (!ord) ord = (int)((TBU(e[EO_STEP + 2 * which + (lt - c0)]) >> bit) & 1u);
-            return ord == 0 ? q0 : (ord == 1 ? q1 : (int)TBU(sxg_global((const int32_t*)R.preds)[pb + ord]));
+            return x == 0 ? q0 : (x == 1 ? q1 : (int)TBU(g_preds[pb + x]));
         };
         if (st == SRC_STOP) {
-            int src;
-            const uint32_t mq = TBU(m[PM_GTQ]), me = TBU(m[PM_GTE]), mo = TBU(m[PM_GTO]), mf = TBU(m[PM_GTF]);
-            if ((mq >> bit) & 1u) src = SRC_Q;
-            else if ((me >> bit) & 1u) src = SRC_E;
-            else if ((mo >> bit) & 1u) src = SRC_O;
-            else if ((mf >> bit) & 1u) src = SRC_F;
-            else src = SRC_D;
-            if (src == SRC_D) {
-                if (lane == 0) {
-                    if (PAIRS) { g_pair_row[n] = i; g_pair_pos[n] = j - 1; }
-                    if (posnode) g_posnode[j - 1] = node;
+            bool done = false;
+            if (j >= 1) {   // D: the first predecessor (list order) with the greatest H[p][j-1]
+                int dmax = -0x40000000, dp = 0;
+                for (int x = 0; x < npe; ++x) {
+                    const int p = pred_at(x);
+                    const int hp = p == 0 ? h_row0(j - 1) : sext(cell(p, j - 1));
+                    if (hp > dmax) { dmax = hp; dp = p; }
                 }
-                ++n;
-                const int letter = (int)TBU(wlet[wj - j]);
-                hv -= (letter == ((info >> 16) & 0xff)) ? S.m : S.n;
-                i = pred_of(0);
-                --j;
-            } else { st = src; gv = hv; }
-        } else if (st == SRC_F || st == SRC_O) {
-            const bool isf = st == SRC_F;
-            const unsigned ext = (TBU(m[isf ? PM_FX : PM_OX]) >> bit) & 1u;
-            if (PAIRS && lane == 0) { g_pair_row[n] = i; g_pair_pos[n] = -1; }
-            ++n;
-            i = pred_of(isf ? 1 : 2);
-            if (ext) gv -= isf ? S.e : S.c;
-            else { hv = gv - (isf ? S.g : S.q); st = SRC_STOP; }
+                const int lo = wj - j;
+                const int letter = (unsigned)lo < (unsigned)TBW_LET ? (int)TBU(wlet[lo]) : (int)TBU(g_seq[j - 1]);
+                if (!miss && dmax + (letter == ((info >> 16) & 0xff) ? sm : sn) == hv) {
+                    if (lane == 0) {
+                        if (PAIRS) { g_pair_row[n] = i; g_pair_pos[n] = j - 1; }
+                        if (posnode) g_posnode[j - 1] = node;
+                    }
+                    ++n;
+                    i = dp; --j; hv = dmax;
+                    done = true;
+                }
+            }
+            if (!done && !miss) {   // F, then O: a predecessor's outgoing candidate equals H
+                int fmax = -0x40000000, omax = -0x40000000;
+                for (int x = 0; x < npe; ++x) {
+                    const int p = pred_at(x);
+                    int of, oo;
+                    if (p == 0) { const int h0 = h_row0(j); of = h0 + g; oo = h0 + q; }
+                    else { const uint32_t w = cell(p, j); const int h = sext(w); of = h - (int)((w >> 16) & 0xffu); oo = h - (int)(w >> 24); }
+                    fmax = max(fmax, of); omax = max(omax, oo);
+                }
+                if (!miss) {
+                    if (fmax == hv) { st = SRC_F; gv = hv; done = true; }
+                    else if (CVX && omax == hv) { st = SRC_O; gv = hv; done = true; }
+                }
+            }
+            if (!done && !miss) {
+                // a gap in the graph.  E: smallest k with H[i][j-k] + g + (k-1) e == hv (k <= kmax_e), else Q
+                // likewise with q, c; 64 columns per round trip, straight from the plane.
+                const int hint = (int)TBU(g_meta[8 * (size_t)(i - 1) + 7]);
+                const int bs0 = band_first_strip(hint, W, BS, T);
+                int kk = 0, hnew = 0;
+                for (int piece = 0; piece < (CVX ? 2 : 1) && !kk && !miss; ++piece) {
+                    const int go = piece ? q : g, ge = piece ? c : e;
+                    const int kcap = piece ? j : min(j, kmax_e);
+                    for (int base = 0; base < kcap && !kk && !miss; base += 64) {
+                        const int x = base + lane + 1;
+                        const bool act = x <= kcap;
+                        const int col = j - x;
+                        const int s = col / W, k = col - s * W, sb = s - bs0;
+                        const bool inb = (unsigned)sb < (unsigned)BS;
+                        int hval = 0;
+                        if (act && inb) hval = sext(g_plane[((size_t)i * W + k) * BS + sb]);
+                        const unsigned long long meq = __ballot(act && inb && hval + go + (x - 1) * ge == hv);
+                        const unsigned long long moob = __ballot(act && !inb);
+                        const int feq = meq ? (int)__builtin_ctzll(meq) : 64, foob = moob ? (int)__builtin_ctzll(moob) : 64;
+                        if (foob < feq) { miss = true; miss_row = i; miss_delta = (j - (base + foob + 1)) - hint; }
+                        else if (meq) { kk = base + feq + 1; hnew = __builtin_amdgcn_readlane(hval, feq); }
+                    }
+                }
+                if (!miss) {
+                    if (!kk) { miss = true; miss_row = i; miss_delta = 0; }   // (cannot happen: some candidate equals H)
+                    else {
+                        if (PAIRS)
+                            for (int x = lane; x < kk; x += 64) { g_pair_row[n + x] = 0; g_pair_pos[n + x] = j - 1 - x; }
+                        n += kk; j -= kk; hv = hnew;
+                    }
+                }
+            }
         } else {
-            const bool ise = st == SRC_E;
-            const unsigned ext = (TBU(m[ise ? PM_EX : PM_QX]) >> bit) & 1u;
-            if (PAIRS && lane == 0) { g_pair_row[n] = 0; g_pair_pos[n] = j - 1; }
-            ++n; --j;
-            if (ext) gv -= ise ? S.e : S.c;
-            else { hv = gv - (ise ? S.g : S.q); st = SRC_STOP; }
+            // walking up a gap in the sequence: the first predecessor whose outgoing candidate carries gv;
+            // it OPENED the gap iff its H + g (q) is that value, else the walk continues in it with gv - e (c)
+            const bool isf = st == SRC_F;
+            const int go = isf ? g : q, ge = isf ? e : c;
+            int pp = -1, hp = 0;
+            for (int x = 0; x < npe && pp < 0; ++x) {
+                const int p = pred_at(x);
+                int h, oc;
+                if (p == 0) { h = h_row0(j); oc = h + go; }
+                else { const uint32_t w = cell(p, j); h = sext(w); oc = h - (int)(isf ? ((w >> 16) & 0xffu) : (w >> 24)); }
+                if (oc == gv) { pp = p; hp = h; }
+            }
+            if (!miss) {
+                if (pp < 0) { miss = true; miss_row = i; miss_delta = 0; }   // (cannot happen)
+                else {
+                    if (PAIRS && lane == 0) { g_pair_row[n] = i; g_pair_pos[n] = -1; }
+                    ++n;
+                    i = pp;
+                    if (hp + go == gv) { st = SRC_STOP; hv = hp; } else gv -= ge;
+                }
+            }
         }
     }
 #undef TBU
+    if (lane == 0) { ctl[TBM_FLAG] = miss ? 1 : 0; ctl[TBM_ROW] = miss_row; ctl[TBM_DELTA] = miss_delta; }
 #ifdef SXG_ROW_PROF
     if (lane == 0 && B.row_prof) {
         B.row_prof[8] += tb_steps; B.row_prof[9] += tb_loads;
         B.row_prof[10] += __builtin_readcyclecounter() - tb_t0; B.row_prof[11] += tb_ld;
     }
 #endif
+    __builtin_amdgcn_s_setprio(0);
     return n;
 }
 

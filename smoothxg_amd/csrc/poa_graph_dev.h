@@ -127,10 +127,13 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq_,
             const int ld = G.leader[G.posnode[i]];
             G.leader[v] = ld;
             slot = group_end(G, ld, n_old) + 1;
+            G.xpos[v] = G.xpos[G.posnode[i]];
         } else {
             G.leader[v] = v;
             G.gmem[5 * v + cc] = v;
             const int s = G.nexta[i], p = G.preva[i];
+            // band hint: continue the backbone coordinate of the nearest aligned neighbour
+            G.xpos[v] = p >= 0 ? G.xpos[G.posnode[p]] + (i - p) : (s < len ? G.xpos[G.posnode[s]] - (s - i) : i + 1);
             if (s < len) {
                 const int anchor = G.kind[s] == 0 ? G.target[s] : G.posnode[s];
                 slot = group_start(G, G.leader[anchor], n_old);
@@ -205,8 +208,9 @@ struct RowCaps {
 // stand-alone align kernel (caller CSR -> rows).  On entry R.flags holds STORE/SINK bits and
 // R.slot[r] the rank of the last reader of row r.  Assigns ring slots of the row pool and
 // the step-mask plane offset of multi-pred rows.  Returns a status (same on every thread).
+// `hinted`: packed sweep -- R.tbx already holds the band hint of every row and there is no step-mask plane.
 template <class Ctx>
-SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps) {
+SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps, const bool hinted = false) {
     const int T = c.nthreads(), t = c.tid();
     c.sync();
     const int n_store = array_excl_sum(c, N, [&](int r) { return (R.flags[r] & ROW_STORE) ? 1 : 0; }, R.sseq);
@@ -222,15 +226,17 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
     }
     worst = c.reduce_max(worst);
     if (worst > caps.pool_slots) return ST_POOL_OVERFLOW;
-    // multi-pred rows: np-1 fold steps each in the step-mask plane
-    const int n_steps = array_excl_sum(c, N, [&](int r) {
-        const int d = R.pred_off[r + 1] - R.pred_off[r];
-        return d > 1 ? d - 1 : 0; }, R.tbx);
-    c.sync();
-    if (n_steps > caps.step_cap) return ST_TBX_OVERFLOW;
-    for (int r = t; r < N; r += T)
-        if (R.pred_off[r + 1] - R.pred_off[r] <= 1) R.tbx[r] = -1;
-    c.sync();
+    if (!hinted) {
+        // multi-pred rows: np-1 fold steps each in the step-mask plane
+        const int n_steps = array_excl_sum(c, N, [&](int r) {
+            const int d = R.pred_off[r + 1] - R.pred_off[r];
+            return d > 1 ? d - 1 : 0; }, R.tbx);
+        c.sync();
+        if (n_steps > caps.step_cap) return ST_TBX_OVERFLOW;
+        for (int r = t; r < N; r += T)
+            if (R.pred_off[r + 1] - R.pred_off[r] <= 1) R.tbx[r] = -1;
+        c.sync();
+    }
     for (int r = t; r < N; r += T) {
         const int pb = R.pred_off[r], np = R.pred_off[r + 1] - pb;
         RowMeta m;
@@ -252,7 +258,7 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
 // Rank-space CSR + per-row DP metadata of the current graph.  Returns a status code
 // (identical on every thread).
 template <class Ctx>
-SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const RowCaps& caps) {
+SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const RowCaps& caps, const bool hinted = false) {
     const int T = c.nthreads(), t = c.tid();
     c.sync();
     const int N = *G.n_nodes;
@@ -261,6 +267,7 @@ SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const 
         const int v = G.order[r];
         R.row_node[r] = v;
         R.code[r] = G.code[v];
+        if (hinted) R.tbx[r] = G.xpos[v];
     }
     const int E = array_excl_sum(c, N, [&](int r) { return G.in_deg[G.order[r]]; }, R.pred_off);
     if (t == 0) R.pred_off[N] = E;
@@ -279,7 +286,7 @@ SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const 
         R.flags[r] = (uint8_t)((store ? ROW_STORE : 0) | (G.out_deg[v] == 0 ? ROW_SINK : 0));
         R.slot[r] = lu;
     }
-    return finish_rows(c, N, R, caps);
+    return finish_rows(c, N, R, caps, hinted);
 }
 
 // S8: heaviest bundle + branch completion.  One thread; scores in sc (int64), preds in pr.

@@ -36,6 +36,7 @@ enum : int {
     ST_NODES_OVERFLOW = 4,
     ST_TOO_LONG = 5,
     ST_RANGE_OVERFLOW = 6,  // a global alignment outgrew the score range of the narrow sweep (re-run wider)
+    ST_BAND_MISS = 7,       // packed sweep: the traceback kept leaving the band of stored cells (re-run with the 32-bit sweep)
 };
 
 // Lower bound of every reachable global-alignment score: the all-gap path (a gap down a chain of
@@ -73,6 +74,10 @@ struct GraphView {
     // scratch for add_alignment (length >= max sequence length / max nodes + 1)
     SXG_GP int32_t *posnode, *target, *newidx, *nexta, *preva, *slotadd;
     SXG_GP int8_t *kind;
+    // backbone coordinate of every node: the DP column at which it is expected to align (first
+    // sequence: its own position; later nodes inherit / interpolate from the nodes they were aligned
+    // next to).  Centres the band of cells the packed sweep keeps for the traceback; never affects results.
+    SXG_GP int32_t *xpos;
 };
 
 // Row structures of the current graph in rank space, rebuilt before every alignment.
@@ -82,8 +87,9 @@ struct RowsView {
     SXG_GP int32_t *pred_off;   // [N+1]
     SXG_GP int32_t *preds;      // [E] row indices (rank+1), in-edge insertion order
     SXG_GP int32_t *slot;       // [N] row-pool slot of stored rows
-    SXG_GP int32_t *tbx;        // [N] first fold step of a multi-pred row in the step-mask plane
-                         //      (row with np preds owns np-1 steps); -1: single-pred row
+    SXG_GP int32_t *tbx;        // [N] 32-bit sweep: first fold step of a multi-pred row in the step-mask plane
+                         //      (row with np preds owns np-1 steps); -1: single-pred row.
+                         //      packed sweep: band hint = expected DP column of the row's node
     SXG_GP int32_t *sseq;       // [N+1] exclusive count of stored rows (scratch)
     SXG_GP int32_t *row_node;   // [N] node id at rank
     SXG_GP int32_t *meta;       // [N*8] per-row DP descriptor, see RowMeta
@@ -97,7 +103,7 @@ struct RowMeta {
     int p0, s0;    // first predecessor row (0 = virtual source) and its pool slot (-1: none/regs)
     int p1, s1;    // second predecessor row / slot (np >= 2)
     int slot;      // own pool slot (-1: row not stored)
-    int tbx;       // first fold step in the step-mask plane, as RowsView::tbx
+    int tbx;       // as RowsView::tbx (fold step / band hint)
 };
 
 }  // namespace sxg

@@ -28,9 +28,10 @@ using namespace sxg;
 struct SlotLayout {  // byte offsets inside one slot arena (all 16-byte aligned)
     size_t hdr, code, rank, order, order_tmp, leader, gmem, in_head, in_tail, out_head, out_tail, in_deg,
         out_deg, e_tail, e_head, e_next_in, e_next_out, e_w, posnode, target, newidx, nexta, preva, slotadd,
-        kind, r_code, r_flags, r_pred_off, r_preds, r_slot, r_tbx, r_sseq, r_row_node, r_meta, tb, steps, pool,
+        kind, xpos, r_code, r_flags, r_pred_off, r_preds, r_slot, r_tbx, r_sseq, r_row_node, r_meta, tb, steps, pool,
         row0, park, cons_sc, cons_pr, pair_row, pair_pos, total;
     int nodes_cap, rows_cap, pool_slots, step_cap, scratch_len, Lpad, word_bytes, threads;
+    int band_strips;  // packed sweep: strips per row in the traceback plane (0 = not the packed sweep)
 };
 
 static size_t lay(size_t& cur, size_t bytes) {
@@ -39,12 +40,15 @@ static size_t lay(size_t& cur, size_t bytes) {
     return o;
 }
 
+// band_strips > 0: packed sweep with strips of Lpad / (2 * threads) columns
 static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int step_cap, int threads, int Lpad,
-                              int word_bytes, bool pairs, bool packed = false) {
+                              int word_bytes, bool pairs, int band_strips = 0) {
     SlotLayout L;
     memset(&L, 0, sizeof(L));
     L.nodes_cap = nodes_cap; L.rows_cap = rows_cap; L.pool_slots = pool_slots;
     L.step_cap = step_cap; L.threads = threads; L.Lpad = Lpad; L.word_bytes = word_bytes;
+    L.band_strips = band_strips;
+    const bool packed = band_strips > 0;
     const size_t C = (size_t)nodes_cap + 4, S = (size_t)std::max(nodes_cap, Lpad) + 4, Rr = (size_t)rows_cap + 4;
     L.scratch_len = (int)S;
     size_t cur = 0;
@@ -58,12 +62,13 @@ static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int s
     L.e_next_out = lay(cur, 4 * C); L.e_w = lay(cur, 4 * C);
     L.posnode = lay(cur, 4 * S); L.target = lay(cur, 4 * S); L.newidx = lay(cur, 4 * S);
     L.nexta = lay(cur, 4 * S); L.preva = lay(cur, 4 * S); L.slotadd = lay(cur, 4 * S); L.kind = lay(cur, S);
+    L.xpos = lay(cur, 4 * C);
     L.r_code = lay(cur, Rr); L.r_flags = lay(cur, Rr); L.r_pred_off = lay(cur, 4 * Rr);
     L.r_preds = lay(cur, 4 * C); L.r_slot = lay(cur, 4 * Rr); L.r_tbx = lay(cur, 4 * Rr);
     L.r_sseq = lay(cur, 4 * Rr); L.r_row_node = lay(cur, 4 * Rr); L.r_meta = lay(cur, 32 * Rr);
-    // traceback plane: one byte per cell, or (packed sweep) 8 mask words per lane and row
-    L.tb = lay(cur, ((size_t)rows_cap + 1) * (packed ? (size_t)threads * P16_TB_WORDS * 4 : (size_t)Lpad));
-    L.steps = lay(cur, (size_t)std::max(step_cap, 1) * 3 * threads * 4);
+    // traceback plane: one byte per cell, or (packed sweep) one dword per cell of the row's band of strips
+    L.tb = lay(cur, ((size_t)rows_cap + 1) * (packed ? (size_t)band_strips * (size_t)(Lpad / (2 * threads)) * 4 : (size_t)Lpad));
+    L.steps = lay(cur, packed ? 256 : (size_t)std::max(step_cap, 1) * 3 * threads * 4);
     L.pool = lay(cur, (size_t)pool_slots * Lpad * word_bytes);
     L.row0 = lay(cur, (size_t)Lpad * word_bytes);
     L.park = lay(cur, (size_t)Lpad * word_bytes);
@@ -95,11 +100,13 @@ __device__ static SlotViews slot_views(uint8_t* base, const SlotLayout& L) {
     V.G.e_next_out = P32(e_next_out); V.G.e_w = (SXG_GP uint32_t*)(base + L.e_w);
     V.G.posnode = P32(posnode); V.G.target = P32(target); V.G.newidx = P32(newidx); V.G.nexta = P32(nexta);
     V.G.preva = P32(preva); V.G.slotadd = P32(slotadd); V.G.kind = (SXG_GP int8_t*)(base + L.kind);
+    V.G.xpos = P32(xpos);
     V.R.code = (SXG_GP uint8_t*)(base + L.r_code); V.R.flags = (SXG_GP uint8_t*)(base + L.r_flags); V.R.pred_off = P32(r_pred_off);
     V.R.preds = P32(r_preds); V.R.slot = P32(r_slot); V.R.tbx = P32(r_tbx); V.R.sseq = P32(r_sseq);
     V.R.row_node = P32(r_row_node); V.R.meta = P32(r_meta);
     V.B.tb = base + L.tb; V.B.steps = (uint32_t*)(base + L.steps);
     V.B.pool = base + L.pool; V.B.row0 = base + L.row0; V.B.park = base + L.park;
+    V.B.band_strips = L.band_strips;
     V.cons_sc = (int64_t*)(base + L.cons_sc); V.cons_pr = (int32_t*)(base + L.cons_pr);
     V.pair_row = (int32_t*)(base + L.pair_row); V.pair_pos = (int32_t*)(base + L.pair_pos);
 #undef P32
@@ -209,21 +216,46 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             }
             if (N > 0 && len > 0) {
                 PROF(0);
-                status = prep_rows(ctx, V.G, V.R, caps);
+                status = prep_rows(ctx, V.G, V.R, caps, RM == 2);
                 if (status != ST_OK) break;
                 PROF(1);
                 DpResult res;
                 V.B.prio_rem0 = est_total > done_cells ? est_total - done_cells : 0ull;
-                if constexpr (RM == 2) dp_fill_p16<W, CVX, SW>(S, V.R, N, seq, len, V.B, smem, res);
-                else dp_fill<W, CVX, H16, SW>(S, V.R, N, seq, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
-                __syncthreads();
-                PROF(2);
-                if constexpr (RM == 2) {  // wave 0 walks together (LDS window)
-                    if (t < 64 && res.bi >= 0) traceback_p16<false, W>(V.R, V.B, S, seq, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj, V.G.posnode, nullptr, nullptr, smem);
-                } else if (t == 0 && res.bi >= 0) traceback<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
+                if constexpr (RM == 2) {
+                    // The traceback derives the alignment from the band of cells the sweep kept around every
+                    // row's hint.  If the walk needs a cell outside (a structural variant moved the alignment
+                    // more than half a band away from the backbone coordinates), the hints of the rows not yet
+                    // walked are shifted onto the walk and this sequence's sweep is repeated.
+                    for (int att = 0;; ++att) {
+                        dp_fill_p16<W, CVX, SW>(S, V.R, N, seq, len, V.B, smem, res);
+                        __syncthreads();
+                        PROF(2);
+                        if (t == 0) lds[TBM_FLAG] = 0;
+                        __syncthreads();
+                        if (t < 64 && res.bi >= 0)
+                            traceback_p16<false, W, CVX>(V.R, V.B, S, seq, len, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj,
+                                                         V.G.posnode, nullptr, nullptr, smem);
+                        __syncthreads();
+                        PROF(3);
+                        if (!lds[TBM_FLAG]) break;
+                        if (att == 5) { status = ST_BAND_MISS; break; }
+                        const int mrow = lds[TBM_ROW], mdelta = lds[TBM_DELTA];
+                        __syncthreads();
+                        for (int r2 = t; r2 < mrow; r2 += T) V.R.meta[8 * (size_t)r2 + 7] += mdelta;
+                        for (int i2 = t; i2 < len; i2 += T) V.G.posnode[i2] = -1;
+                        if (t == 0) prof[27] += 1;
+                        __syncthreads();
+                    }
+                    if (status != ST_OK) break;
+                } else {
+                    dp_fill<W, CVX, H16, SW>(S, V.R, N, seq, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
+                    __syncthreads();
+                    PROF(2);
+                    if (t == 0 && res.bi >= 0) traceback<false>(V.R, V.B, T, W, S.sw, res.bi, res.bj, V.G.posnode, nullptr, nullptr);
+                    __syncthreads();
+                    PROF(3);
+                }
                 score = res.bi >= 0 ? res.best : 0;
-                __syncthreads();
-                PROF(3);
             }
             if (t == 0) { A.score[s] = score; A.cells[s] = (unsigned long long)N * (unsigned long long)len; }
             done_cells += (unsigned long long)N * (unsigned long long)len;
@@ -307,6 +339,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
                 V.R.pred_off[r] = (int)(A.pred_off[r0 + r] - e0);
                 V.R.row_node[r] = r;
                 V.R.slot[r] = r;
+                V.R.tbx[r] = 0;  // (packed sweep: the align-only arenas keep every strip, hints are not used)
                 V.R.flags[r] = A.row_sink[r0 + r] ? ROW_SINK : 0;
             }
             if (t == 0) V.R.pred_off[N] = (int)(A.pred_off[r0 + N] - e0);
@@ -322,16 +355,20 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
                         atomicMax(&V.R.slot[pr - 1], r);
                     }
                 }
-            status = finish_rows(ctx, N, V.R, caps);
+            status = finish_rows(ctx, N, V.R, caps, RM == 2);
             if (status == ST_OK) {
                 DpResult res;
                 if constexpr (RM == 2) dp_fill_p16<W, CVX, SW>(S, V.R, N, A.bases + so, len, V.B, smem, res);
                 else dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 if constexpr (RM == 2) {
-                    if (t < 64 && res.bi >= 0) npairs = traceback_p16<true, W>(V.R, V.B, S, A.bases + so, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj, nullptr, V.pair_row, V.pair_pos, smem);
+                    if (t == 0) lds[TBM_FLAG] = 0;
+                    __syncthreads();
+                    if (t < 64 && res.bi >= 0) npairs = traceback_p16<true, W, CVX>(V.R, V.B, S, A.bases + so, len, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj, nullptr, V.pair_row, V.pair_pos, smem);
+                    __syncthreads();
+                    if (lds[TBM_FLAG]) status = ST_BAND_MISS;  // (cannot happen: these arenas keep every strip)
                 } else if (t == 0 && res.bi >= 0) npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
-                if (t == 0 && res.bi >= 0) {
+                if (t == 0 && res.bi >= 0 && status == ST_OK) {
                     score = res.best;
                     const int64_t out0 = A.row_off[p] + A.seq_off[p];
                     for (int k = 0; k < npairs; ++k) {  // reverse into the output
@@ -506,6 +543,7 @@ struct DevBuf {
 
 struct BlockMeta {
     int maxlen = 0, nseq = 0, rm = 0; bool fits = false; Variant variant{16, 1, 256, 0};
+    int tier = 0;      // arena capacity tier the block runs at next (raised by ROWS/POOL/TBX overflow only)
     int64_t sumlen = 0;
     double cost = 0;
     bool cvx = false, sw = true;
@@ -701,7 +739,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
 }
 
 struct LaunchPlan {
-    Variant variant; bool cvx, sw;
+    Variant variant; bool cvx, sw; int tier = 0;
     std::vector<int32_t> work;  // block ids, largest cost first
     std::vector<unsigned long long> est;  // cost-model cells per work item (priority balancing)
     // filled by prepare_plan
@@ -731,12 +769,14 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
         rows_cap = (int)std::min<double>(nodes_cap, 2.5 * rows_est + 4096);
         pool_slots = std::min(rows_cap + 1, 4096);
         step_cap = 3 * rows_cap;
+    } else if (attempt == 2) {
+        rows_cap = nodes_cap; pool_slots = std::min(rows_cap + 1, 32768); step_cap = nodes_cap;  // edges <= nodes_cap
     } else {
-        rows_cap = nodes_cap; pool_slots = rows_cap + 1; step_cap = nodes_cap;  // edges <= nodes_cap
+        rows_cap = nodes_cap; pool_slots = rows_cap + 1; step_cap = nodes_cap;                    // worst case
     }
     if (rows_cap >= (1 << 20)) rows_cap = (1 << 20) - 1;
     const int wb = V.RM == 1 ? 8 : 4;
-    P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false, V.RM == 2);
+    P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false, V.RM == 2 ? p16_band_strips(V.T(), V.W) : 0);
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
@@ -899,15 +939,21 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
     }
     lap("setup");
     std::vector<LaunchPlan> all_plans;
-    for (int attempt = 0; attempt < 3 && !pending.empty(); ++attempt) {
-        // group by (variant, convex, h16): one launch per group, all groups concurrently
+    std::vector<int32_t> nomem_blocks;  // failed for lack of arena memory: their status is final
+    for (int b = 0; b < nb; ++b) h->meta[b].tier = 0;
+    // Rounds.  A block comes back for two independent reasons, each with its own ladder: its arena was too
+    // small (ROWS / POOL / TBX overflow: capacity tier 0..3, the last one is the worst case) or its sweep was
+    // too narrow (RANGE overflow / BAND miss: packed -> int16 row words -> int32 row words, at the SAME
+    // capacity tier).  3 + 2 steps at most, so 6 rounds always suffice; neither internal status is ever final.
+    for (int attempt = 0; attempt < 6 && !pending.empty(); ++attempt) {
+        // group by (variant, convex, local, capacity tier): one launch per group, all groups concurrently
         std::vector<LaunchPlan> plans;
         for (int b : pending) {
             const BlockMeta& m = h->meta[b];
             LaunchPlan* pl = nullptr;
             for (auto& q : plans)
-                if (q.variant.W == m.variant.W && q.variant.NW == m.variant.NW && q.variant.RM == m.variant.RM && q.cvx == m.cvx && q.sw == m.sw) { pl = &q; break; }
-            if (!pl) { plans.emplace_back(); pl = &plans.back(); pl->variant = m.variant; pl->cvx = m.cvx; pl->sw = m.sw; }
+                if (q.variant.W == m.variant.W && q.variant.NW == m.variant.NW && q.variant.RM == m.variant.RM && q.cvx == m.cvx && q.sw == m.sw && q.tier == m.tier) { pl = &q; break; }
+            if (!pl) { plans.emplace_back(); pl = &plans.back(); pl->variant = m.variant; pl->cvx = m.cvx; pl->sw = m.sw; pl->tier = m.tier; }
             pl->work.push_back(b);
         }
         std::sort(plans.begin(), plans.end(), [](const LaunchPlan& a, const LaunchPlan& b) { return a.variant.Lpad() > b.variant.Lpad(); });
@@ -918,7 +964,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         for (size_t i = 0; i < plans.size(); ++i)
             for (size_t j = i + 1; j < plans.size();) {
                 const LaunchPlan &a = plans[i], &b = plans[j];
-                if (a.variant.RM == b.variant.RM && a.cvx == b.cvx && a.sw == b.sw &&
+                if (a.variant.RM == b.variant.RM && a.cvx == b.cvx && a.sw == b.sw && a.tier == b.tier &&
                     (double)b.variant.Lpad() >= merge_ratio * (double)a.variant.Lpad()) {
                     plans[i].work.insert(plans[i].work.end(), b.work.begin(), b.work.end());
                     plans.erase(plans.begin() + (long)j);
@@ -928,8 +974,18 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         uint64_t want_bytes = 0;
         for (auto& pl : plans) {
             std::stable_sort(pl.work.begin(), pl.work.end(), [&](int a, int b) { return h->meta[a].cost > h->meta[b].cost; });
-            prepare_plan(h, pl, attempt);
+            prepare_plan(h, pl, pl.tier);
             want_bytes += (uint64_t)pl.want_slots * pl.lay.total;
+        }
+        // A geometry whose single arena does not fit the budget fails ITS blocks (per-block status, as the
+        // ABI promises) and the rest of the batch goes on.
+        for (size_t i = 0; i < plans.size();) {
+            if ((uint64_t)plans[i].lay.total > budget) {
+                for (int b : plans[i].work) status[b] = plans[i].tier >= 2 ? ST_POOL_OVERFLOW : ST_ROWS_OVERFLOW;
+                g_err = "memory budget too small for a block arena of " + std::to_string(plans[i].lay.total) + " bytes";
+                nomem_blocks.insert(nomem_blocks.end(), plans[i].work.begin(), plans[i].work.end());
+                plans.erase(plans.begin() + (long)i);
+            } else ++i;
         }
         // Slots per launch.  One geometry: as many as there are blocks / as fit.  Several geometries
         // running side by side should end together, so their WAVES are made proportional to their
@@ -972,12 +1028,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             HIPCHK(hipEventCreate(&r->e1));
             h->planres.push_back(r);
         }
-        for (size_t i = 0; i < plans.size(); ++i) {
-            LaunchPlan& pl = plans[i];
-            pl.n_slots = slots_at(i, lambda);
-            if ((uint64_t)pl.lay.total > budget)
-                return fail(SXG_E_NOMEM, "memory budget too small for a single block arena (" + std::to_string(pl.lay.total) + " bytes)");
-        }
+        for (size_t i = 0; i < plans.size(); ++i) plans[i].n_slots = slots_at(i, lambda);
         lap("plan");
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         for (size_t i = 0; i < plans.size(); ++i) {
@@ -997,27 +1048,39 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             if (dbg) debug_plan(h, plans[i], *h->planres[i], attempt);
         }
         lap("launches");
-        HIPCHK(hipMemcpy(status.data(), h->d_status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        {
+            std::vector<int32_t> dev(std::max(nb, 1));
+            HIPCHK(hipMemcpy(dev.data(), h->d_status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+            for (auto& pl : plans) for (int b : pl.work) status[b] = dev[b];   // only blocks that ran this round
+        }
         std::vector<int32_t> again;
         if (dbg) {
             int cnt[8] = {0};
             for (int b : pending) cnt[status[b] & 7]++;
-            fprintf(stderr, "[sxg] attempt %d: ok %d rows %d pool %d steps %d nodes %d long %d range %d\n", attempt, cnt[0], cnt[1], cnt[2], cnt[3],
-                    cnt[4], cnt[5], cnt[6]);
+            fprintf(stderr, "[sxg] round %d: ok %d rows %d pool %d steps %d nodes %d long %d range %d band %d\n", attempt, cnt[0], cnt[1], cnt[2], cnt[3],
+                    cnt[4], cnt[5], cnt[6], cnt[7]);
         }
         for (int b : pending) {
-            if (status[b] == ST_ROWS_OVERFLOW || status[b] == ST_POOL_OVERFLOW || status[b] == ST_TBX_OVERFLOW) again.push_back(b);
-            else if (status[b] == ST_RANGE_OVERFLOW) {  // one step wider: packed -> int16 row words -> int32 row words
-                BlockMeta& m = h->meta[b];
-                m.rm = row_mode(m.S, m.maxlen, m.maxlen, m.rm == 2 ? 0 : 1);
-                m.fits = variant_for_len(m.maxlen, m.rm, &m.variant);
-                if (m.fits) again.push_back(b);  // (the wider sweeps cover every length the packed one does)
+            BlockMeta& m = h->meta[b];
+            if (std::find(nomem_blocks.begin(), nomem_blocks.end(), b) != nomem_blocks.end()) continue;
+            if (status[b] == ST_ROWS_OVERFLOW || status[b] == ST_POOL_OVERFLOW || status[b] == ST_TBX_OVERFLOW) {
+                if (m.tier < 3) { m.tier += 1; again.push_back(b); }
+            } else if (status[b] == ST_RANGE_OVERFLOW || status[b] == ST_BAND_MISS) {
+                // one step wider at the same capacity tier: packed -> int16 row words -> int32 row words
+                if (m.rm != 1) {
+                    m.rm = row_mode(m.S, m.maxlen, m.maxlen, m.rm == 2 ? 0 : 1);
+                    m.fits = variant_for_len(m.maxlen, m.rm, &m.variant);
+                    if (m.fits) again.push_back(b);  // (the wider sweeps cover every length the packed one does)
+                    else status[b] = ST_TOO_LONG;
+                } else status[b] = ST_TOO_LONG;      // (unreachable: the int32 sweep reports neither)
             }
         }
-        if (attempt < 2) h->stats.retries += (int)again.size();
+        h->stats.retries += (int)again.size();
         pending.swap(again);
         for (auto& pl : plans) all_plans.push_back(std::move(pl));
     }
+    for (int b : pending) status[b] = ST_POOL_OVERFLOW;  // (unreachable: the ladders are shorter than the round limit)
+    if (nb) HIPCHK(hipMemcpy(h->d_status.p, status.data(), 4 * (size_t)nb, hipMemcpyHostToDevice));
     lap("status");
     // accounting
     std::vector<unsigned long long> cells((size_t)std::max<int64_t>(h->n_seqs, 1));
@@ -1308,7 +1371,7 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         // r_preds is sized by nodes_cap in make_layout: give it the edge count
         const int wb = V.RM == 1 ? 8 : 4;
         const SlotLayout lay2 = make_layout((int)std::max<int64_t>(maxe + 8, rows_cap + 8), rows_cap, rows_cap + 1,
-                                            (int)maxe + 8, V.T(), V.Lpad(), wb, true, V.RM == 2);
+                                            (int)maxe + 8, V.T(), V.Lpad(), wb, true, V.RM == 2 ? 2 * V.T() : 0);  // every strip kept
         auto kern = align_kernel(pl.variant, pl.cvx, pl.sw);
         int per_cu = 1;
         int smem = V.RM == 2 ? dp16_lds_bytes(V.T(), V.W) : dp_lds_launch_bytes(V.Lpad(), wb);
