@@ -62,10 +62,19 @@ __device__ __forceinline__ void p16_unpack_row(u32x2 w, int& h, int& of, int& oo
     oo = pk_sub(h, (int)((w.y >> 8) & 0x00ff00ffu));
 }
 
+// Buffer addressing for the sweep's rows: address = descriptor base (one row of the ring / of the plane,
+// built per row with a few SALU instructions) + SGPR offset (column k of the strip) + ONE loop-invariant VGPR
+// offset (the lane).  With global_load/store the compiler formed 64-bit VGPR addresses per access
+// (v_lshl_add_u64) and kept the per-column offsets in SGPR pairs, which it then spilled to VGPR lanes
+// (v_readlane per use): ~25 % of the row's VALU instructions were address bookkeeping.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t p16_rsrc(const void* base, const int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
 // ---- the traceback plane of the packed sweep: a band of strips per row -------------------------
 // Strip s = columns [s*W, (s+1)*W) (s < T: lo strips, s >= T: hi strips).  Row r keeps the BS strips
-// starting at band_first_strip(hint of r); cell (r, column j) is the dword
-//     plane[(r * W + j % W) * BS + (j / W - first strip)]  =  H int16 | (H - oF) << 16 | (H - oO) << 24.
+// starting at band_first_strip(hint of r), strip s in slot s mod BS; cell (r, column j) is the dword
+//     plane[(r * W + j % W) * BS + (j / W) % BS]  =  H int16 | (H - oF) << 16 | (H - oO) << 24.
 __host__ __device__ constexpr int p16_band_strips(int T, int W) {
     return (1100 + W - 1) / W < 2 * T ? (1100 + W - 1) / W : 2 * T;
 }
@@ -74,10 +83,18 @@ __device__ __forceinline__ int band_first_strip(const int hint_col, const int W,
     return min(max(c, 0), 2 * T - BS);
 }
 
+#ifndef SXG_P16_INLINE
+#define SXG_P16_INLINE __noinline__
+#endif
+// (out of line, views by value: inlined into the persistent kernel the sweep shared ~100 SGPRs with the
+// kernel's own state and reloaded its loop-invariant scalars from VGPR lanes -- v_readlane + hazard nops --
+// all over the row loop)
 template <int W, bool CVX, bool SW>
-__device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R, const int N,
-                                            const uint8_t* __restrict__ seq, const int L, const DpBuffers& B,
-                                            char* smem, DpResult& res) {
+__device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R, const int N_,
+                                             const uint8_t* seq, const int L_, const DpBuffers B,
+                                             char* smem) {
+    DpResult res;
+    const int N = __builtin_amdgcn_readfirstlane(N_), L = __builtin_amdgcn_readfirstlane(L_);
     static_assert(W >= 4 && W <= 15, "strip width");
     const int T = (int)blockDim.x;
     const int NW = T >> 6;
@@ -127,7 +144,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     // [row][column-in-strip][strip of the band]: a load/store instruction then covers consecutive words of
     // a wave instead of 64 different cache lines.  Every access is "uniform pointer"[lane offset]: scalar
     // base, one loop-invariant lane offset register, no per-access address arithmetic.
-    const unsigned ut = (unsigned)t;
+    const unsigned ut8 = (unsigned)t * 8u;   // my byte offset inside a [column][lane] row of 8-byte words
     SXG_GLOBAL u32x2* const g_row0 = sxg_uniform(sxg_global((u32x2*)B.row0));
     SXG_GLOBAL u32x2* const g_pool = sxg_uniform(sxg_global((u32x2*)B.pool));
     SXG_GLOBAL uint32_t* const g_tb = sxg_uniform(sxg_global((uint32_t*)B.tb));
@@ -163,16 +180,35 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
     }
     {
 #pragma unroll
-        for (int k = 0; k < W; ++k) (g_row0 + k * T)[ut] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
+        for (int k = 0; k < W; ++k)
+            __builtin_amdgcn_raw_buffer_store_b64(p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]), p16_rsrc((const void*)g_row0, TW * 8), ut8, k * T * 8, 0);
     }
     int best_lo = SW ? 0 : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;
     const int kL_lo = L - j0, kL_hi = L - TW - j0;  // strip-local index of the end column L
 
     bool next_sib = false;      // decided at the end of a row for its successor
+    // (A register/LDS prefetch of the next row's stored predecessor, requested after pass 2 and collected before
+    // this row's stores, was measured again in round 2 with the spills gone: 2.81 s against 2.68 s.  At this VALU
+    // occupancy the co-resident workgroups already hide the round trip; its ~60 extra instructions do not pay.)
+    typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+#define P16_LROW(ptr_)                                                                                      \
+    int tp_ = t;                                                                                            \
+    asm volatile("" : "+v"(tp_));   /* raw LDS offset rebuilt from an opaque t: no loop-invariant address register */ \
+    lds_u32x2* const ptr_ = (lds_u32x2*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() +            \
+                                                 (unsigned)(LDS_CTL_BYTES + MB) + (unsigned)(tp_ * W) * 8u)
     // (B lives in the kernel's private memory: testing B.prio_board per row was a scratch load plus an
     // in-order vmcnt(0) -- a wait for every store of the previous row -- at the top of EVERY row)
     const bool has_board = __builtin_amdgcn_readfirstlane((int)(B.prio_board != nullptr)) != 0;
+    // slots of my two strips in a plane row (strip s -> slot s mod BS: the address of a cell does not depend
+    // on where the row's band starts, so the traceback fetches cells and row descriptors in ONE round trip)
+    const unsigned soff = (unsigned)(t % BS) | ((unsigned)((T + t) % BS) << 16);
     const int prio_rank = __builtin_amdgcn_readfirstlane(B.prio_rank);
+#ifdef SXG_ROW_PROF
+// profiling builds: wait for the fetched row right away and book the time as segment 6 ("stored row fetch")
+#define P16_PROF_FETCH() do { RP_MARK(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RP_MARK(6); } while (0)
+#else
+#define P16_PROF_FETCH() do { } while (0)
+#endif
 #ifdef SXG_ROW_PROF
     unsigned long long racc[8] = {0};  // per row segment; scalar registers (s_memtime deltas)
 #define RP_MARK(seg) do { const unsigned long long tn_ = __builtin_readcyclecounter(); racc[seg] += tn_ - rt_; rt_ = tn_; } while (0)
@@ -213,17 +249,18 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         const bool sib = next_sib;
 // the column left of my strips in a stored row: lane t-1's last column; lane 0: lo = none,
 // hi = last column of the lo half (lane T-1)
-#define P16_LOAD_LEFT(sp_base, hl)                                                    \
-    do {                                                                              \
-        if (t > 0) hl = (int)((sp_base) + (W - 1) * T - 1)[ut].x;                     \
-        else hl = pk2(NEGP, pk_lo((int)(sp_base)[TW - 1].x));                         \
+#define P16_LOAD_LEFT(rs_, hl)                                                                              \
+    do {                                                                                                    \
+        if (t > 0) hl = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_, ut8, (W - 1) * T * 8 - 8, 0);         \
+        else hl = pk2(NEGP, pk_lo((int)__builtin_amdgcn_raw_buffer_load_b32(rs_, 0, (TW - 1) * 8, 0)));      \
     } while (0)
 // words of the stored row of predecessor p_ (slot sl_) and the column to their left
 #define P16_FETCH(p_, sl_, wr_, hl_)                                                                        \
     do {                                                                                                    \
-        SXG_GLOBAL const u32x2* base_ = sxg_uniform(((p_) == 0) ? (SXG_GLOBAL const u32x2*)g_row0 : g_pool + (size_t)(sl_) * TW); \
-        _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = (base_ + k * T)[ut];                         \
-        P16_LOAD_LEFT(base_, hl_);                                                                          \
+        const __amdgpu_buffer_rsrc_t rs_ = p16_rsrc(((p_) == 0) ? (const void*)g_row0 : (const void*)(g_pool + (size_t)(sl_) * TW), TW * 8); \
+        _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = __builtin_amdgcn_raw_buffer_load_b64(rs_, ut8, k * T * 8, 0); \
+        P16_PROF_FETCH();                                                                                   \
+        P16_LOAD_LEFT(rs_, hl_);                                                                            \
     } while (0)
 
         if (np <= 1 && p0 == i - 1) {
@@ -242,13 +279,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             // re-derived by the traceback), so the fold order is free: the register row first.
             const bool reg0 = (p0 == i - 1), reg1 = (np == 2 && p1 == i - 1);
             const bool park = np >= 3;
-            // my slice of the parked row, as a raw LDS offset rebuilt from an opaque t (one loop-invariant
-            // address register less to spill around this path)
-            typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
-            int tp_ = t;
-            asm volatile("" : "+v"(tp_));
-            lds_u32x2* const lrow_t = (lds_u32x2*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() +
-                                                           (unsigned)(LDS_CTL_BYTES + MB) + (unsigned)(tp_ * W) * 8u);
+            P16_LROW(lrow_t);   // my slice of the parked / prefetched row
             if (park) {
 #pragma unroll
                 for (int k = 0; k < W; ++k) lrow_t[k] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
@@ -272,33 +303,38 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
                     SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));
                 }
             }
-            for (int x = 1; x < np; ++x) {
-                int p, sl;
-                if (x == 1) { p = reg1 ? p0 : p1; sl = reg1 ? s0 : s1; }
-                else {
-                    p = __builtin_amdgcn_readfirstlane(g_preds[pb + x]);
-                    sl = (p >= 1 && p != i - 1) ? __builtin_amdgcn_readfirstlane(g_slot[p - 1]) : -1;
-                }
-                u32x2 wr[W];
-                int hl = Hleft;
-                if (p == i - 1) {
-#pragma unroll
-                    for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];
-                } else P16_FETCH(p, sl, wr, hl);
-#pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    int hs, fs, os;
-                    p16_unpack_row(wr[k], hs, fs, os);
-                    Fp[k] = pk_max(Fp[k], fs);
-                    if (CVX) Op[k] = pk_max(Op[k], os);
-                    Hc[k] = pk_max(Hc[k], hl);
-                    hl = hs;
-                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));
-                }
+// fold one more predecessor row (p_, slot sl_) into the running maxima
+#define P16_FOLD(p_, sl_)                                                                                   \
+    do {                                                                                                    \
+        u32x2 wr[W];                                                                                        \
+        int hl = Hleft;                                                                                     \
+        if ((p_) == i - 1) {                                                                                \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];                                \
+        } else P16_FETCH(p_, sl_, wr, hl);                                                                  \
+        _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                     \
+            int hs, fs, os;                                                                                 \
+            p16_unpack_row(wr[k], hs, fs, os);                                                              \
+            Fp[k] = pk_max(Fp[k], fs);                                                                      \
+            if (CVX) Op[k] = pk_max(Op[k], os);                                                             \
+            Hc[k] = pk_max(Hc[k], hl);                                                                      \
+            hl = hs;                                                                                        \
+            SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));                                       \
+        }                                                                                                   \
+    } while (0)
+            // (the second predecessor in straight-line code: two-predecessor rows -- the closing node of every
+            // bubble -- are a third of all rows; the loop form made the allocator spill around them)
+            if (np >= 2) {
+                const int p = reg1 ? p0 : p1, sl = reg1 ? s0 : s1;
+                P16_FOLD(p, sl);
             }
+            for (int x = 2; x < np; ++x) {
+                const int p = __builtin_amdgcn_readfirstlane(g_preds[pb + x]);
+                const int sl = (p >= 1 && p != i - 1) ? __builtin_amdgcn_readfirstlane(g_slot[p - 1]) : -1;
+                P16_FOLD(p, sl);
+            }
+#undef P16_FOLD
         }
 #undef P16_FETCH
-#undef P16_LOAD_LEFT
         if (!CVX) {
 #pragma unroll
             for (int k = 0; k < W; ++k) Op[k] = NEG2;
@@ -424,31 +460,55 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
             next_sib = nnp <= 1 && np0 == p0 && np0 != i;
         }
         // band of this row: strips [bs0, bs0 + BS); my wave covers lo strips [64 wv, 64 wv + 64) and the
-        // hi strips T further on.  (wave-uniform tests; the lane test is an exec mask around the stores)
+        // hi strips T further on.  (wave-uniform tests; the lane test is ONE exec mask around all W stores)
         const int bs0 = band_first_strip(hint, W, BS, T);
         const int w0 = wv << 6;
         const bool band_lo = (w0 + 63 >= bs0) && (w0 < bs0 + BS);
         const bool band_hi = (T + w0 + 63 >= bs0) && (T + w0 < bs0 + BS);
         const bool ring = (flags & ROW_STORE) != 0;
-        SXG_GLOBAL u32x2* const rdst = g_pool + (size_t)myslot * TW;
-        SXG_GLOBAL uint32_t* const pdst = g_tb + (size_t)i * (size_t)(W * BS);
-        const int sb_lo = tt - bs0, sb_hi = T + tt - bs0;
-        const bool in_lo = (unsigned)sb_lo < (unsigned)BS, in_hi = (unsigned)sb_hi < (unsigned)BS;
-        if (ring || band_lo || band_hi || !next_sib) {
+        const __amdgpu_buffer_rsrc_t rs_ring = p16_rsrc((const void*)(g_pool + (size_t)(ring ? myslot : 0) * TW), TW * 8);
+        const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
+        const bool in_lo = (unsigned)(tt - bs0) < (unsigned)BS, in_hi = (unsigned)(T + tt - bs0) < (unsigned)BS;
+        const unsigned so_lo = (soff & 0xffffu) << 2, so_hi = (soff >> 16) << 2;   // strip s lives in slot s mod BS of its row (byte offsets)
+// ring row + band cells of this row; CF(k) / CO(k) = the row's outgoing candidates of column k
+#define P16_STORES(CF, CO)                                                                                  \
+    do {                                                                                                    \
+        if (ring) {                                                                                         \
+            _Pragma("unroll") for (int k = 0; k < W; ++k)                                                   \
+                __builtin_amdgcn_raw_buffer_store_b64(p16_pack_row<CVX>(Hc[k], CF, CO), rs_ring, ut8, k * T * 8, 0); \
+        }                                                                                                   \
+        if (band_lo) {                                                                                      \
+            if (in_lo) {                                                                                    \
+                _Pragma("unroll") for (int k = 0; k < W; ++k) {                                             \
+                    const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                       \
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), rs_plane, so_lo, k * BS * 4, 0); \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+        if (band_hi) {                                                                                      \
+            if (in_hi) {                                                                                    \
+                _Pragma("unroll") for (int k = 0; k < W; ++k) {                                             \
+                    const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                       \
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), rs_plane, so_hi, k * BS * 4, 0); \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+        if (!next_sib) {
 #pragma unroll
             for (int k = 0; k < W; ++k) {
-                const int tf = pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2));
-                const int to = CVX ? pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2)) : NEG2;
-                if (ring || band_lo || band_hi) {
-                    const u32x2 w = p16_pack_row<CVX>(Hc[k], tf, to);
-                    if (ring) (rdst + k * T)[ut] = w;
-                    if (band_lo && in_lo) (pdst + k * BS)[sb_lo] = __builtin_amdgcn_perm(w.y, w.x, 0x05040100u);
-                    if (band_hi && in_hi) (pdst + k * BS)[sb_hi] = __builtin_amdgcn_perm(w.y, w.x, 0x07060302u);
-                }
-                if (!next_sib) { Fp[k] = tf; Op[k] = to; }
+                Fp[k] = pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2));
+                if (CVX) Op[k] = pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2));
                 SXG_PIN("+v"(Fp[k]), "+v"(Op[k]));
             }
+            P16_STORES(Fp[k], Op[k]);
+        } else if (ring || band_lo || band_hi) {
+            // (a sibling follows: Fp/Op stay this row's own F/O, the outgoing candidates are temporaries)
+            P16_STORES(pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2)), (CVX ? pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2)) : NEG2));
         }
+#undef P16_STORES
+#undef P16_LOAD_LEFT
+#undef P16_LROW
 #pragma unroll
         for (int k = 0; k < W; ++k) Hp[k] = Hc[k];
         Hleft = lh;
@@ -489,6 +549,7 @@ __device__ __forceinline__ void dp_fill_p16(const Scoring& S, const RowsView& R,
         res.bi = (int)(0xFFFFFu - (unsigned)((key >> 15) & 0xFFFFFu));
         res.bj = (int)(0x7FFFu - (unsigned)(key & 0x7FFFu));
     }
+    return res;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -568,7 +629,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             if (!miss) { miss = true; miss_row = p; miss_delta = col - hint; }
             return 0u;
         }
-        return TBU(g_plane[((size_t)p * W + k) * BS + sb]);
+        return TBU(g_plane[((size_t)p * W + k) * BS + s % BS]);
     };
     auto wcol0 = [&](int l) -> int { return wj - ((l * slope) >> 8) - (TBW_COLS - 3); };  // first column the window holds of row wtop-l
     auto cell = [&](int p, int col) -> uint32_t {
@@ -612,18 +673,20 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                     SXG_GLOBAL const i32x4* dm = (SXG_GLOBAL const i32x4*)(g_meta + 8 * (size_t)(row - 1));
                     const i32x4 d0 = dm[0], d1 = dm[1];
                     const int node = g_row_node[row - 1];
-                    const int bs0 = band_first_strip(d1.w, W, BS, T);
                     const int c0 = wcol0(lane);
+                    // (a cell's address does not depend on the row's band start: cells and descriptor travel together)
                     uint32_t v[TBW_COLS], valid = 0;
 #pragma unroll
                     for (int x2 = 0; x2 < TBW_COLS; ++x2) {
+                        const int col = min(max(c0 + x2, 0), L);
+                        const int s = col / W, k = col - s * W;
+                        v[x2] = g_plane[((size_t)row * W + k) * BS + s % BS];
+                    }
+                    const int bs0 = band_first_strip(d1.w, W, BS, T);
+#pragma unroll
+                    for (int x2 = 0; x2 < TBW_COLS; ++x2) {
                         const int col = c0 + x2;
-                        const int s = col / W, k = col - s * W, sb = s - bs0;
-                        v[x2] = 0;
-                        if (col >= 0 && col <= L && (unsigned)sb < (unsigned)BS) {
-                            v[x2] = g_plane[((size_t)row * W + k) * BS + sb];
-                            valid |= 1u << x2;
-                        }
+                        if (col >= 0 && col <= L && (unsigned)(col / W - bs0) < (unsigned)BS) valid |= 1u << x2;
                     }
                     uint32_t* en = win + lane * TBW_STRIDE;
 #pragma unroll
@@ -705,7 +768,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                         const int s = col / W, k = col - s * W, sb = s - bs0;
                         const bool inb = (unsigned)sb < (unsigned)BS;
                         int hval = 0;
-                        if (act && inb) hval = sext(g_plane[((size_t)i * W + k) * BS + sb]);
+                        if (act && inb) hval = sext(g_plane[((size_t)i * W + k) * BS + s % BS]);
                         const unsigned long long meq = __ballot(act && inb && hval + go + (x - 1) * ge == hv);
                         const unsigned long long moob = __ballot(act && !inb);
                         const int feq = meq ? (int)__builtin_ctzll(meq) : 64, foob = moob ? (int)__builtin_ctzll(moob) : 64;

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     // more than half a band away from the backbone coordinates), the hints of the rows not yet
                     // walked are shifted onto the walk and this sequence's sweep is repeated.
                     for (int att = 0;; ++att) {
-                        dp_fill_p16<W, CVX, SW>(S, V.R, N, seq, len, V.B, smem, res);
+                        res = dp_fill_p16<W, CVX, SW>(S, V.R, N, seq, len, V.B, smem);
                         __syncthreads();
                         PROF(2);
                         if (t == 0) lds[TBM_FLAG] = 0;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
             status = finish_rows(ctx, N, V.R, caps, RM == 2);
             if (status == ST_OK) {
                 DpResult res;
-                if constexpr (RM == 2) dp_fill_p16<W, CVX, SW>(S, V.R, N, A.bases + so, len, V.B, smem, res);
+                if constexpr (RM == 2) res = dp_fill_p16<W, CVX, SW>(S, V.R, N, A.bases + so, len, V.B, smem);
                 else dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 if constexpr (RM == 2) {
@@ -888,7 +888,7 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
         }
         double rt = 1e-9;
         for (int k = 0; k < 8; ++k) rt += (double)ra[k];
-        static const char* seg[8] = {"setup", "pass1+scan", "wait B1", "combine+pass2", "wait B2", "hand-over+end cell", "mask stores", "outgoing+row store"};
+        static const char* seg[8] = {"setup", "pass1+scan", "wait B1", "combine+pass2", "wait B2", "hand-over+end cell", "stored row fetch", "outgoing+row store"};
         fprintf(stderr, "[sxg]   row profile:");
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", seg[k], 100.0 * (double)ra[k] / rt);
         fprintf(stderr, "\n");
