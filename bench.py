@@ -37,55 +37,136 @@ WORKLOADS = {
     "tiny": (64, 8, 400, (1, -4, -6, -2, -26, -1), "smoke: 64 blocks x 8 seqs x 400 bp"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU issue roof of the packed sweep: 256 CUs x 4 SIMDs, one VOP3/VOP3P wave instruction per 4.27 cycles per SIMD
+# (profiles/ubench/op_rate.hip, measured on the box), at the clock the kernel sustains (profiles/run_clocks.sh)
+VALU_SIMDS, VALU_ISSUE_CYCLES, VALU_CLOCK_GHZ = 1024, 4.27, 2.395
 
 
-def cpu_baseline(workload, mode, seconds_hint=20.0):
-    """Oracle ("port") timed on the host cores on a bounded sample of the same workload."""
+def physical_cores():
+    """Physical cores this process may run on (SMT siblings counted once)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except Exception:
+        allowed = set(range(os.cpu_count() or 1))
+    cores, cpu, phys, core = set(), None, 0, 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+                if cpu in allowed:
+                    cores.add((phys, core))
+    except Exception:
+        pass
+    return max(1, len(cores) if cores else len(allowed))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload, mode):
+    """The oracle ("port") timed on the host's physical cores on WHOLE blocks of the workload (all sequences of
+    every sampled block), one block per thread per round, per-thread workspaces, OpenMP schedule(dynamic,1) as
+    src/smooth.cpp:1931.  Quoted: the AVX2 int16 row sweep (oracle/poa_simd.c) -- the reference's spoa is an int16
+    SIMD row sweep too, so the scalar oracle would be a strawman.  Also reported: the scalar oracle's
+    single-thread and all-thread rates on a smaller sample (the contention check)."""
     from oracle import oracle_py as O
     from smoothxg_amd import synth
     nb, ns, ln, prm, _ = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    # memory guard: ~ (tb + ordinals + live rows) per thread
-    per_thread = 8.0 * ln * ln * 2.2 + 64e6
+    cores = physical_cores()
+    p = O.mkparams(*prm, mode=mode)
+    impl = O.IMPL_AVX2 if O.simd_available() else O.IMPL_SCALAR
+    # memory guard: the vectorised variant keeps H, oF, oO of every cell (6 B) of one alignment per thread
+    rows = ln * max(2.0, 1.0 + 0.0165 * ns) + 1024
+    per_thread = 6.0 * rows * (ln + 64) * 1.2 + 64e6
+    threads = cores
     try:
         with open("/proc/meminfo") as f:
             avail = [int(l.split()[1]) * 1024 for l in f if l.startswith("MemAvailable")][0]
-        cores = max(1, min(cores, int(avail * 0.5 / per_thread)))
+        threads = max(1, min(cores, int(avail * 0.5 / per_thread)))
     except Exception:
         pass
-    # sample: `cores` blocks of the workload (one per thread), each cut to its first k sequences;
-    # k is sized from a short calibration so the timed sample is ~seconds_hint of CPU work
+    # calibration: one whole block on one thread
+    cb, cso, cbo = synth.make_batch(1, ns, ln, first_block=10_000_000)
+    t0 = time.time()
+    _, c1, _, _ = O.blocks_run_omp(cb, cso, cbo, None, p, 1, impl=impl)
+    t_one = time.time() - t0
+    rate_one = c1 / max(t_one, 1e-6)
+    rounds = int(max(1, min(8, 15.0 / max(t_one * 1.5, 1e-3))))   # ~15 s of wall time if threads scale
+    n_blk = threads * rounds
+    bases, seq_off, blk_off = synth.make_batch(n_blk, ns, ln, first_block=10_000_001)
+    t0 = time.time()
+    _, cells, _, _ = O.blocks_run_omp(bases, seq_off, blk_off, None, p, threads, impl=impl)
+    dt = time.time() - t0
+    # scalar oracle: single-thread and all-thread rate on blocks cut to their first 8 sequences
     def cut(bases, seq_off, blk_off, k):
         keep, so, bo = [], [0], [0]
         for b in range(len(blk_off) - 1):
-            for s in range(blk_off[b], blk_off[b] + k):
+            for s in range(blk_off[b], min(blk_off[b] + k, blk_off[b + 1])):
                 keep.append(bases[seq_off[s]:seq_off[s + 1]])
                 so.append(so[-1] + int(seq_off[s + 1] - seq_off[s]))
             bo.append(len(so) - 1)
         return np.concatenate(keep), np.asarray(so, np.int64), np.asarray(bo, np.int32)
-    bases, seq_off, blk_off = synth.make_batch(cores, ns, ln, first_block=10_000_000)
-    p = O.mkparams(*prm, mode=mode)
-    kc = min(4, ns)
-    cb, cso, cbo = cut(bases, seq_off, blk_off, kc)
+    k = min(8, ns)
+    sb, sso, sbo = cut(bases, seq_off, blk_off[:threads + 1], k)
     t0 = time.time()
-    _, ccells, _, _ = O.blocks_run_omp(cb, cso, cbo, None, p, cores)
-    rate = ccells / max(time.time() - t0, 1e-3)            # cells/s of the whole machine
-    k = kc
-    while k < ns and 0.55 * cores * ln * ln * (2 * k) * (2 * k) * (1 + 0.006 * 2 * k) / rate < seconds_hint:
-        k *= 2
-    k = min(k, ns)
-    sb, so, bo = cut(bases, seq_off, blk_off, k)
+    _, sc1, _, _ = O.blocks_run_omp(*cut(cb, cso, cbo, k), None, p, 1, impl=O.IMPL_SCALAR)
+    s_one = sc1 / max(time.time() - t0, 1e-6)
     t0 = time.time()
-    _, cells, _, _ = O.blocks_run_omp(sb, so, bo, None, p, cores)
-    dt = time.time() - t0
-    return {"cells_per_s": cells / dt, "cores": cores, "seconds": dt,
-            "sample": "%d blocks of the workload (one per thread), first %d of %d sequences each, "
-                      "oracle/poa_oracle.c scalar C, OpenMP schedule(dynamic,1); %.1f s, %.3g cells"
-                      % (cores, k, ns, dt, cells)}
+    _, sca, _, _ = O.blocks_run_omp(sb, sso, sbo, None, p, threads, impl=O.IMPL_SCALAR)
+    s_all = sca / max(time.time() - t0, 1e-6)
+    name = "AVX2 int16 row sweep (oracle/poa_simd.c)" if impl == O.IMPL_AVX2 else "scalar oracle (no AVX2 on this host)"
+    return {"cells_per_s": cells / dt, "cores": threads, "seconds": dt,
+            "per_thread_cells_per_s": cells / dt / threads, "single_thread_cells_per_s": rate_one,
+            "scalar_single_thread_cells_per_s": s_one, "scalar_all_threads_cells_per_s": s_all,
+            "cpu": cpu_model(), "physical_cores": cores, "implementation": name,
+            "sample": "%d WHOLE blocks of the workload (%d sequences each, %d threads = physical cores x %d rounds), %s, "
+                      "per-thread workspaces, OpenMP schedule(dynamic,1); %.1f s, %.3g cells; single thread %.3g cells/s, "
+                      "per thread under load %.3g cells/s; scalar oracle %.3g cells/s single / %.3g cells/s on %d threads"
+                      % (n_blk, ns, threads, rounds, name, dt, cells, rate_one, cells / dt / threads, s_one, s_all, threads)}
+
+
+def source_hash():
+    """SHA-256 of the kernel sources: profiles/<round>/counters.json records the hash of the build it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "smoothxg_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "sxg_poa.h"), "rb").read())
+    return h.hexdigest()
+
+
+def profile_counters(key):
+    """Hardware-counter figures of the dominant kernel (per launch) from the newest profiles/rNN/counters.json, and
+    whether they were measured on the sources this run was built from."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "counters.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if key in j.get("workloads", {}):
+            best = (f, j)
+    if not best:
+        return None
+    f, j = best
+    w = dict(j["workloads"][key])
+    w["file"] = os.path.relpath(f, ROOT)
+    w["matches_build"] = j.get("source_sha256") == source_hash()
+    return w
 
 
 def main():
@@ -171,15 +252,28 @@ def main():
     if rank == 0:
         blocks_total = nb * world * a.steps
         value = blocks_total / dt
-        ach = (algo_bytes / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("%s_%s" % (a.workload, a.mode), {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        k_s = kernel_ms / 1e3
+        algo_gbs = (algo_bytes / 1e9) / k_s if k_s > 0 else 0.0
+        pc = profile_counters("%s_%s" % (a.workload, a.mode))
+        launch_cells = cells / max(launches, 1)
+        valu_peak = VALU_SIMDS * VALU_CLOCK_GHZ * 1e9 / VALU_ISSUE_CYCLES          # wave instructions / s
+        traffic = valu_frac = valu_rate = None
+        hbm = {"model": "SURVEY 8(d): 2*n_cross*sizeof(score)+1 bytes per cell", "algo_bytes_per_cell": algo_bytes / max(cells, 1),
+               "algo_GBps": algo_gbs, "algo_frac_of_peak": algo_gbs / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS}
+        valu = {"simds": VALU_SIMDS, "issue_interval_cycles": VALU_ISSUE_CYCLES, "clock_GHz": VALU_CLOCK_GHZ,
+                "peak_wave_insts_per_s": valu_peak}
+        if pc:
+            # per-cell figures from the counter passes (one launch of the same workload), scaled to THIS run's cells
+            ipc = pc["SQ_INSTS_VALU"] / pc["cells_per_launch"]
+            bpc = pc["hbm_bytes_per_launch"] / pc["cells_per_launch"]
+            valu_rate = ipc * cells / k_s
+            valu_frac = valu_rate / valu_peak
+            traffic = bpc * launch_cells if pc["matches_build"] else None
+            valu.update({"wave_insts_per_cell": ipc, "wave_insts_per_launch": ipc * launch_cells, "counter_file": pc["file"],
+                         "counters_match_build": pc["matches_build"]})
+            hbm.update({"counter_bytes_per_cell": bpc, "counter_GBps": bpc * cells / k_s / 1e9,
+                        "counter_frac_of_peak": bpc * cells / k_s / 1e9 / HBM_PEAK_GBS,
+                        "counter_correction": pc.get("correction")})
         out = {
             "metric": "POA blocks/sec (+ DP cells/sec) on 1000-block synthetic",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -188,14 +282,23 @@ def main():
             "config": {"workload": desc, "blocks_per_gpu": nb, "mode": a.mode,
                        "cells_per_step_per_gpu": cells / a.steps},
             "cells_per_sec": total_cells / dt,
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            # The binding roof of this kernel is VALU issue, not HBM: the sweep keeps adjacent-rank rows in
+            # registers and moves about half of SURVEY 8(d)'s 13 B/cell, so the 8(d) figure alone exceeds the HBM
+            # peak (hbm.algo_frac_of_peak > 1 is NOT an achieved fraction).  frac = VALU wave instructions per
+            # second / what 1024 SIMDs can issue; hbm.counter_* is what FETCH_SIZE/WRITE_SIZE measured.
+            "roofline": {"bound": "valu" if valu_frac is not None else "hbm",
+                         "achieved": (valu_rate / 1e9) if valu_rate is not None else algo_gbs,
+                         "peak": (valu_peak / 1e9) if valu_rate is not None else HBM_PEAK_GBS,
+                         "unit": "G wave-instructions/s" if valu_rate is not None else "GB/s",
+                         "frac": valu_frac if valu_frac is not None else algo_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic,
                          "kernel": "poa_block_kernel<T=%d, cols/lane=%d, %s>" % (
                              st["dom_threads"], st["dom_cols_per_lane"],
                              "packed int16 sweep" if st["dom_row_mode"] == 2 else "32-bit sweep"),
                          "kernel_ms_per_launch": kernel_ms / max(launches, 1),
                          "algo_bytes_per_launch": algo_bytes / max(launches, 1),
-                         "bytes_per_cell": algo_bytes / max(cells, 1)},
+                         "bytes_per_cell": algo_bytes / max(cells, 1),
+                         "valu": valu, "hbm": hbm},
             "engine": {"slots": st["n_slots"], "retries": st["retries"], "arena_bytes": st["device_bytes"]},
         }
         if world == 1 and not a.no_cpu_baseline and a.workload != "c4":  # (no fixed shape to sample for c4)
@@ -203,7 +306,13 @@ def main():
             cells_per_block = cells / a.steps / nb
             out["cpu_baseline"] = {"value": cb["cells_per_s"] / cells_per_block, "unit": "blocks/s",
                                    "cores": cb["cores"], "kind": "port", "sample": cb["sample"],
-                                   "cells_per_sec": cb["cells_per_s"]}
+                                   "cells_per_sec": cb["cells_per_s"], "cpu": cb["cpu"],
+                                   "implementation": cb["implementation"],
+                                   "per_thread_cells_per_sec": cb["per_thread_cells_per_s"],
+                                   "single_thread_cells_per_sec": cb["single_thread_cells_per_s"],
+                                   "scalar_single_thread_cells_per_sec": cb["scalar_single_thread_cells_per_s"],
+                                   "scalar_all_threads_cells_per_sec": cb["scalar_all_threads_cells_per_s"],
+                                   "gpu_over_cpu": (total_cells / dt) / cb["cells_per_s"]}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

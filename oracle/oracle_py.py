@@ -19,7 +19,7 @@ class Params(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("poa_oracle.c", "poa_vtb.c", "poa_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("poa_oracle.c", "poa_vtb.c", "poa_simd.c", "poa_oracle.h", "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -56,6 +56,13 @@ def lib():
         L.poa_block_run.argtypes = [u8p, i32p, C.c_int, u32p, C.POINTER(Params), i32p, u64p]
         L.poa_blocks_run_omp.argtypes = [u8p, i64p, i32p, C.c_int, u32p, C.POINTER(Params), C.c_int,
                                          i32p, u64p, i32p, i32p]
+        L.poa_blocks_run_omp2.argtypes = [u8p, i64p, i32p, C.c_int, u32p, C.POINTER(Params), C.c_int, C.c_int,
+                                          i32p, u64p, i32p, i32p]
+        L.poa_ws_new.restype = vp
+        L.poa_ws_free.argtypes = [vp]
+        L.poa_ws_set_impl.argtypes = [vp, C.c_int]
+        L.poa_block_run_ws.restype = vp
+        L.poa_block_run_ws.argtypes = [vp, u8p, i32p, C.c_int, u32p, C.POINTER(Params), i32p, u64p]
         L.poa_xxh64.restype = C.c_uint64
         L.poa_xxh64.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
         L.poa_rescore.restype = C.c_int32
@@ -185,7 +192,14 @@ def align_csr(codes, off, pred, sink, seq, params, vtb=False):
     return an[:k].copy(), ap[:k].copy(), sc.value
 
 
-def block_run(seqs, weights, params):
+IMPL_SCALAR, IMPL_AVX2 = 0, 1
+
+
+def simd_available():
+    return bool(lib().poa_simd_available())
+
+
+def block_run(seqs, weights, params, impl=IMPL_SCALAR):
     """seqs: list of uint8 arrays.  Returns (Graph, scores, cells)."""
     bases = np.concatenate([np.asarray(s, np.uint8) for s in seqs]) if seqs else np.zeros(0, np.uint8)
     bases = np.ascontiguousarray(bases if len(bases) else np.zeros(1, np.uint8))
@@ -194,12 +208,15 @@ def block_run(seqs, weights, params):
     w = np.ascontiguousarray(weights if weights is not None else np.ones(len(seqs)), np.uint32)
     scores = np.zeros(max(len(seqs), 1), np.int32)
     cells = np.zeros(max(len(seqs), 1), np.uint64)
-    h = lib().poa_block_run(_p(bases, C.c_uint8), _p(off, C.c_int32), len(seqs), _p(w, C.c_uint32),
-                            C.byref(params), _p(scores, C.c_int32), _p(cells, C.c_uint64))
+    ws = lib().poa_ws_new()
+    lib().poa_ws_set_impl(ws, impl)
+    h = lib().poa_block_run_ws(ws, _p(bases, C.c_uint8), _p(off, C.c_int32), len(seqs), _p(w, C.c_uint32),
+                               C.byref(params), _p(scores, C.c_int32), _p(cells, C.c_uint64))
+    lib().poa_ws_free(ws)
     return Graph(h), scores[:len(seqs)], cells[:len(seqs)]
 
 
-def blocks_run_omp(bases, seq_off, blk_off, weights, params, n_threads):
+def blocks_run_omp(bases, seq_off, blk_off, weights, params, n_threads, impl=IMPL_SCALAR):
     """Flat batch (same layout as include/sxg_poa.h).  Returns (scores, cells_total, n_nodes, n_edges)."""
     bases = np.ascontiguousarray(bases, np.uint8)
     seq_off = np.ascontiguousarray(seq_off, np.int64)
@@ -211,9 +228,9 @@ def blocks_run_omp(bases, seq_off, blk_off, weights, params, n_threads):
     nn = np.zeros(max(nb, 1), np.int32)
     ne = np.zeros(max(nb, 1), np.int32)
     total = C.c_uint64(0)
-    lib().poa_blocks_run_omp(_p(bases, C.c_uint8), _p(seq_off, C.c_int64), _p(blk_off, C.c_int32), nb,
-                             _p(w, C.c_uint32), C.byref(params), n_threads, _p(scores, C.c_int32),
-                             C.byref(total), _p(nn, C.c_int32), _p(ne, C.c_int32))
+    lib().poa_blocks_run_omp2(_p(bases, C.c_uint8), _p(seq_off, C.c_int64), _p(blk_off, C.c_int32), nb,
+                              _p(w, C.c_uint32), C.byref(params), n_threads, impl, _p(scores, C.c_int32),
+                              C.byref(total), _p(nn, C.c_int32), _p(ne, C.c_int32))
     return scores[:ns], total.value, nn[:nb], ne[:nb]
 
 

@@ -169,39 +169,94 @@ static norm_params_t normalise(const poa_params_t *p) {
     return r;                                                        /* convex  */
 }
 
-static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int32_t *pred,
+/* Per-thread workspace: every buffer align_rows / poa_align need is grown on demand and kept, so a block
+ * (and every later block of the same OpenMP thread) allocates nothing per alignment.  The first baseline
+ * malloc'ed ~25 MB per alignment: 256 threads then spend their time in mmap/munmap and page faults
+ * (4.6 Mcells/s/thread against 70 single-threaded), which measured the allocator, not the DP.       */
+enum { WS_HM, WS_LAST, WS_FHEAD, WS_FNEXT, WS_SPARE, WS_TB, WS_MP, WS_TBX, WS_CODES, WS_SINK, WS_OFF, WS_PRED,
+       WS_ROWNODE, WS_NBUF };
+struct poa_ws {
+    void *buf[WS_NBUF];
+    size_t cap[WS_NBUF];
+    int32_t **rows;      /* every DP row buffer ever allocated (3 * row_cap ints each) */
+    int n_rows, cap_rows;
+    size_t row_cap;
+    int impl;            /* POA_IMPL_SCALAR | POA_IMPL_AVX2 */
+    poa_simd_ws_t *simd;
+};
+poa_ws_t *poa_ws_new(void) { return (poa_ws_t *)calloc(1, sizeof(poa_ws_t)); }
+void poa_ws_free(poa_ws_t *w) {
+    if (!w) return;
+    for (int k = 0; k < WS_NBUF; ++k) free(w->buf[k]);
+    for (int k = 0; k < w->n_rows; ++k) free(w->rows[k]);
+    free(w->rows);
+    poa_simd_ws_free(w->simd);
+    free(w);
+}
+void poa_ws_set_impl(poa_ws_t *w, int impl) { w->impl = impl; }
+static void *ws_get(poa_ws_t *w, int k, size_t bytes) {
+    if (bytes > w->cap[k]) {
+        free(w->buf[k]);
+        w->cap[k] = bytes + bytes / 4 + 64;
+        w->buf[k] = malloc(w->cap[k]);
+        if (!w->buf[k]) { fprintf(stderr, "poa_oracle: out of memory\n"); abort(); }
+    }
+    return w->buf[k];
+}
+
+static int32_t *ws_new_row(poa_ws_t *w) {
+    if (w->n_rows == w->cap_rows) {
+        w->cap_rows = w->cap_rows ? 2 * w->cap_rows : 1024;
+        w->rows = (int32_t **)xrealloc(w->rows, sizeof(int32_t *) * (size_t)w->cap_rows);
+    }
+    int32_t *r = (int32_t *)malloc(sizeof(int32_t) * w->row_cap);
+    if (!r) { fprintf(stderr, "poa_oracle: out of memory\n"); abort(); }
+    w->rows[w->n_rows++] = r;
+    return r;
+}
+
+static int align_rows(poa_ws_t *ws, int N, const uint8_t *codes, const int32_t *off, const int32_t *pred,
                       const uint8_t *sink, const int32_t *row_node, const uint8_t *seq, int L,
                       const poa_params_t *pp, int32_t *out_node, int32_t *out_pos,
                       int32_t *score) {
+    poa_ws_t *own_ws = NULL;
+    if (!ws) ws = own_ws = poa_ws_new();
     norm_params_t P = normalise(pp);
     if (score) *score = 0;
-    if (N <= 0 || L <= 0) return 0;
+    if (N <= 0 || L <= 0) { poa_ws_free(own_ws); return 0; }
     for (int i = 1; i <= N; ++i) if (off[i] - off[i - 1] > 65535) { fprintf(stderr, "poa_oracle: in-degree > 65535\n"); abort(); }
     const size_t W = (size_t)L + 1;
     /* rows of H,F,O kept until their last reader is done */
-    int32_t **Hm = (int32_t **)calloc((size_t)N + 1, sizeof(int32_t *));
-    int32_t *last_use = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    int32_t **Hm = (int32_t **)ws_get(ws, WS_HM, ((size_t)N + 1) * sizeof(int32_t *));
+    memset(Hm, 0, ((size_t)N + 1) * sizeof(int32_t *));
+    int32_t *last_use = (int32_t *)ws_get(ws, WS_LAST, sizeof(int32_t) * ((size_t)N + 1));
     for (int i = 0; i <= N; ++i) last_use[i] = i;
     for (int i = 1; i <= N; ++i)
         for (int k = off[i - 1]; k < off[i]; ++k)
             if (last_use[pred[k]] < i) last_use[pred[k]] = i;
     /* free lists keyed by last_use */
-    int32_t *free_head = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 2));
-    int32_t *free_next = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    int32_t *free_head = (int32_t *)ws_get(ws, WS_FHEAD, sizeof(int32_t) * ((size_t)N + 2));
+    int32_t *free_next = (int32_t *)ws_get(ws, WS_FNEXT, sizeof(int32_t) * ((size_t)N + 1));
     for (int i = 0; i <= N + 1; ++i) free_head[i] = -1;
     for (int i = 0; i <= N; ++i) { free_next[i] = free_head[last_use[i]]; free_head[last_use[i]] = i; }
 
-    /* freed row buffers are recycled (a malloc per row serialises 256 OpenMP threads in glibc) */
-    int32_t **spare = (int32_t **)malloc(sizeof(int32_t *) * ((size_t)N + 2));
+    /* row buffers: the workspace keeps every buffer it ever allocated; all of them are spare at the start */
+    if (3 * W > ws->row_cap) {
+        for (int k = 0; k < ws->n_rows; ++k) free(ws->rows[k]);
+        ws->n_rows = 0;
+        ws->row_cap = 3 * W + 3 * W / 4;
+    }
+    int32_t **spare = (int32_t **)ws_get(ws, WS_SPARE, sizeof(int32_t *) * ((size_t)N + 2 + (size_t)ws->n_rows));
     int n_spare = 0;
-#define ROW_ALLOC() (n_spare ? spare[--n_spare] : (int32_t *)malloc(sizeof(int32_t) * 3 * W))
+    for (int k = 0; k < ws->n_rows; ++k) spare[n_spare++] = ws->rows[k];
+#define ROW_ALLOC() (n_spare ? spare[--n_spare] : ws_new_row(ws))
 #define ROW_FREE(p) (spare[n_spare++] = (p))
-    uint8_t *tb = (uint8_t *)malloc(((size_t)N + 1) * W);
+    uint8_t *tb = (uint8_t *)ws_get(ws, WS_TB, ((size_t)N + 1) * W);
     /* ordinals of the winning pred for D,F,O on multi-pred rows */
-    int32_t *mp_index = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    int32_t *mp_index = (int32_t *)ws_get(ws, WS_MP, sizeof(int32_t) * ((size_t)N + 1));
     size_t n_mp = 0;
     for (int i = 1; i <= N; ++i) mp_index[i] = (off[i] - off[i - 1] > 1) ? (int32_t)n_mp++ : -1;
-    uint16_t *tbx = (uint16_t *)malloc(sizeof(uint16_t) * 3 * (n_mp ? n_mp : 1) * W); /* ordinals < 65536 */
+    uint16_t *tbx = (uint16_t *)ws_get(ws, WS_TBX, sizeof(uint16_t) * 3 * (n_mp ? n_mp : 1) * W); /* ordinals < 65536 */
 
     /* row 0 */
     Hm[0] = ROW_ALLOC();
@@ -264,12 +319,8 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
         /* release rows nobody will read again */
         for (int r = free_head[i]; r >= 0; r = free_next[r]) { ROW_FREE(Hm[r]); Hm[r] = NULL; }
     }
-    for (int i = 0; i <= N; ++i) free(Hm[i]);
-    while (n_spare) free(spare[--n_spare]);
-    free(spare);
 #undef ROW_ALLOC
 #undef ROW_FREE
-    free(Hm); free(last_use); free(free_head); free(free_next);
 
     int n = 0;
     if (best_i >= 0) {
@@ -309,7 +360,7 @@ static int align_rows(int N, const uint8_t *codes, const int32_t *off, const int
             x = out_pos[a]; out_pos[a] = out_pos[b]; out_pos[b] = x;
         }
     }
-    free(tb); free(tbx); free(mp_index);
+    poa_ws_free(own_ws);
     return n;
 }
 
@@ -319,7 +370,7 @@ int poa_align_csr(int N, const uint8_t *codes, const int32_t *off, const int32_t
                   int32_t *out_node, int32_t *out_pos, int32_t *score) {
     int32_t *row_node = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N ? N : 1));
     for (int i = 0; i < N; ++i) row_node[i] = i; /* report ranks */
-    int n = align_rows(N, codes, off, pred, sink, row_node, seq, L, p, out_node, out_pos, score);
+    int n = align_rows(NULL, N, codes, off, pred, sink, row_node, seq, L, p, out_node, out_pos, score);
     free(row_node);
     return n;
 }
@@ -338,20 +389,31 @@ void poa_graph_rows(const poa_graph_t *g, uint8_t *codes, int32_t *off, int32_t 
     }
 }
 
-int poa_align(const poa_graph_t *g, const uint8_t *seq, int len, const poa_params_t *p,
-              int32_t *out_node, int32_t *out_pos, int32_t *score, uint64_t *cells) {
+int poa_align_ws(poa_ws_t *ws, const poa_graph_t *g, const uint8_t *seq, int len, const poa_params_t *p,
+                 int32_t *out_node, int32_t *out_pos, int32_t *score, uint64_t *cells) {
     int N = g->n_nodes;
     if (cells) *cells = (uint64_t)N * (uint64_t)len;
     if (score) *score = 0;
     if (N == 0 || len == 0) return 0;
-    uint8_t *codes = (uint8_t *)malloc((size_t)N), *sink = (uint8_t *)malloc((size_t)N);
-    int32_t *off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
-    int32_t *pred = (int32_t *)malloc(sizeof(int32_t) * ((size_t)g->n_edges + 1));
-    int32_t *row_node = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+    poa_ws_t *own = NULL;
+    if (!ws) ws = own = poa_ws_new();
+    uint8_t *codes = (uint8_t *)ws_get(ws, WS_CODES, (size_t)N), *sink = (uint8_t *)ws_get(ws, WS_SINK, (size_t)N);
+    int32_t *off = (int32_t *)ws_get(ws, WS_OFF, sizeof(int32_t) * ((size_t)N + 1));
+    int32_t *pred = (int32_t *)ws_get(ws, WS_PRED, sizeof(int32_t) * ((size_t)g->n_edges + 1));
+    int32_t *row_node = (int32_t *)ws_get(ws, WS_ROWNODE, sizeof(int32_t) * (size_t)N);
     poa_graph_rows(g, codes, off, pred, sink, row_node);
-    int n = align_rows(N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score);
-    free(codes); free(sink); free(off); free(pred); free(row_node);
+    int n = -1;
+    if (ws->impl == POA_IMPL_AVX2) {   /* (-1: no AVX2 on this host, or the scores leave int16: scalar path) */
+        if (!ws->simd) ws->simd = poa_simd_ws_new();
+        n = poa_align_rows_simd(ws->simd, N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score);
+    }
+    if (n < 0) n = align_rows(ws, N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score);
+    poa_ws_free(own);
     return n;
+}
+int poa_align(const poa_graph_t *g, const uint8_t *seq, int len, const poa_params_t *p,
+              int32_t *out_node, int32_t *out_pos, int32_t *score, uint64_t *cells) {
+    return poa_align_ws(NULL, g, seq, len, p, out_node, out_pos, score, cells);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -550,9 +612,23 @@ int poa_msa(const poa_graph_t *g, int with_consensus, char *out) {
 poa_graph_t *poa_block_run(const uint8_t *bases, const int32_t *seq_off, int n_seqs,
                            const uint32_t *weights, const poa_params_t *p,
                            int32_t *scores, uint64_t *cells) {
+    return poa_block_run_ws(NULL, bases, seq_off, n_seqs, weights, p, scores, cells);
+}
+poa_graph_t *poa_block_run_ws(poa_ws_t *ws, const uint8_t *bases, const int32_t *seq_off, int n_seqs,
+                              const uint32_t *weights, const poa_params_t *p,
+                              int32_t *scores, uint64_t *cells) {
     poa_graph_t *g = poa_graph_new();
-    int64_t maxpairs = 16;
-    for (int s = 0; s < n_seqs; ++s) maxpairs += 2 * (int64_t)(seq_off[s + 1] - seq_off[s]);
+    int64_t maxpairs = 16, maxlen = 0;
+    for (int s = 0; s < n_seqs; ++s) {
+        maxpairs += 2 * (int64_t)(seq_off[s + 1] - seq_off[s]);
+        if (seq_off[s + 1] - seq_off[s] > maxlen) maxlen = seq_off[s + 1] - seq_off[s];
+    }
+    if (ws && ws->impl == POA_IMPL_AVX2 && poa_simd_available()) {
+        /* rows a block of similar sequences is expected to reach (same estimate as the GPU engine's arenas) */
+        const double grow_f = 1.0 + 0.0165 * n_seqs;
+        if (!ws->simd) ws->simd = poa_simd_ws_new();
+        poa_simd_ws_reserve(ws->simd, (long)(maxlen * (grow_f > 2.0 ? grow_f : 2.0)) + 1024, (long)maxlen);
+    }
     int32_t *an = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
     int32_t *ap = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
     for (int s = 0; s < n_seqs; ++s) {
@@ -560,7 +636,7 @@ poa_graph_t *poa_block_run(const uint8_t *bases, const int32_t *seq_off, int n_s
         const int len = seq_off[s + 1] - seq_off[s];
         int32_t sc = 0;
         uint64_t cl = 0;
-        int n = poa_align(g, seq, len, p, an, ap, &sc, &cl);
+        int n = poa_align_ws(ws, g, seq, len, p, an, ap, &sc, &cl);
         if (scores) scores[s] = sc;
         if (cells) cells[s] = cl;
         poa_add_alignment(g, an, ap, n, seq, len, weights ? weights[s] : 1);
@@ -573,23 +649,38 @@ int poa_blocks_run_omp(const uint8_t *bases, const int64_t *seq_off, const int32
                        int n_blocks, const uint32_t *weights, const poa_params_t *p,
                        int n_threads, int32_t *scores, uint64_t *cells_total,
                        int32_t *n_nodes_out, int32_t *n_edges_out) {
+    return poa_blocks_run_omp2(bases, seq_off, blk_off, n_blocks, weights, p, n_threads, POA_IMPL_SCALAR, scores,
+                               cells_total, n_nodes_out, n_edges_out);
+}
+int poa_blocks_run_omp2(const uint8_t *bases, const int64_t *seq_off, const int32_t *blk_off,
+                        int n_blocks, const uint32_t *weights, const poa_params_t *p,
+                        int n_threads, int impl, int32_t *scores, uint64_t *cells_total,
+                        int32_t *n_nodes_out, int32_t *n_edges_out) {
     uint64_t total = 0;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+#pragma omp parallel reduction(+ : total)
+#endif
+    {
+    poa_ws_t *ws = poa_ws_new();   /* one workspace per thread, reused by every block the thread takes */
+    poa_ws_set_impl(ws, impl);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
 #endif
     for (int b = 0; b < n_blocks; ++b) {
         const int s0 = blk_off[b], ns = blk_off[b + 1] - s0;
         int32_t *off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)ns + 1));
         for (int s = 0; s <= ns; ++s) off[s] = (int32_t)(seq_off[s0 + s] - seq_off[s0]);
         uint64_t *cl = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(ns ? ns : 1));
-        poa_graph_t *g = poa_block_run(bases + seq_off[s0], off, ns, weights ? weights + s0 : NULL, p,
-                                       scores ? scores + s0 : NULL, cl);
+        poa_graph_t *g = poa_block_run_ws(ws, bases + seq_off[s0], off, ns, weights ? weights + s0 : NULL, p,
+                                          scores ? scores + s0 : NULL, cl);
         for (int s = 0; s < ns; ++s) total += cl[s];
         if (n_nodes_out) n_nodes_out[b] = g->n_nodes;
         if (n_edges_out) n_edges_out[b] = g->n_edges;
         poa_graph_free(g);
         free(off); free(cl);
+    }
+    poa_ws_free(ws);
     }
     if (cells_total) *cells_total = total;
     return 0;

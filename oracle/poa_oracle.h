@@ -42,6 +42,25 @@ typedef struct {
 
 typedef struct poa_graph poa_graph_t;
 
+/* Implementations of Align (same results): the scalar recorded-choice DP of poa_oracle.c, or the AVX2
+ * int16 row sweep with value-derived traceback of poa_simd.c (falls back to scalar when the host has no
+ * AVX2 or the scores leave int16).  A workspace keeps every buffer an alignment needs; one per thread.  */
+#define POA_IMPL_SCALAR 0
+#define POA_IMPL_AVX2 1
+typedef struct poa_ws poa_ws_t;
+typedef struct poa_simd_ws poa_simd_ws_t;
+poa_ws_t *poa_ws_new(void);
+void poa_ws_free(poa_ws_t *w);
+void poa_ws_set_impl(poa_ws_t *w, int impl);
+poa_simd_ws_t *poa_simd_ws_new(void);
+void poa_simd_ws_free(poa_simd_ws_t *w);
+void poa_simd_ws_reserve(poa_simd_ws_t *w, long rows, long len);
+/* returns the number of pairs, or -1 when not applicable (caller uses the scalar path) */
+int poa_align_rows_simd(poa_simd_ws_t *w, int n_rows, const uint8_t *codes, const int32_t *off, const int32_t *pred,
+                        const uint8_t *sink, const int32_t *row_node, const uint8_t *seq, int len,
+                        const poa_params_t *p, int32_t *out_node, int32_t *out_pos, int32_t *score);
+int poa_simd_available(void);
+
 poa_graph_t *poa_graph_new(void);
 void poa_graph_free(poa_graph_t *g);
 int poa_graph_num_nodes(const poa_graph_t *g);
@@ -53,6 +72,9 @@ int poa_graph_num_seqs(const poa_graph_t *g);
  * Returns number of pairs; *score = optimal score; *cells = num_nodes * len.           */
 int poa_align(const poa_graph_t *g, const uint8_t *seq, int len, const poa_params_t *p,
               int32_t *out_node, int32_t *out_pos, int32_t *score, uint64_t *cells);
+
+int poa_align_ws(poa_ws_t *ws, const poa_graph_t *g, const uint8_t *seq, int len, const poa_params_t *p,
+                 int32_t *out_node, int32_t *out_pos, int32_t *score, uint64_t *cells);
 
 /* Same DP over a caller-supplied CSR in rank space (rows as poa_graph_rows() lays them
  * out); reported node ids are ranks.  Checks the HIP align-only entry point.            */
@@ -93,6 +115,9 @@ poa_graph_t *poa_block_run(const uint8_t *bases, const int32_t *seq_off, int n_s
                            const uint32_t *weights, const poa_params_t *p,
                            int32_t *scores, uint64_t *cells);
 
+poa_graph_t *poa_block_run_ws(poa_ws_t *ws, const uint8_t *bases, const int32_t *seq_off, int n_seqs,
+                              const uint32_t *weights, const poa_params_t *p, int32_t *scores, uint64_t *cells);
+
 /* Many blocks, OpenMP `parallel for schedule(dynamic,1)` as src/smooth.cpp:1931.
  * Only aggregate outputs (for the CPU baseline): total cells and per-block node/edge
  * counts + checksum of (scores).  Returns 0.                                            */
@@ -100,6 +125,12 @@ int poa_blocks_run_omp(const uint8_t *bases, const int64_t *seq_off, const int32
                        int n_blocks, const uint32_t *weights, const poa_params_t *p,
                        int n_threads, int32_t *scores, uint64_t *cells_total,
                        int32_t *n_nodes_out, int32_t *n_edges_out);
+
+/* ... with a chosen implementation (POA_IMPL_*) and one workspace per thread */
+int poa_blocks_run_omp2(const uint8_t *bases, const int64_t *seq_off, const int32_t *blk_off,
+                        int n_blocks, const uint32_t *weights, const poa_params_t *p,
+                        int n_threads, int impl, int32_t *scores, uint64_t *cells_total,
+                        int32_t *n_nodes_out, int32_t *n_edges_out);
 
 /* XXH64 (Cyan4973/xxHash, published algorithm), seed as given. */
 uint64_t poa_xxh64(const void *data, uint64_t len, uint64_t seed);

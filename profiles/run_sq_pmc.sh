@@ -3,8 +3,7 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
 CMD="python $R/bench.py --workload ns --steps 1 --warmup 0 --no-cpu-baseline"
 i=0
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
-         "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" \
-         "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INSTS_WAVE32_LDS SQ_IFETCH"; do
+         "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc16_$i -o pmc -- $CMD > $OUT/pmc16_$i.log 2>&1
 done

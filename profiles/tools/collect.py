@@ -1,5 +1,7 @@
 """Fold the outputs of profiles/run_pmc.sh and profiles/run_sq_pmc.sh (gpurun_out/) into the tracked
-evidence: profiles/<round>/ns_sw_* and profiles/traffic.json.  Usage: python profiles/tools/collect.py r01"""
+evidence: profiles/<round>/ns_sw_*, profiles/<round>/counters.json (what bench.py's roofline reads, keyed by the
+SHA-256 of the kernel sources it was measured on) and profiles/traffic.json.
+Usage: python profiles/tools/collect.py r02"""
 import csv
 import glob
 import json
@@ -47,6 +49,20 @@ if agg:
 b = os.path.join(OUT, "bench_ns_sw.json")
 if os.path.exists(b):
     d = json.loads(open(b).read().strip().splitlines()[-1])
+    sys.path.insert(0, ROOT)
+    import bench
+    counters = {"source_sha256": bench.source_hash(),
+                "collected_with": "profiles/run_pmc.sh + profiles/run_sq_pmc.sh (rocprofv3 --kernel-trace --pmc, one counter "
+                                  "group per run, one launch of the workload each)",
+                "workloads": {"ns_sw": {
+                    "kernel": row["Name"], "cells_per_launch": d["config"]["cells_per_step_per_gpu"],
+                    "kernel_ms_avg_rocprof": float(row["AverageNs"]) / 1e6,
+                    "SQ_INSTS_VALU": agg.get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": agg.get("SQ_INSTS_SALU"),
+                    "SQ_WAVE_CYCLES": agg.get("SQ_WAVE_CYCLES"), "SQ_BUSY_CYCLES": agg.get("SQ_BUSY_CYCLES"),
+                    "FETCH_SIZE_KB": F, "WRITE_SIZE_KB": W, "hbm_bytes_per_launch": (2 * F + W) * 1024,
+                    "hbm_bytes_per_launch_uncorrected": (F + W) * 1024,
+                    "correction": traffic["ns_sw"]["correction"]}}}
+    json.dump(counters, open(os.path.join(dst, "counters.json"), "w"), indent=1)
     d["roofline"]["traffic"] = traffic["ns_sw"]["hbm_bytes_per_launch"]
     open(os.path.join(dst, "bench_ns_sw.json"), "w").write(json.dumps(d) + "\n")
     print("bench: %.1f %s, kernel %.1f ms, frac %.3f" % (d["value"], d["unit"], d["roofline"]["kernel_ms_per_launch"], d["roofline"]["frac"]))

@@ -271,3 +271,53 @@ def test_fullshape_fixture_is_reproducible_on_its_small_cases(oracle):
         again = MF.run_case((c["name"], c["block_id"], c["n_seqs"], c["length"], tuple(c["params"]), c["mode"]))
         for k in ("scores", "cells", "n_nodes", "n_edges", "digests", "seq_lens"):
             assert again[k] == c[k], (c["name"], k)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+def test_avx2_row_sweep_equals_scalar_oracle(oracle, mode, pname):
+    """oracle/poa_simd.c (the vectorised CPU baseline: AVX2 int16 row sweep, prefix-maximum in-row gaps,
+    value-derived traceback) must reproduce the scalar recorded-choice oracle exactly: scores, graphs,
+    paths, consensus -- including blocks whose lengths are not multiples of the vector width."""
+    if not oracle.simd_available():
+        pytest.skip("host without AVX2")
+    rng = np.random.default_rng(21 + mode)
+    p = oparams(pname, mode)
+    for trial in range(25):
+        S = int(rng.integers(2, 10))
+        L = int(rng.integers(1, 260))
+        seqs = random_block(rng, S, L, div=(0.04, 0.12, 0.3)[trial % 3], alphabet=(2, 4, 5)[trial % 3])
+        g1, s1, c1 = oracle.block_run(seqs, None, p)
+        g2, s2, c2 = oracle.block_run(seqs, None, p, impl=oracle.IMPL_AVX2)
+        assert (s1 == s2).all() and (c1 == c2).all(), f"trial {trial}"
+        assert all((a == b).all() for a, b in zip(g1.nodes(), g2.nodes()))
+        assert all((a == b).all() for a, b in zip(g1.edges(), g2.edges()))
+        for s in range(g1.n_seqs):
+            assert (g1.seq_path(s) == g2.seq_path(s)).all()
+        assert (g1.consensus() == g2.consensus()).all()
+
+
+def test_avx2_row_sweep_on_the_committed_fullshape_fixture(oracle):
+    """The vectorised variant against the committed full-shape oracle output (config 2 blocks: 16 x 1 kbp)."""
+    if not oracle.simd_available():
+        pytest.skip("host without AVX2")
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "fullshape_oracle.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["name"] in ("c2", "c4_min")]
+    for c in cases:
+        seqs = synth.make_block(c["block_id"], c["n_seqs"], c["length"])
+        g, sc, cells = oracle.block_run(seqs, None, oracle.mkparams(*c["params"], mode=c["mode"]), impl=oracle.IMPL_AVX2)
+        assert sc.tolist() == c["scores"] and g.n_nodes == c["n_nodes"] and g.n_edges == c["n_edges"]
+
+
+def test_threaded_block_driver_with_workspaces(oracle):
+    """poa_blocks_run_omp2: per-thread workspaces, both implementations, same aggregate results."""
+    bases, seq_off, blk_off = synth.make_batch(6, 5, 300)
+    p = oracle.mkparams()
+    a = oracle.blocks_run_omp(bases, seq_off, blk_off, None, p, 3)
+    b = oracle.blocks_run_omp(bases, seq_off, blk_off, None, p, 3, impl=oracle.IMPL_AVX2)
+    assert (a[0] == b[0]).all() and a[1] == b[1] and (a[2] == b[2]).all() and (a[3] == b[3]).all()
+    for blk in range(6):
+        seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[blk], blk_off[blk + 1])]
+        g, sc, _ = oracle.block_run(seqs, None, p)
+        assert (a[0][blk_off[blk]:blk_off[blk + 1]] == sc).all() and a[2][blk] == g.n_nodes
