@@ -64,6 +64,27 @@ def physical_cores():
     return max(1, len(cores) if cores else len(allowed))
 
 
+def cgroup_cpu_limit():
+    """CPUs the container's cgroup allows (cpu.max quota / period), None if unlimited.  Measured on the GPU box:
+    cpu.max = "1600000 100000" -- 16 CPUs of a 2 x 64-core host; with more runnable threads than that the CFS
+    quota throttles all of them and the aggregate rate FALLS (22 -> 9 Gcells/s from 32 to 128 threads)."""
+    for f in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(f).read().split()[:2]
+            if q != "max":
+                return max(1, int(int(q) / int(per)))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except Exception:
+        pass
+    return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -83,7 +104,9 @@ def cpu_baseline(workload, mode):
     from oracle import oracle_py as O
     from smoothxg_amd import synth
     nb, ns, ln, prm, _ = WORKLOADS[workload]
-    cores = physical_cores()
+    phys = physical_cores()
+    quota = cgroup_cpu_limit()
+    cores = min(phys, quota) if quota else phys
     p = O.mkparams(*prm, mode=mode)
     impl = O.IMPL_AVX2 if O.simd_available() else O.IMPL_SCALAR
     # memory guard: the vectorised variant keeps H, oF, oO of every cell (6 B) of one alignment per thread
@@ -129,8 +152,8 @@ def cpu_baseline(workload, mode):
     return {"cells_per_s": cells / dt, "cores": threads, "seconds": dt,
             "per_thread_cells_per_s": cells / dt / threads, "single_thread_cells_per_s": rate_one,
             "scalar_single_thread_cells_per_s": s_one, "scalar_all_threads_cells_per_s": s_all,
-            "cpu": cpu_model(), "physical_cores": cores, "implementation": name,
-            "sample": "%d WHOLE blocks of the workload (%d sequences each, %d threads = physical cores x %d rounds), %s, "
+            "cpu": cpu_model(), "physical_cores": phys, "cgroup_cpu_limit": quota, "implementation": name,
+            "sample": "%d WHOLE blocks of the workload (%d sequences each, %d threads = min(physical cores, cgroup CPU quota) x %d rounds), %s, "
                       "per-thread workspaces, OpenMP schedule(dynamic,1); %.1f s, %.3g cells; single thread %.3g cells/s, "
                       "per thread under load %.3g cells/s; scalar oracle %.3g cells/s single / %.3g cells/s on %d threads"
                       % (n_blk, ns, threads, rounds, name, dt, cells, rate_one, cells / dt / threads, s_one, s_all, threads)}
@@ -307,6 +330,7 @@ def main():
             out["cpu_baseline"] = {"value": cb["cells_per_s"] / cells_per_block, "unit": "blocks/s",
                                    "cores": cb["cores"], "kind": "port", "sample": cb["sample"],
                                    "cells_per_sec": cb["cells_per_s"], "cpu": cb["cpu"],
+                                   "physical_cores": cb["physical_cores"], "cgroup_cpu_limit": cb["cgroup_cpu_limit"],
                                    "implementation": cb["implementation"],
                                    "per_thread_cells_per_sec": cb["per_thread_cells_per_s"],
                                    "single_thread_cells_per_sec": cb["single_thread_cells_per_s"],
