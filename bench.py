@@ -159,6 +159,49 @@ def cpu_baseline(workload, mode):
                       % (n_blk, ns, threads, rounds, name, dt, cells, rate_one, cells / dt / threads, s_one, s_all, threads)}
 
 
+def end_to_end(eng, bases, seq_off, blk_off, prm, mode):
+    """One whole smoothing iteration through sxg_smooth_gfa (include/sxg_smooth.h) on the SAME blocks the kernel
+    bench runs: host collection (A2-A4) -> upload -> POA kernels -> download -> block graphs (A9/A10) -> lacing ->
+    validation -> unchop -> GFA text.  The input graph has one node per (block, sequence) and one path per
+    sequence rank, the blockset comes in through sxg_blockset_from_ranges, padding is off (-O 0) so that the blocks
+    reach the engine exactly as in the kernel-only measurement.  Returns seconds and output size."""
+    import ctypes as C
+    from smoothxg_amd import smooth as SM
+    nb = len(blk_off) - 1
+    depth = int(blk_off[1] - blk_off[0])
+    lut = np.frombuffer(b"ACGTN", np.uint8)
+    text = lut[bases].tobytes()
+    lines = []
+    for b in range(nb):
+        for k in range(depth):
+            s = int(blk_off[b]) + k
+            lines.append(b"S\t%d\t%s\n" % (b * depth + k + 1, text[int(seq_off[s]):int(seq_off[s + 1])]))
+    for k in range(depth):
+        lines.append(b"P\thap%d\t%s\t*\n" % (k, b",".join(b"%d+" % (b * depth + k + 1) for b in range(nb))))
+    gfa = b"".join(lines)
+    blocks = [[(k, b, b + 1) for k in range(depth)] for b in range(nb)]
+    sm = SM.Smoother(gfa, blocks=blocks)
+    del gfa, lines, text
+    p = SM.default_params(poa_m=prm[0], poa_n=-prm[1], poa_g=-prm[2], poa_e=-prm[3], poa_q=-prm[4], poa_c=-prm[5],
+                          local_alignment=1 if mode == 0 else 0, poa_padding_fraction=0.0)
+    run, fre, ctx = SM.gpu_provider(eng)
+    out = C.c_void_p()
+    t0 = time.perf_counter()
+    rc = sm.L.sxg_smooth_gfa(sm.g, sm.b, C.byref(p), run, fre, ctx, C.byref(out))
+    dt = time.perf_counter() - t0
+    if rc:
+        raise RuntimeError("sxg_smooth_gfa: " + sm.L.sxg_smooth_last_error().decode())
+    libc = C.CDLL("libc.so.6")
+    libc.strlen.restype = C.c_size_t
+    libc.strlen.argtypes = [C.c_void_p]
+    n = libc.strlen(out)
+    head = C.string_at(out, 12)
+    sm.L.sxg_smooth_free(out)
+    sm.close()
+    assert head.startswith(b"H\tVN:Z:1.0"), head
+    return dt, int(n)
+
+
 def source_hash():
     """SHA-256 of the kernel sources: profiles/<round>/counters.json records the hash of the build it measured."""
     import hashlib
@@ -201,6 +244,7 @@ def main():
     ap.add_argument("--mode", default="sw", choices=["sw", "nw"])
     ap.add_argument("--blocks", type=int, default=0, help="override the number of blocks per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sxg_smooth_gfa measurement")
     ap.add_argument("--check", action="store_true", help="also verify 2 blocks against the oracle")
     a = ap.parse_args()
 
@@ -324,6 +368,13 @@ def main():
                          "valu": valu, "hbm": hbm},
             "engine": {"slots": st["n_slots"], "retries": st["retries"], "arena_bytes": st["device_bytes"]},
         }
+        if world == 1 and not a.no_e2e and a.workload in ("ns", "c2", "c3", "tiny"):
+            e_s, e_bytes = end_to_end(eng, bases, seq_off, blk_off, prm, mode)
+            out["end_to_end"] = {"what": "sxg_smooth_gfa on the same %d blocks: host collection + upload + POA kernels + "
+                                         "download + block graphs + lacing + validation + unchop + GFA text (padding off)" % nb,
+                                 "seconds": e_s, "blocks_per_sec": nb / e_s, "gfa_bytes": e_bytes,
+                                 "kernel_only_blocks_per_sec": nb * a.steps / (kernel_ms / 1e3),
+                                 "ratio_to_kernel_only": (nb / e_s) / (nb * a.steps / (kernel_ms / 1e3))}
         if world == 1 and not a.no_cpu_baseline and a.workload != "c4":  # (no fixed shape to sample for c4)
             cb = cpu_baseline(a.workload, mode)
             cells_per_block = cells / a.steps / nb

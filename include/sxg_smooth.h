@@ -65,6 +65,19 @@ int64_t sxg_graph_path_count(const sxg_graph *g);
  * steps -- roughly homologous for collinear haplotypes -- so that collection, POA and lacing can be
  * exercised end to end.  Ranges of a block are ordered longest first (src/blocks.cpp:206-219). */
 int sxg_blockset_by_path_windows(const sxg_graph *g, uint64_t target_bp, sxg_blockset **out);
+
+/* path_range_t of the reference (src/blocks.hpp:29-33): steps [step_begin, step_end) of path `path`
+ * (rank of the P line in the input GFA), `length` = their bases (0 = let the library compute it; a
+ * non-zero value is checked against the steps). */
+typedef struct sxg_path_range {
+    int64_t path, step_begin, step_end, length;
+} sxg_path_range;
+/* blockset_t from the caller's own blocks (src/blocks.hpp:70-120, what smoothable_blocks / break_blocks
+ * produce): block k owns ranges[blk_off[k] .. blk_off[k+1]) in alignment order. */
+int sxg_blockset_from_ranges(const sxg_graph *g, int64_t n_blocks, const int64_t *blk_off, const sxg_path_range *ranges,
+                             sxg_blockset **out);
+int64_t sxg_blockset_block_size(const sxg_blockset *b, int64_t block_id);              /* ranges of a block, -1 on error */
+int sxg_blockset_block_ranges(const sxg_blockset *b, int64_t block_id, sxg_path_range *out); /* out[block size] */
 void sxg_blockset_free(sxg_blockset *b);
 int64_t sxg_blockset_size(const sxg_blockset *b);
 

@@ -39,7 +39,7 @@ def build_smooth(force=False, verbose=False):
     if not force and os.path.exists(SMOOTH_SO) and \
             all(os.path.getmtime(os.path.join(CSRC, d)) <= os.path.getmtime(SMOOTH_SO) for d in SMOOTH_DEPS):
         return SMOOTH_SO
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SMOOTH_SO,
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wall", "-o", SMOOTH_SO,
            os.path.join(CSRC, "sxg_smooth.cpp")]
     if verbose:
         print(" ".join(cmd))

@@ -12,7 +12,10 @@
 // restated by decree and mirrored line for line by oracle/smooth_oracle.py.
 #include "../../include/sxg_smooth.h"
 
+#include <omp.h>
 #include <algorithm>
+#include <parallel/algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -194,24 +197,63 @@ inline uint8_t code_of(char ch) {
 
 // ---------------------------------------------------------------------------------------------
 // output-side graph (odgi::graph_t's role): nodes, bidirected edges, named paths
+typedef std::pair<handle_t, handle_t> edge_t;
 struct ograph_t {
     std::vector<std::string> seq;                       // node i has id i+1
-    std::set<std::pair<handle_t, handle_t>> edges;      // canonical form
+    std::vector<edge_t> edges;                          // canonical form, sorted, unique
     std::vector<std::pair<std::string, std::vector<handle_t>>> paths;
-    static std::pair<handle_t, handle_t> canon(handle_t a, handle_t b) {
-        const std::pair<handle_t, handle_t> x(a, b), y(flip(b), flip(a));
+    static edge_t canon(handle_t a, handle_t b) {
+        const edge_t x(a, b), y(flip(b), flip(a));
         return y < x ? y : x;
     }
-    void add_edge(handle_t a, handle_t b) { edges.insert(canon(a, b)); }
+    void sort_edges() {
+        if (!std::is_sorted(edges.begin(), edges.end())) {
+            if (edges.size() > 200000) __gnu_parallel::sort(edges.begin(), edges.end());
+            else std::sort(edges.begin(), edges.end());
+        }
+        edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    }
+};
+
+// Edge set under construction.  The edges of a block graph are the consecutive step pairs of its paths
+// (src/smooth.cpp:980-994): 64 paths x 5 kbp walk the same ~14 k edges 320 k times, so duplicates are
+// filtered on insertion with a short per-handle list instead of a tree (the round-1 std::set) or a sort.
+struct edge_acc_t {
+    struct item_t { handle_t to; int32_t next; };
+    std::vector<int32_t> head;
+    std::vector<item_t> pool;
+    explicit edge_acc_t(size_t n_nodes) : head(2 * n_nodes, -1) {}
+    void add(handle_t a, handle_t b) {
+        const edge_t e = ograph_t::canon(a, b);
+        for (int32_t k = head[e.first]; k >= 0; k = pool[(size_t)k].next)
+            if (pool[(size_t)k].to == e.second) return;
+        pool.push_back(item_t{e.second, head[e.first]});
+        head[e.first] = (int32_t)pool.size() - 1;
+    }
+    void into(std::vector<edge_t>& out) const {
+        out.clear();
+        out.reserve(pool.size());
+        for (size_t h = 0; h < head.size(); ++h) {
+            const size_t first = out.size();
+            for (int32_t k = head[h]; k >= 0; k = pool[(size_t)k].next) out.emplace_back((handle_t)h, pool[(size_t)k].to);
+            std::sort(out.begin() + (long)first, out.end());
+        }
+    }
 };
 
 // unchop, by decree (odgi::algorithms::unchop is absent): merge u+ -> v+ when the right side of u
 // has the single edge to v+, the left side of v the single edge from u+, u != v, and no path starts
 // or ends inside the link.  Merged nodes are numbered by their chain head, in head order.
+// Only the out-degree of every handle and its neighbour when that degree is 1 are needed; paths are
+// rewritten in parallel (the laced graph of the headline workload walks 1.6e8 steps).
 void unchop(ograph_t& G) {
     const size_t n = G.seq.size();
-    std::vector<std::vector<handle_t>> out(2 * n);
-    for (auto& e : G.edges) { out[e.first].push_back(e.second); out[flip(e.second)].push_back(flip(e.first)); }
+    std::vector<uint32_t> deg(2 * n, 0);
+    std::vector<handle_t> only(2 * n, 0);
+    for (auto& e : G.edges) {
+        deg[e.first]++; only[e.first] = e.second;
+        deg[flip(e.second)]++; only[flip(e.second)] = flip(e.first);
+    }
     std::vector<char> start_at(2 * n, 0), end_at(2 * n, 0);
     for (auto& p : G.paths) {
         if (p.second.empty()) continue;
@@ -221,11 +263,11 @@ void unchop(ograph_t& G) {
     std::vector<int64_t> next(n, -1), prev(n, -1);
     for (size_t u = 0; u < n; ++u) {
         const handle_t uf = mk(u, false);
-        if (out[uf].size() != 1) continue;
-        const handle_t vf = out[uf][0];
+        if (deg[uf] != 1) continue;
+        const handle_t vf = only[uf];
         if (rev(vf) || nid(vf) == u) continue;
         const size_t v = nid(vf);
-        if (out[flip(vf)].size() != 1 || out[flip(vf)][0] != flip(uf)) continue;
+        if (deg[flip(vf)] != 1 || only[flip(vf)] != flip(uf)) continue;
         if (end_at[uf] || start_at[vf] || end_at[flip(vf)] || start_at[flip(uf)]) continue;
         next[u] = (int64_t)v; prev[v] = (int64_t)u;
     }
@@ -248,37 +290,46 @@ void unchop(ograph_t& G) {
         std::string s;
         size_t x = u, last = u;
         while (true) { chain_of[x] = c; s += G.seq[x]; last = x; if (next[x] < 0) break; x = (size_t)next[x]; }
-        nseq.push_back(s); first_of.push_back((int64_t)u); last_of.push_back((int64_t)last);
+        nseq.push_back(std::move(s)); first_of.push_back((int64_t)u); last_of.push_back((int64_t)last);
     }
     auto map_handle = [&](handle_t h) { return mk((uint64_t)chain_of[nid(h)], rev(h)); };
-    std::set<std::pair<handle_t, handle_t>> nedges;
+    std::vector<edge_t> nedges;
+    nedges.reserve(G.edges.size());
     for (auto& e : G.edges) {
         const size_t a = nid(e.first), b = nid(e.second);
         if (!rev(e.first) && !rev(e.second) && next[a] == (int64_t)b) continue;  // interior of a chain
-        nedges.insert(ograph_t::canon(map_handle(e.first), map_handle(e.second)));
+        nedges.push_back(ograph_t::canon(map_handle(e.first), map_handle(e.second)));
     }
-    for (auto& p : G.paths) {
-        std::vector<handle_t> ns;
-        for (handle_t h : p.second) {
+    const int64_t np = (int64_t)G.paths.size();
+#pragma omp parallel for schedule(dynamic, 1) if (n > 100000)
+    for (int64_t q = 0; q < np; ++q) {
+        auto& st = G.paths[(size_t)q].second;
+        size_t w = 0;
+        for (size_t r = 0; r < st.size(); ++r) {
+            const handle_t h = st[r];
             const size_t x = nid(h);
             const int64_t c = chain_of[x];
-            if (!rev(h)) { if (first_of[c] == (int64_t)x) ns.push_back(mk((uint64_t)c, false)); }
-            else { if (last_of[c] == (int64_t)x) ns.push_back(mk((uint64_t)c, true)); }
+            if (!rev(h)) { if (first_of[(size_t)c] == (int64_t)x) st[w++] = mk((uint64_t)c, false); }
+            else { if (last_of[(size_t)c] == (int64_t)x) st[w++] = mk((uint64_t)c, true); }
         }
-        p.second.swap(ns);
+        st.resize(w);
     }
     G.seq.swap(nseq);
     G.edges.swap(nedges);
+    G.sort_edges();
 }
 
 // topological order, by decree (odgi::algorithms::topological_order is absent): Kahn over the
 // forward-to-forward edges, smallest node first; leftovers (cycles) in id order.  Renumbers.
 void topo_renumber(ograph_t& G) {
     const size_t n = G.seq.size();
-    std::vector<std::vector<size_t>> succ(n);
+    std::vector<uint32_t> off(n + 1, 0);
     std::vector<int> indeg(n, 0);
-    for (auto& e : G.edges)
-        if (!rev(e.first) && !rev(e.second) && nid(e.first) != nid(e.second)) { succ[nid(e.first)].push_back(nid(e.second)); indeg[nid(e.second)]++; }
+    auto fwd = [](const edge_t& e) { return !rev(e.first) && !rev(e.second) && nid(e.first) != nid(e.second); };
+    for (auto& e : G.edges) if (fwd(e)) { off[nid(e.first) + 1]++; indeg[nid(e.second)]++; }
+    for (size_t u = 0; u < n; ++u) off[u + 1] += off[u];
+    std::vector<uint32_t> succ(off[n]), fill(off.begin(), off.end() - 1);
+    for (auto& e : G.edges) if (fwd(e)) succ[fill[nid(e.first)]++] = (uint32_t)nid(e.second);
     std::priority_queue<size_t, std::vector<size_t>, std::greater<size_t>> q;
     for (size_t u = 0; u < n; ++u) if (!indeg[u]) q.push(u);
     std::vector<int64_t> newid(n, -1);
@@ -286,34 +337,110 @@ void topo_renumber(ograph_t& G) {
     while (!q.empty()) {
         const size_t u = q.top(); q.pop();
         newid[u] = (int64_t)k++;
-        for (size_t v : succ[u]) if (--indeg[v] == 0) q.push(v);
+        for (uint32_t x = off[u]; x < off[u + 1]; ++x) if (--indeg[succ[x]] == 0) q.push(succ[x]);
     }
     for (size_t u = 0; u < n; ++u) if (newid[u] < 0) newid[u] = (int64_t)k++;
     std::vector<std::string> nseq(n);
-    for (size_t u = 0; u < n; ++u) nseq[(size_t)newid[u]] = G.seq[u];
-    std::set<std::pair<handle_t, handle_t>> ne;
-    for (auto& e : G.edges) ne.insert(ograph_t::canon(mk((uint64_t)newid[nid(e.first)], rev(e.first)), mk((uint64_t)newid[nid(e.second)], rev(e.second))));
+    for (size_t u = 0; u < n; ++u) nseq[(size_t)newid[u]].swap(G.seq[u]);
+    for (auto& e : G.edges) e = ograph_t::canon(mk((uint64_t)newid[nid(e.first)], rev(e.first)), mk((uint64_t)newid[nid(e.second)], rev(e.second)));
+    G.sort_edges();
     for (auto& p : G.paths) for (auto& h : p.second) h = mk((uint64_t)newid[nid(h)], rev(h));
-    G.seq.swap(nseq); G.edges.swap(ne);
+    G.seq.swap(nseq);
 }
 
 // GFA1 text in the convention the in-tree XG::to_gfa shows (src/xg.cpp:1532-1580) minus its tags;
 // S by id, L sorted by (from, to), P in path order.  odgi::to_gfa is absent: byte parity unpinned.
-std::string to_gfa(const ograph_t& G) {
-    std::string o = "H\tVN:Z:1.0\n";
-    for (size_t i = 0; i < G.seq.size(); ++i) { o += "S\t" + std::to_string(i + 1) + "\t" + G.seq[i] + "\n"; }
-    for (auto& e : G.edges) {
-        o += "L\t" + std::to_string(nid(e.first) + 1) + "\t" + (rev(e.first) ? "-" : "+") + "\t" + std::to_string(nid(e.second) + 1) + "\t" +
-             (rev(e.second) ? "-" : "+") + "\t0M\n";
-    }
-    for (auto& p : G.paths) {
-        o += "P\t" + p.first + "\t";
-        for (size_t k = 0; k < p.second.size(); ++k) {
-            if (k) o += ",";
-            o += std::to_string(nid(p.second[k]) + 1) + (rev(p.second[k]) ? "-" : "+");
+inline void put_u64(std::string& o, uint64_t v) {
+    char buf[24];
+    int k = 24;
+    do { buf[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+    o.append(buf + k, (size_t)(24 - k));
+}
+// Pieces (node chunks, edge chunks, one per path) are formatted in parallel and copied in parallel into ONE
+// malloc'ed buffer, which is what the C ABI hands out: the laced graph of the headline workload is 2.7 GB of
+// text, and building it as one std::string plus a copy for the caller took 2.4 s of the iteration.
+inline size_t digits_u64(uint64_t v) {
+    size_t d = 1;
+    while (v >= 10) { v /= 10; ++d; }
+    return d;
+}
+inline char* put_u64_at(char* o, uint64_t v) {
+    char buf[24];
+    int k = 24;
+    do { buf[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+    memcpy(o, buf + k, (size_t)(24 - k));
+    return o + (24 - k);
+}
+char* to_gfa_c(const ograph_t& G, size_t* out_len) {
+    const size_t n = G.seq.size(), ne = G.edges.size(), np = G.paths.size();
+    const size_t CH = 65536;
+    const size_t nch = (n + CH - 1) / CH, ech = (ne + CH - 1) / CH;
+    const size_t pieces = 1 + nch + ech + np;
+    // pass 1: the exact size of every piece (counting digits touches no output memory)
+    std::vector<size_t> off(pieces + 1, 0);
+    const bool par = n > 100000;
+    static const char head[] = "H\tVN:Z:1.0\n";
+    off[1] = sizeof(head) - 1;
+#pragma omp parallel for schedule(dynamic, 1) if (par)
+    for (int64_t q = 1; q < (int64_t)pieces; ++q) {
+        const size_t x = (size_t)q - 1;
+        size_t bytes = 0;
+        if (x < nch) {
+            const size_t lo = x * CH, hi = std::min(n, lo + CH);
+            for (size_t i = lo; i < hi; ++i) bytes += 4 + digits_u64(i + 1) + G.seq[i].size();          // "S\t" id "\t" seq "\n"
+        } else if (x < nch + ech) {
+            const size_t lo = (x - nch) * CH, hi = std::min(ne, lo + CH);
+            for (size_t i = lo; i < hi; ++i) bytes += 11 + digits_u64(nid(G.edges[i].first) + 1) + digits_u64(nid(G.edges[i].second) + 1);
+        } else {
+            const auto& p = G.paths[x - nch - ech];
+            bytes = 3 + p.first.size() + 3;                                                           // "P\t" name "\t" ... "\t*\n"
+            for (size_t k = 0; k < p.second.size(); ++k) bytes += digits_u64(nid(p.second[k]) + 1) + 1 + (k ? 1 : 0);
         }
-        o += "\t*\n";
+        off[(size_t)q + 1] = bytes;
     }
+    for (size_t q = 0; q < pieces; ++q) off[q + 1] += off[q];
+    char* buf = (char*)malloc(off.back() + 1);
+    if (!buf) return nullptr;
+    memcpy(buf, head, sizeof(head) - 1);
+    // pass 2: every piece is written in place
+#pragma omp parallel for schedule(dynamic, 1) if (par)
+    for (int64_t q = 1; q < (int64_t)pieces; ++q) {
+        const size_t x = (size_t)q - 1;
+        char* o = buf + off[(size_t)q];
+        if (x < nch) {
+            const size_t lo = x * CH, hi = std::min(n, lo + CH);
+            for (size_t i = lo; i < hi; ++i) {
+                *o++ = 'S'; *o++ = '\t'; o = put_u64_at(o, i + 1); *o++ = '\t';
+                memcpy(o, G.seq[i].data(), G.seq[i].size()); o += G.seq[i].size(); *o++ = '\n';
+            }
+        } else if (x < nch + ech) {
+            const size_t lo = (x - nch) * CH, hi = std::min(ne, lo + CH);
+            for (size_t i = lo; i < hi; ++i) {
+                const edge_t& e = G.edges[i];
+                *o++ = 'L'; *o++ = '\t'; o = put_u64_at(o, nid(e.first) + 1); *o++ = '\t'; *o++ = rev(e.first) ? '-' : '+'; *o++ = '\t';
+                o = put_u64_at(o, nid(e.second) + 1); *o++ = '\t'; *o++ = rev(e.second) ? '-' : '+'; memcpy(o, "\t0M\n", 4); o += 4;
+            }
+        } else {
+            const auto& p = G.paths[x - nch - ech];
+            *o++ = 'P'; *o++ = '\t'; memcpy(o, p.first.data(), p.first.size()); o += p.first.size(); *o++ = '\t';
+            for (size_t k = 0; k < p.second.size(); ++k) {
+                if (k) *o++ = ',';
+                o = put_u64_at(o, nid(p.second[k]) + 1);
+                *o++ = rev(p.second[k]) ? '-' : '+';
+            }
+            memcpy(o, "\t*\n", 3); o += 3;
+        }
+        if (o != buf + off[(size_t)q + 1]) abort();   // (size pass and write pass must agree)
+    }
+    buf[off.back()] = 0;
+    if (out_len) *out_len = off.back();
+    return buf;
+}
+std::string to_gfa(const ograph_t& G) {
+    size_t len = 0;
+    char* c = to_gfa_c(G, &len);
+    std::string o(c ? c : "", c ? len : 0);
+    free(c);
     return o;
 }
 
@@ -345,15 +472,24 @@ ograph_t build_block_graph(const collected_t& c, const uint8_t* node_code, int64
     std::vector<int64_t> keep(n_nodes, -1);
     for (auto& p : by_name) for (handle_t h : p.second) keep[nid(h)] = 0;
     for (int64_t v = 0, k = 0; v < n_nodes; ++v) if (keep[v] == 0) { keep[v] = k++; G.seq.push_back(std::string(1, dec[node_code[v] > 4 ? 4 : node_code[v]])); }
+    edge_acc_t acc(G.seq.size());
     for (auto& p : by_name) {
         for (auto& h : p.second) h = mk((uint64_t)keep[nid(h)], rev(h));
-        for (size_t k = 1; k < p.second.size(); ++k) G.add_edge(p.second[k - 1], p.second[k]);
+        for (size_t k = 1; k < p.second.size(); ++k) acc.add(p.second[k - 1], p.second[k]);
     }
+    acc.into(G.edges);
     // A10 :996-1010 paths in the order of the input block, consensus last
     std::map<std::string, size_t> idx;
     for (size_t k = 0; k < by_name.size(); ++k) idx[by_name[k].first] = k;
-    for (auto& nm : c.all_names_in_original_order) G.paths.push_back(by_name[idx[nm]]);
-    if (!consensus_name.empty()) G.paths.push_back(by_name.back());
+    // (a name occurs once per range -- path name + start position -- so every entry is taken exactly once;
+    //  should two ranges ever share a name, the later ones copy)
+    std::vector<char> taken(by_name.size(), 0);
+    for (auto& nm : c.all_names_in_original_order) {
+        const size_t k = idx[nm];
+        if (!taken[k] && (consensus_name.empty() || k + 1 != by_name.size())) { G.paths.push_back(std::move(by_name[k])); taken[k] = 1; G.paths.back().first = nm; }
+        else G.paths.push_back(taken[k] ? *std::find_if(G.paths.begin(), G.paths.end(), [&](const std::pair<std::string, std::vector<handle_t>>& q) { return q.first == nm; }) : by_name[k]);
+    }
+    if (!consensus_name.empty()) G.paths.push_back(std::move(by_name.back()));
     unchop(G);          // :935
     topo_renumber(G);   // :947
     return G;
@@ -686,7 +822,7 @@ int sxg_block_graph_gfa(const sxg_graph* g, const sxg_blockset* b, int64_t block
     sxg_poa_batch_out out;
     memset(&out, 0, sizeof(out));
     const int rc = run(ctx, &in, &out);
-    if (rc != SXG_OK) return fail(rc, "POA provider failed");
+    if (rc != SXG_OK) { if (fre) fre(&out); return fail(rc, "POA provider failed"); }
     const ograph_t G = block_graph_from_out(c, B, out, 0, cons_name(*p, block_id));
     if (fre) fre(&out);
     *out_gfa = dup_out(to_gfa(G));
@@ -709,7 +845,7 @@ static int block_maf_rows(const sxg_graph* g, const sxg_blockset* b, int64_t blo
     sxg_poa_batch_out out;
     memset(&out, 0, sizeof(out));
     const int rc = run(ctx, &in, &out);
-    if (rc != SXG_OK) return fail(rc, "POA provider failed");
+    if (rc != SXG_OK) { if (fre) fre(&out); return fail(rc, "POA provider failed"); }
     if (!out.msa || !out.msa_off || !out.msa_cols) { if (fre) fre(&out); return fail(SXG_E_INVALID, "POA provider returned no MSA"); }
     const size_t nrow = c.seqs.size() + (p->add_consensus ? 1 : 0), cols = (size_t)out.msa_cols[0];
     std::vector<std::string> msa;
@@ -740,18 +876,77 @@ int sxg_block_maf(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, c
     return SXG_OK;
 }
 
+// OpenMP team size: the hardware threads this process may use, capped by the container's CPU quota (cgroup
+// cpu.max).  Measured on the GPU box: 256 hardware threads, quota 16 CPUs -- the default team of 256 is
+// throttled by CFS and runs the host phases ~2x slower than a team of 16.  OMP_NUM_THREADS overrides.
+static int host_threads() {
+    static int cached = 0;
+    if (cached) return cached;
+    int n = omp_get_num_procs();
+    if (!getenv("OMP_NUM_THREADS")) {
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            long long per = 0;
+            if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+                const long long cpus = atoll(q) / per;
+                if (cpus >= 1 && cpus < n) n = (int)cpus;
+            }
+            fclose(f);
+        }
+    } else n = omp_get_max_threads();
+    cached = n > 0 ? n : 1;
+    return cached;
+}
+
 int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, sxg_poa_run_fn run, sxg_poa_free_fn fre, void* ctx,
                    char** out_gfa) {
     if (!g || !b || !p || !run || !out_gfa) return fail(SXG_E_INVALID, "NULL argument");
+    omp_set_num_threads(host_threads());
     const int64_t nb = (int64_t)b->blocks.size();
-    // phase 1: A2-A4 for every block (the reference's OpenMP loop up to src/smooth.cpp:743)
-    std::vector<collected_t> col(nb);
+    const bool timing = getenv("SXG_SMOOTH_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto T1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sxg_smooth] %-22s %.3f s\n", what, std::chrono::duration<double>(T1 - T0).count());
+        T0 = T1;
+    };
+    // phase 1: A2-A4 for every block, in parallel over blocks as the reference's OpenMP loop
+    // (src/smooth.cpp:1931, schedule(dynamic,1)) up to :743; the flat batch is filled in place
+    std::vector<collected_t> col((size_t)nb);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t k = 0; k < nb; ++k) col[(size_t)k] = collect(*g, b->blocks[(size_t)k], *p);
     batch_t B;
-    for (int64_t k = 0; k < nb; ++k) { col[k] = collect(*g, b->blocks[k], *p); add_to_batch(B, col[k]); }
+    {
+        B.blk_off.assign((size_t)nb + 1, 0);
+        for (int64_t k = 0; k < nb; ++k) B.blk_off[(size_t)k + 1] = B.blk_off[(size_t)k] + (int32_t)col[(size_t)k].seqs.size();
+        const size_t ns = (size_t)B.blk_off[(size_t)nb];
+        B.seq_off.assign(ns + 1, 0);
+        B.weights.assign(ns, 1);
+        for (int64_t k = 0; k < nb; ++k)
+            for (size_t i = 0; i < col[(size_t)k].seqs.size(); ++i) {
+                const size_t sidx = (size_t)B.blk_off[(size_t)k] + i;
+                B.seq_off[sidx + 1] = B.seq_off[sidx] + (int64_t)col[(size_t)k].seqs[i].size();
+                B.weights[sidx] = col[(size_t)k].weights[i];
+            }
+        B.bases.resize((size_t)B.seq_off[ns]);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t k = 0; k < nb; ++k)
+            for (size_t i = 0; i < col[(size_t)k].seqs.size(); ++i) {
+                const std::string& sq = col[(size_t)k].seqs[i];
+                uint8_t* dst = B.bases.data() + B.seq_off[(size_t)B.blk_off[(size_t)k] + i];
+                for (size_t x = 0; x < sq.size(); ++x) dst[x] = code_of(sq[x]);
+            }
+    }
+    lap("collect + batch");
     // phase 2: ONE batched POA call (replaces src/smooth.cpp:752-786 of every block)
     // A14: with -a every block brings its own scores (the engine's per_block_params)
     std::vector<sxg_poa_params> pps;
-    if (p->adaptive_poa_params) for (int64_t k = 0; k < nb; ++k) pps.push_back(block_poa_params(*g, b->blocks[k], *p));
+    if (p->adaptive_poa_params) {
+        pps.resize((size_t)nb);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t k = 0; k < nb; ++k) pps[(size_t)k] = block_poa_params(*g, b->blocks[(size_t)k], *p);
+    }
     if (pps.empty()) pps.push_back(poa_params(*p));
     sxg_poa_batch_in in;
     memset(&in, 0, sizeof(in));
@@ -763,43 +958,80 @@ int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_p
     sxg_poa_batch_out out;
     memset(&out, 0, sizeof(out));
     const int rc = run(ctx, &in, &out);
-    if (rc != SXG_OK) return fail(rc, "POA provider failed");
-    // phase 3: A9/A10 per block, path_mapping rows (src/smooth.cpp:2277-2296)
+    if (rc != SXG_OK) { if (fre) fre(&out); return fail(rc, "POA provider failed"); }
+    lap("POA provider");
+    // phase 3: A9/A10 per block in parallel (the second half of the reference's loop), then the
+    // path_mapping rows (src/smooth.cpp:2277-2296)
     struct frag_t { uint64_t path, start, end; int64_t target, block; };
-    std::vector<ograph_t> graphs(nb);
-    std::vector<frag_t> mapping;
+    std::vector<ograph_t> graphs((size_t)nb);
+#pragma omp parallel for schedule(dynamic, 1)
     for (int64_t k = 0; k < nb; ++k) {
-        if (col[k].seqs.empty()) continue;
-        graphs[k] = block_graph_from_out(col[k], B, out, k, cons_name(*p, k));
-        if (graphs[k].seq.empty()) continue;
-        int64_t path_id = 0;
-        for (auto& r : b->blocks[k]) mapping.push_back(frag_t{r.path, g->pos[r.path][r.begin], g->pos[r.path][r.end], path_id++, k});
+        if (col[(size_t)k].seqs.empty()) continue;
+        graphs[(size_t)k] = block_graph_from_out(col[(size_t)k], B, out, k, cons_name(*p, k));
+        collected_t().seqs.swap(col[(size_t)k].seqs);   // the padded sequences are not needed any more
     }
     if (fre) fre(&out);
+    std::vector<frag_t> mapping;
+    for (int64_t k = 0; k < nb; ++k) {
+        if (graphs[(size_t)k].seq.empty()) continue;
+        int64_t path_id = 0;
+        for (auto& r : b->blocks[(size_t)k]) mapping.push_back(frag_t{r.path, g->pos[r.path][r.begin], g->pos[r.path][r.end], path_id++, k});
+    }
+    lap("block graphs");
     // lacing (src/main.cpp:599-764): fragments by (path, start); blocks concatenated with an id offset
     std::stable_sort(mapping.begin(), mapping.end(), [](const frag_t& a, const frag_t& c) { return a.path < c.path || (a.path == c.path && a.start < c.start); });
     ograph_t S;
-    std::vector<uint64_t> id_trans(nb, 0);
+    std::vector<uint64_t> id_trans((size_t)nb + 1, 0), e_trans((size_t)nb + 1, 0);
     for (int64_t k = 0; k < nb; ++k) {
-        id_trans[k] = S.seq.size();
-        for (auto& s : graphs[k].seq) S.seq.push_back(s);
-        for (auto& e : graphs[k].edges) S.add_edge(mk(nid(e.first) + id_trans[k], rev(e.first)), mk(nid(e.second) + id_trans[k], rev(e.second)));
+        id_trans[(size_t)k + 1] = id_trans[(size_t)k] + graphs[(size_t)k].seq.size();
+        e_trans[(size_t)k + 1] = e_trans[(size_t)k] + graphs[(size_t)k].edges.size();
     }
+    S.seq.resize((size_t)id_trans[(size_t)nb]);
+    S.edges.resize((size_t)e_trans[(size_t)nb]);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t k = 0; k < nb; ++k) {
+        ograph_t& Gk = graphs[(size_t)k];
+        const uint64_t o = id_trans[(size_t)k];
+        for (size_t x = 0; x < Gk.seq.size(); ++x) S.seq[(size_t)o + x].swap(Gk.seq[x]);
+        // (block-local edges are canonical and sorted; the offset keeps both, and blocks are disjoint)
+        for (size_t x = 0; x < Gk.edges.size(); ++x)
+            S.edges[(size_t)e_trans[(size_t)k] + x] = edge_t(mk(nid(Gk.edges[x].first) + o, rev(Gk.edges[x].first)),
+                                                              mk(nid(Gk.edges[x].second) + o, rev(Gk.edges[x].second)));
+    }
+    // one laced path per input path: its fragments in order (parallel over paths, src/main.cpp:706-764)
+    std::vector<std::pair<size_t, size_t>> runs;   // [a, z) of every path's fragments
     for (size_t a = 0; a < mapping.size();) {
         size_t z = a;
         while (z < mapping.size() && mapping[z].path == mapping[a].path) ++z;
-        std::vector<handle_t> steps;
-        uint64_t last_end = 0;
-        for (size_t f = a; f < z; ++f) {
-            if (mapping[f].start != last_end) return fail(SXG_E_INVALID, "path " + g->pname[mapping[a].path] + " is not covered by the blocks");
-            const auto& bp = graphs[mapping[f].block].paths[(size_t)mapping[f].target].second;
-            for (handle_t h : bp) steps.push_back(mk(nid(h) + id_trans[mapping[f].block], rev(h)));
-            last_end = mapping[f].end;
-        }
-        if (last_end != g->pos[mapping[a].path].back()) return fail(SXG_E_INVALID, "path " + g->pname[mapping[a].path] + " is not covered to its end");
-        S.paths.emplace_back(g->pname[mapping[a].path], steps);
+        runs.emplace_back(a, z);
         a = z;
     }
+    S.paths.resize(runs.size());
+    std::vector<std::string> errs(runs.size());
+    std::vector<std::vector<edge_t>> links(runs.size());   // edges between the fragments of a path
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t q = 0; q < (int64_t)runs.size(); ++q) {
+        const size_t a = runs[(size_t)q].first, z = runs[(size_t)q].second;
+        size_t total = 0;
+        for (size_t f = a; f < z; ++f) total += graphs[(size_t)mapping[f].block].paths[(size_t)mapping[f].target].second.size();
+        std::vector<handle_t> steps;
+        steps.reserve(total);
+        uint64_t last_end = 0;
+        for (size_t f = a; f < z; ++f) {
+            if (mapping[f].start != last_end) { errs[(size_t)q] = "path " + g->pname[mapping[a].path] + " is not covered by the blocks"; break; }
+            const auto& bp = graphs[(size_t)mapping[f].block].paths[(size_t)mapping[f].target].second;
+            const uint64_t o = id_trans[(size_t)mapping[f].block];
+            if (!steps.empty() && !bp.empty()) links[(size_t)q].push_back(ograph_t::canon(steps.back(), mk(nid(bp.front()) + o, rev(bp.front()))));
+            for (handle_t h : bp) steps.push_back(mk(nid(h) + o, rev(h)));
+            last_end = mapping[f].end;
+        }
+        if (errs[(size_t)q].empty() && last_end != g->pos[mapping[a].path].back())
+            errs[(size_t)q] = "path " + g->pname[mapping[a].path] + " is not covered to its end";
+        S.paths[(size_t)q].first = g->pname[mapping[a].path];
+        S.paths[(size_t)q].second.swap(steps);
+    }
+    for (auto& e : errs) if (!e.empty()) return fail(SXG_E_INVALID, e);
+    lap("lacing");
     // validation (src/main.cpp:770-810)
     {
         size_t nonempty = 0;
@@ -807,24 +1039,84 @@ int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_p
         if (S.paths.size() != nonempty) return fail(SXG_E_INVALID, "path count mismatch between input and smoothed graph");
         std::unordered_map<std::string, size_t> byname;
         for (size_t q = 0; q < g->pname.size(); ++q) byname[g->pname[q]] = q;
-        for (auto& sp : S.paths) {
+        std::vector<char> bad(S.paths.size(), 0);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t q = 0; q < (int64_t)S.paths.size(); ++q) {
+            const auto& sp = S.paths[(size_t)q];
             std::string s;
-            for (handle_t h : sp.second) s += rev(h) ? revcomp(S.seq[nid(h)]) : S.seq[nid(h)];
-            if (s != g->path_sequence(byname[sp.first])) return fail(SXG_E_INVALID, "path " + sp.first + " was corrupted in the smoothed graph");
+            s.reserve((size_t)g->pos[byname[sp.first]].back());
+            for (handle_t h : sp.second) { if (rev(h)) s += revcomp(S.seq[nid(h)]); else s += S.seq[nid(h)]; }
+            if (s != g->path_sequence(byname[sp.first])) bad[(size_t)q] = 1;
         }
+        for (size_t q = 0; q < bad.size(); ++q)
+            if (bad[q]) return fail(SXG_E_INVALID, "path " + S.paths[q].first + " was corrupted in the smoothed graph");
     }
+    lap("validation");
     // consensus paths (src/main.cpp:812-870, no merged consensus: -M is out of scope)
     if (p->add_consensus)
         for (int64_t k = 0; k < nb; ++k) {
-            if (graphs[k].seq.empty()) continue;
+            if (graphs[(size_t)k].paths.empty()) continue;
             std::vector<handle_t> steps;
-            for (handle_t h : graphs[k].paths.back().second) steps.push_back(mk(nid(h) + id_trans[k], rev(h)));
-            S.paths.emplace_back(graphs[k].paths.back().first, steps);
+            for (handle_t h : graphs[(size_t)k].paths.back().second) steps.push_back(mk(nid(h) + id_trans[(size_t)k], rev(h)));
+            S.paths.emplace_back(graphs[(size_t)k].paths.back().first, steps);
         }
-    // walk every path and make sure its edges exist (src/main.cpp:1002-1016), then unchop (:1021)
-    for (auto& sp : S.paths) for (size_t k = 1; k < sp.second.size(); ++k) S.add_edge(sp.second[k - 1], sp.second[k]);
-    unchop(S);
-    *out_gfa = dup_out(to_gfa(S));
+    std::vector<ograph_t>().swap(graphs);
+    // walk every path and make sure its edges exist (src/main.cpp:1002-1016): inside a block they do by
+    // construction (A10 keeps exactly the path-supported edges), so only the links between fragments are new
+    {
+        std::vector<edge_t> lk;
+        for (auto& l : links) lk.insert(lk.end(), l.begin(), l.end());
+        std::sort(lk.begin(), lk.end());
+        lk.erase(std::unique(lk.begin(), lk.end()), lk.end());
+        std::vector<edge_t> merged(S.edges.size() + lk.size());
+        // (the block edges are sorted: canonical and sorted inside a block, blocks at increasing id offsets)
+        merged.resize((size_t)(std::set_union(S.edges.begin(), S.edges.end(), lk.begin(), lk.end(), merged.begin()) - merged.begin()));
+        S.edges.swap(merged);
+        S.sort_edges();   // (no-op check)
+    }
+    unchop(S);          // :1021
+    lap("unchop");
+    *out_gfa = to_gfa_c(S, nullptr);
+    lap("GFA text");
+    if (!*out_gfa) return fail(SXG_E_NOMEM, "out of memory for the GFA text");
+    return SXG_OK;
+}
+
+// blockset_t from the caller's own blocks (src/blocks.hpp:29-43,70-120): block k owns ranges
+// blk_off[k] .. blk_off[k+1]-1, each {path rank, first step, one-past-last step, length in bp}, in the order
+// they are to be aligned (smoothxg: longest first, src/blocks.cpp:206-219 -- kept as given).
+int sxg_blockset_from_ranges(const sxg_graph* g, int64_t n_blocks, const int64_t* blk_off, const sxg_path_range* ranges, sxg_blockset** out) {
+    if (!g || !out || n_blocks < 0 || (n_blocks > 0 && (!blk_off || !ranges))) return fail(SXG_E_INVALID, "bad argument");
+    *out = nullptr;
+    if (n_blocks > 0 && blk_off[0] != 0) return fail(SXG_E_INVALID, "blk_off[0] must be 0");
+    sxg_blockset* b = new sxg_blockset();
+    b->blocks.resize((size_t)n_blocks);
+    for (int64_t k = 0; k < n_blocks; ++k) {
+        if (blk_off[k + 1] < blk_off[k]) { delete b; return fail(SXG_E_INVALID, "blk_off not monotone"); }
+        for (int64_t r = blk_off[k]; r < blk_off[k + 1]; ++r) {
+            const sxg_path_range& pr = ranges[r];
+            if (pr.path < 0 || pr.path >= (int64_t)g->steps.size() || pr.step_begin < 0 || pr.step_end < pr.step_begin ||
+                pr.step_end > (int64_t)g->steps[(size_t)pr.path].size()) {
+                delete b;
+                return fail(SXG_E_INVALID, "range " + std::to_string(r) + " is outside its path");
+            }
+            const uint64_t bp = g->pos[(size_t)pr.path][(size_t)pr.step_end] - g->pos[(size_t)pr.path][(size_t)pr.step_begin];
+            if (pr.length != 0 && (uint64_t)pr.length != bp) { delete b; return fail(SXG_E_INVALID, "range " + std::to_string(r) + ": length does not match its steps"); }
+            b->blocks[(size_t)k].push_back(path_range_t{(uint64_t)pr.path, (uint64_t)pr.step_begin, (uint64_t)pr.step_end, bp});
+        }
+    }
+    *out = b;
+    return SXG_OK;
+}
+
+int64_t sxg_blockset_block_size(const sxg_blockset* b, int64_t block_id) {
+    if (!b || block_id < 0 || block_id >= (int64_t)b->blocks.size()) return -1;
+    return (int64_t)b->blocks[(size_t)block_id].size();
+}
+int sxg_blockset_block_ranges(const sxg_blockset* b, int64_t block_id, sxg_path_range* out) {
+    if (!b || !out || block_id < 0 || block_id >= (int64_t)b->blocks.size()) return fail(SXG_E_INVALID, "bad argument");
+    size_t k = 0;
+    for (auto& r : b->blocks[(size_t)block_id]) out[k++] = sxg_path_range{(int64_t)r.path, (int64_t)r.begin, (int64_t)r.end, (int64_t)r.length};
     return SXG_OK;
 }
 

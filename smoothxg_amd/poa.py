@@ -318,9 +318,9 @@ class PoaEngine:
                      _p(bases, C.c_uint8), parr, per)
         out = AlignOut()
         rc = self.lib.sxg_poa_align_batch(self.h, C.byref(ai), C.byref(out))
-        if rc and (check or rc != -4):
-            raise self._err("sxg_poa_align_batch")
         try:
+            if rc and (check or rc != -4):
+                raise self._err("sxg_poa_align_batch")
             status = _arr(out.status, n, np.int32)
             score = _arr(out.score, n, np.int32)
             po = _arr(out.pair_off, n + 1, np.int64)

@@ -27,7 +27,13 @@ EXPORTS = ["sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_fre
            "sxg_graph_free", "sxg_graph_node_count", "sxg_graph_path_count", "sxg_blockset_by_path_windows",
            "sxg_blockset_free", "sxg_blockset_size", "sxg_block_collect_text", "sxg_block_graph_gfa",
            "sxg_smooth_gfa", "sxg_adaptive_poa_scores", "sxg_block_identity_threshold",
-           "sxg_block_maf_rows", "sxg_block_maf"]
+           "sxg_block_maf_rows", "sxg_block_maf", "sxg_blockset_from_ranges", "sxg_blockset_block_size",
+           "sxg_blockset_block_ranges"]
+
+
+class PathRange(C.Structure):
+    """path_range_t (src/blocks.hpp:29-33): steps [step_begin, step_end) of path `path`, `length` bases."""
+    _fields_ = [("path", C.c_int64), ("step_begin", C.c_int64), ("step_end", C.c_int64), ("length", C.c_int64)]
 
 
 def load_library():
@@ -49,6 +55,10 @@ def load_library():
     L.sxg_graph_path_count.restype = C.c_int64
     L.sxg_graph_path_count.argtypes = [vp]
     L.sxg_blockset_by_path_windows.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.sxg_blockset_from_ranges.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(PathRange), C.POINTER(vp)]
+    L.sxg_blockset_block_size.restype = C.c_int64
+    L.sxg_blockset_block_size.argtypes = [vp, C.c_int64]
+    L.sxg_blockset_block_ranges.argtypes = [vp, C.c_int64, C.POINTER(PathRange)]
     L.sxg_blockset_free.argtypes = [vp]
     L.sxg_blockset_size.restype = C.c_int64
     L.sxg_blockset_size.argtypes = [vp]
@@ -94,7 +104,10 @@ def gpu_provider(engine):
 class Smoother:
     """An input GFA + a blockset; collect / block graph / full iteration through the C ABI."""
 
-    def __init__(self, gfa_text, target_bp):
+    def __init__(self, gfa_text, target_bp=None, blocks=None):
+        """blocks: the caller's own blockset -- a list of blocks, each a list of (path, step_begin, step_end)
+        or (path, step_begin, step_end, length) in alignment order (sxg_blockset_from_ranges); otherwise the
+        demo partition into path windows of target_bp."""
         self.L = load_library()
         data = gfa_text.encode() if isinstance(gfa_text, str) else gfa_text
         g = C.c_void_p()
@@ -102,9 +115,31 @@ class Smoother:
             raise SmoothError(self.L.sxg_smooth_last_error().decode())
         self.g = g
         b = C.c_void_p()
-        if self.L.sxg_blockset_by_path_windows(g, target_bp, C.byref(b)):
-            raise SmoothError(self.L.sxg_smooth_last_error().decode())
+        if blocks is not None:
+            flat = [r for blk in blocks for r in blk]
+            arr = (PathRange * max(len(flat), 1))(*[PathRange(r[0], r[1], r[2], r[3] if len(r) > 3 else 0) for r in flat])
+            off = (C.c_int64 * (len(blocks) + 1))()
+            for k, blk in enumerate(blocks):
+                off[k + 1] = off[k] + len(blk)
+            rc = self.L.sxg_blockset_from_ranges(g, len(blocks), off, arr, C.byref(b))
+        else:
+            rc = self.L.sxg_blockset_by_path_windows(g, target_bp, C.byref(b))
+        if rc:
+            msg = self.L.sxg_smooth_last_error().decode()
+            self.L.sxg_graph_free(g)
+            self.g = None
+            raise SmoothError(msg)
         self.b = b
+
+    def block_ranges(self, block_id):
+        """The ranges of a block as (path, step_begin, step_end, length) tuples."""
+        n = self.L.sxg_blockset_block_size(self.b, block_id)
+        if n < 0:
+            raise SmoothError("no such block")
+        arr = (PathRange * max(n, 1))()
+        if self.L.sxg_blockset_block_ranges(self.b, block_id, arr):
+            raise SmoothError(self.L.sxg_smooth_last_error().decode())
+        return [(arr[k].path, arr[k].step_begin, arr[k].step_end, arr[k].length) for k in range(n)]
 
     def close(self):
         if getattr(self, "b", None):

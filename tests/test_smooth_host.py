@@ -330,3 +330,52 @@ def test_host_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(S.EXPORTS) == names
+
+
+def test_blockset_from_callers_own_ranges(prov):
+    """sxg_blockset_from_ranges: real block_t's (src/blocks.hpp:29-43) enter sxg_smooth_gfa.  The demo
+    partition's ranges, handed back through the public constructor, give the same blocks and the same
+    smoothed GFA; malformed ranges are rejected, not trusted."""
+    text = synthetic_gfa(9, n_paths=6, n_nodes=80)
+    a = S.Smoother(text, 150)
+    blocks = [a.block_ranges(k) for k in range(a.n_blocks)]
+    assert all(r[3] > 0 and r[2] > r[1] for blk in blocks for r in blk)
+    b = S.Smoother(text, blocks=blocks)
+    assert b.n_blocks == a.n_blocks
+    assert [b.block_ranges(k) for k in range(b.n_blocks)] == blocks
+    p = S.default_params(add_consensus=1)
+    for k in range(a.n_blocks):
+        assert a.collect_text(k, p) == b.collect_text(k, p)
+    assert a.smooth_gfa(p, prov.provider()) == b.smooth_gfa(p, prov.provider())
+    # length 0 = "compute it"; a wrong length, a range past its path or an unknown path are errors
+    c = S.Smoother(text, blocks=[[(r[0], r[1], r[2]) for r in blk] for blk in blocks])
+    assert [c.block_ranges(k) for k in range(c.n_blocks)] == blocks
+    for bad in ([[(0, 0, 10 ** 6)]], [[(99, 0, 1)]], [[(0, 3, 2)]], [[(0, 0, 1, 123456)]]):
+        with pytest.raises(S.SmoothError):
+            S.Smoother(text, blocks=bad)
+    # a blockset that does not cover a path is caught by the lacing check, as src/main.cpp:770-810 would
+    with pytest.raises(S.SmoothError):
+        S.Smoother(text, blocks=[blocks[0]]).smooth_gfa(p, prov.provider())
+
+
+def test_integration_snippet_compiles_and_links_against_the_c_abi(tmp_path):
+    """INTEGRATION.md's phase-2 binding (the code a smoothxg maintainer pastes into smooth_spoa) is kept as
+    tests/csrc/integration_snippet.cpp: it must compile as C++17 against include/sxg_poa.h, link against
+    libsxgpoa.so, and -- on this GPU-less box -- report the missing device through the error path."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    src = os.path.join(HERE, "csrc", "integration_snippet.cpp")
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = open(src).read()
+    body = code[code.index("// ---- INTEGRATION.md snippet begin"):code.index("// ---- INTEGRATION.md snippet end")]
+    for line in body.splitlines()[1:]:
+        if line.strip():
+            assert line in md, "INTEGRATION.md and tests/csrc/integration_snippet.cpp drifted apart: " + line
+    P.load_library()
+    exe = str(tmp_path / "snippet")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"), src, "-o", exe,
+                           "-L", os.path.join(root, "smoothxg_amd", "csrc"), "-lsxgpoa", "-L/opt/rocm/lib",
+                           "-Wl,-rpath," + os.path.join(root, "smoothxg_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi 1" in r.stdout
