@@ -52,7 +52,7 @@ void sxg_smooth_default_params(sxg_smooth_params *p);
 const char *sxg_smooth_last_error(void);
 void sxg_smooth_free(void *p);
 
-/* GFA reader: S and P lines (L lines are implied by the paths for everything on this path).
+/* GFA reader: S, P and L lines (the L lines only serve block discovery's edge-jump limit).
  * Letters outside ACGT become N as in XG's 3-bit alphabet (src/xg.cpp:24-53). */
 int sxg_graph_from_gfa(const char *text, size_t len, sxg_graph **out);
 void sxg_graph_free(sxg_graph *g);
@@ -76,6 +76,21 @@ typedef struct sxg_path_range {
  * produce): block k owns ranges[blk_off[k] .. blk_off[k+1]) in alignment order. */
 int sxg_blockset_from_ranges(const sxg_graph *g, int64_t n_blocks, const int64_t *blk_off, const sxg_path_range *ranges,
                              sxg_blockset **out);
+/* Block discovery, src/blocks.cpp:7-327 (smoothable_blocks): the greedy sweep over the nodes in rank order
+ * with the weight / path-length / path-jump / edge-jump limits, ranges broken at steps an earlier block took,
+ * blocks split into the connected components of their path adjacencies.  smoothxg passes
+ * max_block_weight = target_poa_length * n_haps (-w), max_block_path_length = target_poa_length (-l),
+ * max_path_jump (-j, default 100), max_edge_jump (-e, default 0 = off), src/main.cpp:282-283,376-377,447-455.
+ * Needs the L lines of the GFA (edge jumps).  Decrees: stable ordering of equal-length ranges, id order = XG
+ * node order. */
+int sxg_blockset_smoothable(const sxg_graph *g, uint64_t max_block_weight, uint64_t max_block_path_length,
+                            uint64_t max_path_jump, uint64_t max_edge_jump, int order_paths_from_longest,
+                            sxg_blockset **out);
+/* The cutting half of break_blocks, src/breaks.cpp:210-330: ranges longer than max_poa_length (-q, default
+ * 2 * target) are cut; repeat-aware cut lengths (sautocorr, absent) and identity splitting (off by default)
+ * are not applied. */
+int sxg_blockset_break(const sxg_graph *g, const sxg_blockset *in, uint64_t max_poa_length, int order_paths_from_longest,
+                       sxg_blockset **out);
 int64_t sxg_blockset_block_size(const sxg_blockset *b, int64_t block_id);              /* ranges of a block, -1 on error */
 int sxg_blockset_block_ranges(const sxg_blockset *b, int64_t block_id, sxg_path_range *out); /* out[block size] */
 void sxg_blockset_free(sxg_blockset *b);

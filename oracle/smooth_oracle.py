@@ -39,13 +39,15 @@ class Graph:
     """S and P lines of a GFA; letters outside ACGT -> N (XG alphabet, src/xg.cpp:24-53)."""
 
     def __init__(self, text):
-        nodes, plines = [], []
+        nodes, plines, llines = [], [], []
         for line in text.split("\n"):
             f = line.rstrip("\r").split("\t")
             if f[0] == "S" and len(f) >= 3:
                 nodes.append((int(f[1]), "".join(c if c in "ACGT" else "N" for c in f[2].upper())))
             elif f[0] == "P" and len(f) >= 3:
                 plines.append((f[1], f[2]))
+            elif f[0] == "L" and len(f) >= 5:
+                llines.append((int(f[1]), f[2] == "-", int(f[3]), f[4] == "-"))
         nodes.sort(key=lambda x: x[0])
         self.ids = [n[0] for n in nodes]
         self.seq = [n[1] for n in nodes]
@@ -64,6 +66,26 @@ class Graph:
             self.pname.append(name)
             self.steps.append(hs)
             self.pos.append(ps)
+        # block discovery (src/blocks.cpp): oriented neighbours from the L lines, steps on every node, vector offsets
+        n = len(self.seq)
+        self.right_of, self.left_of = [[] for _ in range(n)], [[] for _ in range(n)]
+        for a, ar, b, br in llines:
+            A, B = mk(rank[a], ar), mk(rank[b], br)
+            if not A & 1:
+                self.right_of[A >> 1].append(B)
+            else:
+                self.left_of[A >> 1].append(B ^ 1)
+            if not B & 1:
+                self.left_of[B >> 1].append(A)
+            else:
+                self.right_of[B >> 1].append(A ^ 1)
+        self.on_node = [[] for _ in range(n)]
+        for p, st in enumerate(self.steps):
+            for k, h in enumerate(st):
+                self.on_node[h >> 1].append((p, k))
+        self.vec_off = [0]
+        for sq in self.seq:
+            self.vec_off.append(self.vec_off[-1] + len(sq))
 
     def sequence(self, h):
         s = self.seq[h >> 1]
@@ -88,6 +110,137 @@ def blockset_by_path_windows(g, target_bp):
             blocks[k].append((p, s, e, bp))
             s, k = e, k + 1
     return [sorted(b, key=lambda r: -r[3]) for b in blocks]  # stable, longest first
+
+
+def smoothable_blocks(g, max_block_weight, max_block_path_length, max_path_jump, max_edge_jump, from_longest=True):
+    """src/blocks.cpp:7-327, restated (stable ordering of equal lengths by decree).  Blocks = lists of
+    (path, step_begin, step_end, length)."""
+    seen = [[False] * len(st) for st in g.steps]
+    blocks, handles = [], []
+
+    def node_len(p, k):
+        return len(g.seq[g.steps[p][k] >> 1])
+
+    def toposplit(ranges):
+        entry = {}
+        for p, b, e, _ in ranges:
+            for k in range(b, e):
+                entry.setdefault(g.steps[p][k] >> 1, len(entry))
+        parent = list(range(len(entry)))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        for p, b, e, _ in ranges:
+            for k in range(b, e - 1):
+                x, y = find(entry[g.steps[p][k] >> 1]), find(entry[g.steps[p][k + 1] >> 1])
+                if x != y:
+                    parent[max(x, y)] = min(x, y)
+        ids, out = {}, []
+        for p, b, e, _ in ranges:
+            for k in range(b, e):
+                d = find(entry[g.steps[p][k] >> 1])
+                if d not in ids:
+                    ids[d] = len(ids)
+                    out.append([])
+        for r in ranges:
+            out[ids[find(entry[g.steps[r[0]][r[1]] >> 1])]].append(r)
+        return out
+
+    def finalize():
+        trav = sorted(st for u in handles for st in g.on_node[u] if not seen[st[0]][st[1]])
+        del handles[:]
+        spans = []
+        for p, k in trav:
+            if spans and spans[-1][0] == p and g.pos[p][k] - (g.pos[p][spans[-1][2]] + node_len(p, spans[-1][2])) <= max_path_jump:
+                spans[-1][2] = k
+            else:
+                spans.append([p, k, k])
+        ranges = []
+        for p, b, last in spans:
+            cur_open = False
+            for k in range(b, last + 1):
+                if not cur_open:
+                    ranges.append([p, k, k])
+                    cur_open = True
+                ranges[-1][2] = k
+                if seen[p][k]:
+                    cur_open = False
+            if cur_open:
+                ranges[-1][2] = last + 1
+        ranges = [r for r in ranges if r[1] != r[2]]
+        full, total = [], 0
+        for p, b, e in ranges:
+            ln = 0
+            for k in range(b, e):
+                seen[p][k] = True
+                ln += node_len(p, k)
+            full.append((p, b, e, ln))
+            total += ln
+        if total > 0:
+            full.sort(key=lambda r: -r[3] if from_longest else r[3])   # stable
+            blocks.extend(toposplit(full))
+
+    total_path_length, coverage = 0, {}
+    for u in range(len(g.seq)):
+        hl = len(g.seq[u])
+        to_add = sum(hl for st in g.on_node[u] if not seen[st[0]][st[1]])
+        max_path_length = 0
+        for p, (bp, cnt) in coverage.items():
+            div = 1.0 if cnt < len(handles) else cnt / len(handles)
+            max_path_length = max(max_path_length, int(_cround(bp / div)) + hl)
+        jump, off = 0, g.vec_off[u]
+        for o in g.right_of[u]:
+            other = g.vec_off[o >> 1] + (len(g.seq[o >> 1]) if o & 1 else 0)
+            jump = max(jump, abs(other - (off + hl)))
+        for o in g.left_of[u]:
+            other = g.vec_off[o >> 1] + (0 if o & 1 else len(g.seq[o >> 1]))
+            jump = max(jump, abs(other - off))
+        if handles and (total_path_length + to_add > max_block_weight or (max_edge_jump and jump > max_edge_jump)
+                        or max_path_length > max_block_path_length):
+            finalize()
+            total_path_length, coverage = 0, {}
+        total_path_length += to_add
+        for st in g.on_node[u]:
+            if not seen[st[0]][st[1]]:
+                bp, cnt = coverage.get(st[0], (0, 0))
+                coverage[st[0]] = (bp + hl, cnt + 1)
+        handles.append(u)
+    finalize()
+    return blocks
+
+
+def _cround(x):
+    """C's round(): half away from zero."""
+    import math
+    return math.floor(x + 0.5) if x >= 0 else math.ceil(x - 0.5)
+
+
+def break_blocks(g, blocks, max_poa_length, from_longest=True):
+    """The cutting half of src/breaks.cpp:210-330 (no repeat detection, no identity splitting)."""
+    out = []
+    for blk in blocks:
+        if not (len(blk) > 1 and any(r[3] > max_poa_length for r in blk)):
+            out.append(list(blk))
+            continue
+        chopped = []
+        for p, b, e, ln in blk:
+            if ln < max_poa_length:
+                chopped.append((p, b, e, ln))
+                continue
+            last_cut, last_end, pos = 0, b, 0
+            for k in range(b, e):
+                pos += len(g.seq[g.steps[p][k] >> 1])
+                if pos - last_cut > max_poa_length:
+                    chopped.append((p, last_end, k + 1, pos - last_cut))
+                    last_end, last_cut = k + 1, pos
+            if e != last_end:
+                chopped.append((p, last_end, e, pos - last_cut))
+        chopped.sort(key=lambda r: -r[3] if from_longest else r[3])
+        out.append(chopped)
+    return out
 
 
 def append_to_sequence(g, path, starting_step, poa_padding, on_the_left):

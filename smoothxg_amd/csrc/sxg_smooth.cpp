@@ -57,6 +57,11 @@ struct sxg_graph {
     std::vector<std::string> pname;
     std::vector<std::vector<handle_t>> steps;
     std::vector<std::vector<uint64_t>> pos;  // bp offset of every step (+ total length at the end)
+    // what block discovery needs on top (src/blocks.cpp): the L lines as oriented neighbour lists, the steps on
+    // every node, and the offset of every node in the concatenated node sequences (XG's vectorised order)
+    std::vector<std::vector<handle_t>> right_of, left_of;          // by node rank: follow_edges(n+, false / true)
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> on_node;  // (path, step) of every visit, path-major
+    std::vector<uint64_t> vec_off;
     std::string sequence(handle_t h) const { return rev(h) ? revcomp(seq[nid(h)]) : seq[nid(h)]; }
     std::string path_sequence(size_t p) const {
         std::string s;
@@ -719,6 +724,8 @@ int sxg_graph_from_gfa(const char* text, size_t len, sxg_graph** out) {
     *out = nullptr;
     std::vector<std::pair<int64_t, std::string>> nodes;
     std::vector<std::pair<std::string, std::string>> plines;
+    struct lrec_t { int64_t a, b; bool ar, br; };
+    std::vector<lrec_t> llines;
     size_t i = 0;
     while (i < len) {
         size_t j = i;
@@ -734,6 +741,7 @@ int sxg_graph_from_gfa(const char* text, size_t len, sxg_graph** out) {
                 for (auto& ch : s) { ch = (char)toupper(ch); if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ch = 'N'; }
                 nodes.emplace_back(atoll(f[1].c_str()), s);
             } else if (f[0] == "P" && f.size() >= 3) plines.emplace_back(f[1], f[2]);
+            else if (f[0] == "L" && f.size() >= 5) llines.push_back(lrec_t{atoll(f[1].c_str()), atoll(f[3].c_str()), f[2] == "-", f[4] == "-"});
         }
         i = j + 1;
     }
@@ -765,6 +773,18 @@ int sxg_graph_from_gfa(const char* text, size_t len, sxg_graph** out) {
             }
         g->pos.back().push_back(bp);
     }
+    const size_t nn = g->seq.size();
+    g->right_of.assign(nn, {}); g->left_of.assign(nn, {}); g->on_node.assign(nn, {}); g->vec_off.assign(nn + 1, 0);
+    for (size_t u = 0; u < nn; ++u) g->vec_off[u + 1] = g->vec_off[u] + g->seq[u].size();
+    for (auto& l : llines) {
+        auto ia = rank.find(l.a), ib = rank.find(l.b);
+        if (ia == rank.end() || ib == rank.end()) { delete g; return fail(SXG_E_INVALID, "L line names an unknown segment"); }
+        const handle_t A = mk(ia->second, l.ar), Bh = mk(ib->second, l.br);   // edge A -> B  ==  flip(B) -> flip(A)
+        if (!rev(A)) g->right_of[nid(A)].push_back(Bh); else g->left_of[nid(A)].push_back(flip(Bh));
+        if (!rev(Bh)) g->left_of[nid(Bh)].push_back(A); else g->right_of[nid(Bh)].push_back(flip(A));
+    }
+    for (size_t p = 0; p < g->steps.size(); ++p)
+        for (size_t st = 0; st < g->steps[p].size(); ++st) g->on_node[nid(g->steps[p][st])].emplace_back((uint32_t)p, (uint32_t)st);
     *out = g;
     return SXG_OK;
 }
@@ -1079,6 +1099,161 @@ int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_p
     *out_gfa = to_gfa_c(S, nullptr);
     lap("GFA text");
     if (!*out_gfa) return fail(SXG_E_NOMEM, "out of memory for the GFA text");
+    return SXG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block discovery: smoothable_blocks (src/blocks.cpp:7-327).  A greedy sweep over the nodes in rank order
+// collects handles until the block would outgrow its weight / path-length / edge-jump limits, turns the
+// unseen steps on those handles into path ranges (contiguous within max_path_jump, broken at steps that
+// an earlier block took), and splits the result into the weakly connected components of its path
+// adjacencies.  Restated line by line; two decrees: ranges are ordered with a STABLE sort (the reference's
+// std::sort leaves the order of equal lengths to the library), and XG's node order is id order.
+int sxg_blockset_smoothable(const sxg_graph* g, uint64_t max_block_weight, uint64_t max_block_path_length, uint64_t max_path_jump,
+                            uint64_t max_edge_jump, int order_paths_from_longest, sxg_blockset** out) {
+    if (!g || !out) return fail(SXG_E_INVALID, "NULL argument");
+    sxg_blockset* bs = new sxg_blockset();
+    const size_t np = g->steps.size(), nn = g->seq.size();
+    std::vector<std::vector<char>> seen(np);
+    for (size_t p = 0; p < np; ++p) seen[p].assign(g->steps[p].size(), 0);
+    typedef std::pair<uint32_t, uint32_t> step_t;   // (path, step rank)
+    std::vector<uint64_t> block_handles;            // node ranks
+    auto toposplit = [&](const std::vector<path_range_t>& ranges) {   // :45-107
+        std::unordered_map<uint64_t, uint64_t> id_to_entry;
+        for (auto& r : ranges)
+            for (uint64_t st = r.begin; st != r.end; ++st) {
+                const uint64_t id = nid(g->steps[r.path][st]);
+                if (!id_to_entry.count(id)) { const uint64_t e = id_to_entry.size(); id_to_entry[id] = e; }
+            }
+        std::vector<uint64_t> parent(id_to_entry.size());
+        for (size_t k = 0; k < parent.size(); ++k) parent[k] = k;
+        auto find = [&](uint64_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        for (auto& r : ranges)
+            for (uint64_t st = r.begin; st + 1 < r.end; ++st) {
+                const uint64_t a = find(id_to_entry[nid(g->steps[r.path][st])]), b = find(id_to_entry[nid(g->steps[r.path][st + 1])]);
+                if (a != b) parent[a < b ? b : a] = a < b ? a : b;
+            }
+        std::unordered_map<uint64_t, uint64_t> dset_ids;
+        std::vector<std::vector<path_range_t>> blocks;
+        for (auto& r : ranges)   // sets are numbered in the order the ranges' steps meet them (:80-91)
+            for (uint64_t st = r.begin; st != r.end; ++st) {
+                const uint64_t d = find(id_to_entry[nid(g->steps[r.path][st])]);
+                if (!dset_ids.count(d)) { const uint64_t k = dset_ids.size(); dset_ids[d] = k; blocks.emplace_back(); }
+            }
+        for (auto& r : ranges) blocks[dset_ids[find(id_to_entry[nid(g->steps[r.path][r.begin])])]].push_back(r);
+        return blocks;
+    };
+    auto finalize_block = [&]() {   // :109-231
+        std::vector<step_t> traversals;
+        for (uint64_t u : block_handles)
+            for (auto& st : g->on_node[u]) if (!seen[st.first][st.second]) traversals.push_back(st);
+        block_handles.clear();
+        std::sort(traversals.begin(), traversals.end());
+        struct span_t { uint32_t path; uint64_t begin, last; };   // closed span of step ranks
+        std::vector<span_t> spans;
+        for (auto& st : traversals) {
+            if (spans.empty()) { spans.push_back(span_t{st.first, st.second, st.second}); continue; }
+            span_t& sp = spans.back();
+            const uint64_t last_end_bp = g->pos[sp.path][sp.last] + g->seq[nid(g->steps[sp.path][sp.last])].size();
+            if (sp.path != st.first || g->pos[st.first][st.second] - last_end_bp > max_path_jump) spans.push_back(span_t{st.first, st.second, st.second});
+            else sp.last = st.second;
+        }
+        std::vector<path_range_t> ranges;
+        for (auto& sp : spans) {     // break the spans on steps an earlier block has taken (:151-174)
+            const uint64_t end = sp.last + 1;
+            bool open = false;
+            for (uint64_t cur = sp.begin; cur != end; ++cur) {
+                if (!open) { ranges.push_back(path_range_t{sp.path, cur, cur, 0}); open = true; }
+                ranges.back().end = cur;
+                if (seen[sp.path][cur]) open = false;
+            }
+            if (open) ranges.back().end = end;
+        }
+        ranges.erase(std::remove_if(ranges.begin(), ranges.end(), [](const path_range_t& r) { return r.begin == r.end; }), ranges.end());
+        uint64_t total = 0;
+        for (auto& r : ranges) {
+            r.length = 0;
+            for (uint64_t st = r.begin; st != r.end; ++st) { seen[r.path][st] = 1; r.length += g->seq[nid(g->steps[r.path][st])].size(); }
+            total += r.length;
+        }
+        if (total > 0) {
+            if (order_paths_from_longest) std::stable_sort(ranges.begin(), ranges.end(), [](const path_range_t& a, const path_range_t& b) { return a.length > b.length; });
+            else std::stable_sort(ranges.begin(), ranges.end(), [](const path_range_t& a, const path_range_t& b) { return a.length < b.length; });
+            for (auto& split : toposplit(ranges)) bs->blocks.push_back(split);
+        }
+    };
+    uint64_t total_path_length = 0;
+    std::unordered_map<uint32_t, std::pair<uint64_t, uint64_t>> path_coverage;
+    for (size_t u = 0; u < nn; ++u) {   // :239-316
+        const int64_t handle_length = (int64_t)g->seq[u].size();
+        uint64_t sequence_to_add = 0;
+        for (auto& st : g->on_node[u]) if (!seen[st.first][st.second]) sequence_to_add += (uint64_t)handle_length;
+        uint64_t max_path_length = 0;
+        for (auto& pc : path_coverage) {
+            const double div = pc.second.second < block_handles.size() ? 1.0 : (double)pc.second.second / (double)block_handles.size();
+            const uint64_t est = (uint64_t)std::round((double)pc.second.first / div);
+            max_path_length = std::max<uint64_t>(est + (uint64_t)handle_length, max_path_length);
+        }
+        int64_t longest_edge_jump = 0;
+        const int64_t off = (int64_t)g->vec_off[u];
+        for (handle_t o : g->right_of[u]) {
+            const int64_t other = (int64_t)g->vec_off[nid(o)] + (rev(o) ? (int64_t)g->seq[nid(o)].size() : 0);
+            longest_edge_jump = std::max<int64_t>(longest_edge_jump, std::llabs(other - (off + handle_length)));
+        }
+        for (handle_t o : g->left_of[u]) {
+            const int64_t other = (int64_t)g->vec_off[nid(o)] + (rev(o) ? 0 : (int64_t)g->seq[nid(o)].size());
+            longest_edge_jump = std::max<int64_t>(longest_edge_jump, std::llabs(other - off));
+        }
+        if (!block_handles.empty() &&
+            (total_path_length + sequence_to_add > max_block_weight || (max_edge_jump && (uint64_t)longest_edge_jump > max_edge_jump) ||
+             max_path_length > max_block_path_length)) {
+            finalize_block();
+            total_path_length = 0;
+            path_coverage.clear();
+        }
+        total_path_length += sequence_to_add;
+        for (auto& st : g->on_node[u])
+            if (!seen[st.first][st.second]) { path_coverage[st.first].first += (uint64_t)handle_length; path_coverage[st.first].second++; }
+        block_handles.push_back(u);
+    }
+    finalize_block();   // :322-324
+    *out = bs;
+    return SXG_OK;
+}
+
+// The cutting half of break_blocks (src/breaks.cpp:210-330): a block with more than one range and a range
+// longer than max_poa_length has every such range cut into pieces of just over max_poa_length bases
+// (a piece is closed by the step that takes it past the limit), then re-ordered by length.  The
+// repeat-aware cut length (:226-262) needs sautocorr, an absent dependency: by decree it is off (cut
+// blindly, the reference's own fallback when no repeat is found); splitting by identity (:335+) stays off
+// as in the defaults (block_group_identity = 0, src/main.cpp:316-320).
+int sxg_blockset_break(const sxg_graph* g, const sxg_blockset* in, uint64_t max_poa_length, int order_paths_from_longest, sxg_blockset** out) {
+    if (!g || !in || !out) return fail(SXG_E_INVALID, "NULL argument");
+    sxg_blockset* bs = new sxg_blockset();
+    for (auto& blk : in->blocks) {
+        bool to_break = false;
+        for (auto& r : blk) if (r.length > max_poa_length) { to_break = true; break; }
+        if (!(blk.size() > 1 && to_break)) { bs->blocks.push_back(blk); continue; }
+        const uint64_t cut_length = max_poa_length;
+        std::vector<path_range_t> chopped;
+        for (auto& r : blk) {
+            if (r.length < cut_length) { chopped.push_back(r); continue; }
+            uint64_t last_cut = 0, last_end = r.begin, pos = 0, st;
+            for (st = r.begin; st != r.end; ++st) {
+                pos += g->seq[nid(g->steps[r.path][st])].size();
+                if (pos - last_cut > cut_length) {
+                    chopped.push_back(path_range_t{r.path, last_end, st + 1, pos - last_cut});
+                    last_end = st + 1;
+                    last_cut = pos;
+                }
+            }
+            if (st != last_end) chopped.push_back(path_range_t{r.path, last_end, st, pos - last_cut});
+        }
+        if (order_paths_from_longest) std::stable_sort(chopped.begin(), chopped.end(), [](const path_range_t& a, const path_range_t& b) { return a.length > b.length; });
+        else std::stable_sort(chopped.begin(), chopped.end(), [](const path_range_t& a, const path_range_t& b) { return a.length < b.length; });
+        bs->blocks.push_back(chopped);
+    }
+    *out = bs;
     return SXG_OK;
 }
 

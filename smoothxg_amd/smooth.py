@@ -28,7 +28,7 @@ EXPORTS = ["sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_fre
            "sxg_blockset_free", "sxg_blockset_size", "sxg_block_collect_text", "sxg_block_graph_gfa",
            "sxg_smooth_gfa", "sxg_adaptive_poa_scores", "sxg_block_identity_threshold",
            "sxg_block_maf_rows", "sxg_block_maf", "sxg_blockset_from_ranges", "sxg_blockset_block_size",
-           "sxg_blockset_block_ranges"]
+           "sxg_blockset_block_ranges", "sxg_blockset_smoothable", "sxg_blockset_break"]
 
 
 class PathRange(C.Structure):
@@ -59,6 +59,8 @@ def load_library():
     L.sxg_blockset_block_size.restype = C.c_int64
     L.sxg_blockset_block_size.argtypes = [vp, C.c_int64]
     L.sxg_blockset_block_ranges.argtypes = [vp, C.c_int64, C.POINTER(PathRange)]
+    L.sxg_blockset_smoothable.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.sxg_blockset_break.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
     L.sxg_blockset_free.argtypes = [vp]
     L.sxg_blockset_size.restype = C.c_int64
     L.sxg_blockset_size.argtypes = [vp]
@@ -104,8 +106,10 @@ def gpu_provider(engine):
 class Smoother:
     """An input GFA + a blockset; collect / block graph / full iteration through the C ABI."""
 
-    def __init__(self, gfa_text, target_bp=None, blocks=None):
-        """blocks: the caller's own blockset -- a list of blocks, each a list of (path, step_begin, step_end)
+    def __init__(self, gfa_text, target_bp=None, blocks=None, discover=None):
+        """discover: block discovery as smoothxg does it -- a dict with target_poa_length and n_haps (and optionally
+        max_path_jump, max_edge_jump, max_poa_length): smoothable_blocks then the length cut of break_blocks.
+        blocks: the caller's own blockset -- a list of blocks, each a list of (path, step_begin, step_end)
         or (path, step_begin, step_end, length) in alignment order (sxg_blockset_from_ranges); otherwise the
         demo partition into path windows of target_bp."""
         self.L = load_library()
@@ -115,7 +119,16 @@ class Smoother:
             raise SmoothError(self.L.sxg_smooth_last_error().decode())
         self.g = g
         b = C.c_void_p()
-        if blocks is not None:
+        if discover is not None:
+            tl = int(discover["target_poa_length"])
+            raw = C.c_void_p()
+            rc = self.L.sxg_blockset_smoothable(g, int(discover.get("max_block_weight", tl * int(discover["n_haps"]))), tl,
+                                                int(discover.get("max_path_jump", 100)), int(discover.get("max_edge_jump", 0)), 1,
+                                                C.byref(raw))
+            if not rc:
+                rc = self.L.sxg_blockset_break(g, raw, int(discover.get("max_poa_length", 2 * tl)), 1, C.byref(b))
+                self.L.sxg_blockset_free(raw)
+        elif blocks is not None:
             flat = [r for blk in blocks for r in blk]
             arr = (PathRange * max(len(flat), 1))(*[PathRange(r[0], r[1], r[2], r[3] if len(r) > 3 else 0) for r in flat])
             off = (C.c_int64 * (len(blocks) + 1))()

@@ -87,3 +87,20 @@ def test_maf_rows_from_the_gpu_msa(engine, cons):
         msa, clen = SO.poa_msa(c, bool(cons))
         rows = SO.maf_rows(g, blocks[k], c, msa, ("Consensus_%d" % k) if cons else "", clen)
         assert sm.block_maf(k, p, S.gpu_provider(engine)) == SO.maf_block_text(rows)
+
+
+@pytest.mark.parametrize("tl", [700, 1100])
+def test_drb1_real_block_discovery_round_trip_on_gpu(engine, tl):
+    """Config 1/5 with REAL blocks: smoothable_blocks + break_blocks' length cut with the flags of the reference's
+    ctest (CMakeLists.txt:565: -j 5k -e 5k -l 700,...,1100 -r 12), collection, ONE batched GPU POA call, lacing:
+    GFA byte-identical to the oracle stack, all 12 paths preserved."""
+    text = open(DRB1).read()
+    g = SO.Graph(text)
+    blocks = SO.break_blocks(g, SO.smoothable_blocks(g, tl * 12, tl, 5000, 5000), 2 * tl)
+    sm = S.Smoother(text, discover=dict(target_poa_length=tl, n_haps=12, max_path_jump=5000, max_edge_jump=5000))
+    assert [sm.block_ranges(k) for k in range(sm.n_blocks)] == [[tuple(r) for r in blk] for blk in blocks]
+    got = sm.smooth_gfa(S.default_params(add_consensus=1), S.gpu_provider(engine))
+    assert got == SO.smooth(g, blocks, add_consensus=True)
+    out = SO.Graph(got)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)

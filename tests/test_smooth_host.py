@@ -379,3 +379,53 @@ def test_integration_snippet_compiles_and_links_against_the_c_abi(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi 1" in r.stdout
+
+
+def gfa_with_links(text):
+    """Adds the L lines the paths imply (a seqwish graph's edges are its path adjacencies)."""
+    links = set()
+    for line in text.split("\n"):
+        f = line.split("\t")
+        if f[0] == "P":
+            st = f[2].split(",")
+            for a, b in zip(st, st[1:]):
+                links.add((a[:-1], a[-1], b[:-1], b[-1]))
+    return text + "".join("L\t%s\t%s\t%s\t%s\t0M\n" % l for l in sorted(links))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_block_discovery_matches_restatement(seed):
+    """smoothable_blocks (src/blocks.cpp:7-327) + the length cut of break_blocks (src/breaks.cpp:210-330): C++ against
+    the Python restatement on graphs with shared and reversed nodes, several limit settings."""
+    text = gfa_with_links(synthetic_gfa(seed, n_paths=6, n_nodes=90))
+    g = SO.Graph(text)
+    for tl, haps, jump, ejump in ((60, 6, 100, 0), (150, 3, 20, 0), (400, 6, 100, 50), (100000, 6, 100, 0)):
+        want = SO.break_blocks(g, SO.smoothable_blocks(g, tl * haps, tl, jump, ejump), 2 * tl)
+        sm = S.Smoother(text, discover=dict(target_poa_length=tl, n_haps=haps, max_path_jump=jump, max_edge_jump=ejump))
+        got = [sm.block_ranges(k) for k in range(sm.n_blocks)]
+        assert got == [[tuple(r) for r in blk] for blk in want], (seed, tl, haps, jump, ejump)
+        # every step belongs to at most one range; ranges are inside their paths
+        taken = set()
+        for blk in got:
+            for p, b, e, ln in blk:
+                assert 0 <= b < e <= len(g.steps[p]) and ln == g.pos[p][e] - g.pos[p][b]
+                for k in range(b, e):
+                    assert (p, k) not in taken
+                    taken.add((p, k))
+
+
+def test_block_discovery_on_the_reference_fixture_and_round_trip(prov):
+    """DRB1 with the flags of the reference's own test (CMakeLists.txt:565: -j 5k -e 5k -l 700 -r 12, first iteration):
+    discovered blocks == restatement, cover every step, and the smoothing iteration on them preserves all paths."""
+    text = open(DRB1).read()
+    g = SO.Graph(text)
+    want = SO.break_blocks(g, SO.smoothable_blocks(g, 700 * 12, 700, 5000, 5000), 1400)
+    sm = S.Smoother(text, discover=dict(target_poa_length=700, n_haps=12, max_path_jump=5000, max_edge_jump=5000))
+    got = [sm.block_ranges(k) for k in range(sm.n_blocks)]
+    assert got == [[tuple(r) for r in blk] for blk in want]
+    assert sum(e - b for blk in got for _, b, e, _ in blk) == sum(len(st) for st in g.steps)   # nothing left out here
+    assert max(ln for blk in got if len(blk) > 1 for _, _, _, ln in blk) <= 1400 + max(len(sq) for sq in g.seq)
+    out = SO.Graph(sm.smooth_gfa(S.default_params(), prov.provider()))
+    assert sorted(out.pname) == sorted(g.pname)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
