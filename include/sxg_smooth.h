@@ -142,6 +142,24 @@ int sxg_block_maf(const sxg_graph *g, const sxg_blockset *b, int64_t block_id, c
 int sxg_smooth_gfa(const sxg_graph *g, const sxg_blockset *b, const sxg_smooth_params *p,
                    sxg_poa_run_fn run, sxg_poa_free_fn fre, void *ctx, char **out_gfa);
 
+/* A13 + 8f-4: the iteration with the in-order MAF consumer of smooth_and_lace (src/smooth.cpp:1600-1919): every
+ * block's MAF rows are merged into groups of blocks whose path ranges continue one another (contiguous-path Jaccard
+ * >= the threshold, -M / -J), a block that joins a group in the opposite orientation is FLIPPED -- its block graph is
+ * rebuilt reverse-complemented (src/smooth.cpp:2352-2436), which changes the laced GFA --, merged groups get one
+ * merged consensus path (src/main.cpp:870-960) and the MAF text is written group by group (src/smooth.cpp:1312-1544).
+ * Decrees: hash-map walks of the reference become insertion order; the flip applies the intended transformation
+ * (see sxg_smooth.cpp: the reference indexes its handle table with keys it never inserted). */
+typedef struct sxg_merge_params {
+    int32_t merge_blocks;                 /* -M, default 0 */
+    double contiguous_path_jaccard;       /* -J, default 1.0 */
+    int32_t preserve_unmerged_consensus;  /* -N, default 0 */
+    uint64_t max_merged_groups_in_memory; /* default 50 */
+    const char *maf_header;               /* written before the first block (src/main.cpp:489-520); NULL = none */
+} sxg_merge_params;
+void sxg_merge_default_params(sxg_merge_params *mp);
+int sxg_smooth_maf_gfa(const sxg_graph *g, const sxg_blockset *b, const sxg_smooth_params *p, const sxg_merge_params *mp,
+                       sxg_poa_run_fn run, sxg_poa_free_fn fre, void *ctx, char **out_gfa, char **out_maf, int64_t *n_flipped);
+
 #ifdef __cplusplus
 }
 #endif

@@ -647,10 +647,13 @@ def block_scores(g, ranges, adaptive, k, max_depth, m=1, n=4, g_=6, e=2, q=26, c
 
 
 def smooth(g, blocks, add_consensus=False, consensus_base="Consensus_", fraction=0.001, max_depth=1000, adaptive=False,
-           kmer_size=17, **scores):
-    """One smoothing iteration (src/main.cpp:599-1061 around the per-block POA) -> GFA text."""
+           kmer_size=17, merge=None, **scores):
+    """One smoothing iteration (src/main.cpp:599-1061 around the per-block POA) -> GFA text.
+    merge: dict(merge_blocks, jaccard, preserve_unmerged, max_groups, header) -> runs the in-order MAF consumer as
+    well (block merging, flips) and returns (GFA text, MAF text, flipped blocks)."""
     cols = [collect(g, b, fraction, max_depth) for b in blocks]
     graphs, mapping = [], []
+    block_mafs, groom = [], []
     for k, c in enumerate(cols):
         if not c.seqs:
             graphs.append(OGraph())
@@ -663,8 +666,31 @@ def smooth(g, blocks, add_consensus=False, consensus_base="Consensus_", fraction
             code, paths, cons = poa(c, m_, n_, g__, e_, q_, c_, local)
         else:
             code, paths, cons = poa(c, **scores)
-        G = build_block_graph(c, code, paths, cons, (consensus_base + str(k)) if add_consensus else "")
+        cname = (consensus_base + str(k)) if add_consensus else ""
+        G = build_block_graph(c, code, paths, cons, cname)
         graphs.append(G)
+        if merge is not None:
+            if adaptive:
+                msa, _ = poa_msa(c, add_consensus, m_, n_, g__, e_, q_, c_, local)
+            else:
+                msa, _ = poa_msa(c, add_consensus, **scores)
+            while len(block_mafs) < k:
+                block_mafs.append(None)
+                groom.append(False)
+            block_mafs.append(maf_block_map(maf_rows(g, blocks[k], c, msa, cname, len(cons))))
+            groom.append(groom_flip(g, G, cname))
+    flips, groups, in_merged, maf_text = set(), [], set(), None
+    if merge is not None:
+        while len(block_mafs) < len(blocks):
+            block_mafs.append(None)
+            groom.append(False)
+        maf_text, flips, groups, in_merged = merge_maf_blocks(
+            block_mafs, groom, merge.get("merge_blocks", False), merge.get("jaccard", 1.0), add_consensus, consensus_base,
+            merge.get("max_groups", 50), merge.get("preserve_unmerged", False), merge.get("header"))
+        for k in flips:
+            if graphs[k].seq:
+                graphs[k] = flip_block_graph(graphs[k], (consensus_base + str(k)) if add_consensus else "")
+    for k, G in enumerate(graphs):
         if not G.seq:
             continue
         for t, (p, b, e, _) in enumerate(blocks[k]):
@@ -696,11 +722,289 @@ def smooth(g, blocks, add_consensus=False, consensus_base="Consensus_", fraction
         spelled = "".join(revcomp(S.seq[h >> 1]) if h & 1 else S.seq[h >> 1] for h in st)
         assert spelled == g.path_sequence(byname[nm]), "path %s corrupted" % nm
     if add_consensus:
+        def cons_steps(k):
+            return [h + (id_trans[k] << 1) for h in graphs[k].paths[-1][1]] if graphs[k].paths else []
+        preserve = merge is None or merge.get("preserve_unmerged", False)
         for k, G in enumerate(graphs):
-            if G.seq:
-                S.paths.append((G.paths[-1][0], [h + (id_trans[k] << 1) for h in G.paths[-1][1]]))
+            if G.paths and not (merge is not None and groups and not preserve and k in in_merged):
+                S.paths.append((G.paths[-1][0], cons_steps(k)))
+        for grp in groups:   # src/main.cpp:870-960
+            iv, steps = sorted(grp["intervals"]), []
+            if not grp["inverted"]:
+                for lo, hi in iv:
+                    for k in range(lo, hi):
+                        steps += cons_steps(k)
+            else:
+                for lo, hi in reversed(iv):
+                    for k in range(hi - 1, lo - 1, -1):
+                        steps += cons_steps(k)
+            S.paths.append((consensus_base + grp["ranges"], steps))
     for _, st in S.paths:
         for x, y in zip(st[:-1], st[1:]):
             S.add_edge(x, y)
     unchop(S)
+    if merge is not None:
+        return to_gfa(S), maf_text, sorted(flips)
     return to_gfa(S)
+
+
+# ---- A13 + 8f-4: MAF block merging, flip decision, flip rebuild (src/smooth.cpp:1091-1544, 1600-1919, 2352-2436).
+# The reference keeps rows in hash maps and walks them in hash order; here every map is in insertion order
+# (first emission), by decree.  Rows are lists [record_start, seq_size, is_reversed, path_length, aligned_seq].
+def maf_block_map(rows):
+    """maf_rows() output -> ordered {src: [row, ...]} (what smooth_spoa hands to the writer thread, :893-905)."""
+    m = {}
+    for (s, st, sz, rv, ps, tx) in rows:
+        m.setdefault(s, []).append([st, sz, rv, ps, tx])
+    return m
+
+
+def _write_maf_rows(maf):
+    """src/maf.hpp:35-66 over an ordered map."""
+    w_src = max((len(s) for s, rs in maf.items() if rs), default=0)
+    w_start = max((len(str(r[0])) for rs in maf.values() for r in rs), default=0)
+    w_size = max((len(str(r[1])) for rs in maf.values() for r in rs), default=0)
+    w_ps = max((len(str(r[3])) for rs in maf.values() for r in rs), default=0)
+    out = ""
+    for s, rs in maf.items():
+        for r in rs:
+            out += "s " + s.ljust(w_src) + str(r[0]).rjust(w_start + 1) + str(r[1]).rjust(w_size + 1) + ("-" if r[2] else "+").rjust(2) + \
+                   str(r[3]).rjust(w_ps + 1) + " " + r[4] + "\n"
+    return out + "\n"
+
+
+def _put_block_in_group(grp, block_id, maf, consensus_name, on_the_left, flip):
+    """src/smooth.cpp:1091-1310"""
+    width = len(next(iter(grp["rows"].values()))[0][4]) if grp["block_ids"] else 0
+    gaps = "-" * width
+    for name, rows in maf.items():
+        if name == consensus_name:
+            continue
+        if name not in grp["rows"]:
+            grp["rows"][name] = []
+            for r in rows:
+                start = r[3] - (r[0] + r[1]) if flip else r[0]
+                if flip:
+                    r[4] = revcomp_gapped(r[4])
+                grp["rows"][name].append([start, r[1], bool(flip) != bool(r[2]), r[3], (r[4] + gaps) if on_the_left else (gaps + r[4])])
+        else:
+            unmerged = []
+            for rk, r in enumerate(rows):
+                start = r[3] - (r[0] + r[1]) if flip else r[0]
+                merged = False
+                for m in grp["rows"][name]:
+                    if (bool(flip) != bool(r[2])) == m[2] and len(m[4]) == width:
+                        if m[2]:
+                            if m[3] - m[0] == r[3] - (start + r[1]):
+                                m[0] -= r[1]
+                                if flip:
+                                    r[4] = revcomp_gapped(r[4])
+                                m[4] = r[4] + m[4]
+                                m[1] += r[1]
+                                merged = True
+                                break
+                            elif r[3] - start == m[3] - (m[0] + m[1]):
+                                if flip:
+                                    r[4] = revcomp_gapped(r[4])
+                                m[4] += r[4]
+                                m[1] += r[1]
+                                merged = True
+                                break
+                        else:
+                            if m[0] + m[1] == start:
+                                if flip:
+                                    r[4] = revcomp_gapped(r[4])
+                                m[4] += r[4]
+                                m[1] += r[1]
+                                merged = True
+                                break
+                            elif start + r[1] == m[0]:
+                                m[0] -= r[1]
+                                if flip:
+                                    r[4] = revcomp_gapped(r[4])
+                                m[4] = r[4] + m[4]
+                                m[1] += r[1]
+                                merged = True
+                                break
+                if not merged:
+                    unmerged.append(rk)
+            for rk in unmerged:
+                r = rows[rk]
+                start = r[3] - (r[0] + r[1]) if flip else r[0]
+                if flip:
+                    r[4] = revcomp_gapped(r[4])
+                grp["rows"][name].append([start, r[1], bool(flip) != bool(r[2]), r[3], (r[4] + gaps) if on_the_left else (gaps + r[4])])
+    if consensus_name:
+        r = maf[consensus_name][0]
+        if flip:
+            r[4] = revcomp_gapped(r[4])
+        entry = (consensus_name, [r[0], r[1], r[2], r[3], r[4]])
+        if on_the_left:
+            grp["cons"].insert(0, entry)
+        else:
+            grp["cons"].append(entry)
+    add = len(next(iter(maf.values()))[0][4])
+    width += add
+    gaps = "-" * add
+    for rows in grp["rows"].values():
+        for m in rows:
+            if len(m[4]) < width:
+                m[4] = (gaps + m[4]) if on_the_left else (m[4] + gaps)
+    if on_the_left:
+        grp["block_ids"].insert(0, block_id)
+    else:
+        grp["block_ids"].append(block_id)
+
+
+def revcomp_gapped(s):
+    """odgi::reverse_complement_in_place on an aligned row: '-' stays '-' (any other non-ACGT letter becomes N)."""
+    comp = {"A": "T", "T": "A", "C": "G", "G": "C", "-": "-"}
+    return "".join(comp.get(c, "N") for c in reversed(s))
+
+
+def _write_group(grp, st, add_consensus, consensus_base, below, preserve_unmerged):
+    """src/smooth.cpp:1312-1544 -> MAF text of the group; records the merged-consensus bookkeeping in st."""
+    ids = grp["block_ids"]
+    n = len(ids)
+    lo, hi = min(ids[0], ids[-1]), max(ids[0], ids[-1])
+    ranges, full = str(lo), str(ids[0])
+    if n > 1:
+        full, ranges = "", ranges + "-" + str(hi)
+        inverted = ids[0] > ids[-1]
+        intervals, begin = [], 0
+        if add_consensus:
+            st["in_merged"].add(ids[0])
+        for i in range(1, n):
+            contiguous = (ids[i - 1] - ids[i] == 1) if inverted else (ids[i] - ids[i - 1] == 1)
+            if not contiguous:
+                intervals.append((ids[i - 1], ids[begin] + 1) if inverted else (ids[begin], ids[i - 1] + 1))
+                full += str(ids[begin]) + (("-" + str(ids[i - 1])) if (i - 1) - begin > 0 else "") + "_"
+                begin = i
+            if add_consensus:
+                st["in_merged"].add(ids[i])
+        intervals.append((ids[n - 1], ids[begin] + 1) if inverted else (ids[begin], ids[n - 1] + 1))
+        full += str(ids[begin]) + (("-" + str(ids[n - 1])) if (n - 1) - begin > 0 else "")
+        st["groups"].append({"ranges": ranges, "inverted": inverted, "intervals": intervals})
+    loops = any(len(rs) > 1 for rs in grp["rows"].values())
+    maf = {name: [list(r) for r in rs] for name, rs in grp["rows"].items()}
+    if add_consensus:
+        length = len(next(iter(grp["rows"].values()))[0][4])
+        pos0, m_size, m_plen, m_text = 0, 0, 0, ""
+        for cname, r in grp["cons"]:
+            if n == 1 or preserve_unmerged:
+                maf.setdefault(cname, []).append([r[0], r[1], r[2], r[3], ("-" * pos0 + r[4]).ljust(length, "-")])
+                pos0 += len(r[4])
+            if n > 1:
+                m_size += r[1]
+                m_plen += r[3]
+                m_text += r[4]
+        if n > 1:
+            maf.setdefault(consensus_base + ranges + " ", []).append([grp["cons"][0][1][0], m_size, grp["cons"][0][1][2], m_plen, m_text])
+    out = "a blocks=" + full + " loops=" + ("true" if loops else "false")
+    if n > 1:
+        out += " merged=true" + (" below_thresh=true" if below else "")
+    return out + "\n" + _write_maf_rows(maf)
+
+
+def merge_maf_blocks(block_mafs, groom_flips, merge_blocks, contiguous_path_jaccard=1.0, add_consensus=False, consensus_base="Consensus_",
+                     max_groups=50, preserve_unmerged=False, header=""):
+    """The in-order MAF consumer of smooth_and_lace (src/smooth.cpp:1600-1919).  block_mafs[k]: ordered map of block k
+    (None/empty: block without sequences, skipped); groom_flips[k]: orientation of the lowest-ranked path in block k's
+    graph (:1826-1842).  -> (maf text, set of blocks to flip, merged groups, blocks inside merged groups)"""
+    st = {"groups": [], "in_merged": set()}
+    out, queue, flips = (header + "\n") if header is not None else "", [], set()
+    for block_id, maf in enumerate(block_mafs):
+        if not maf:
+            continue
+        cname = (consensus_base + str(block_id)) if add_consensus else ""
+        merged, below = False, False
+        flip_in, where, left_in = False, -1, -1
+        if merge_blocks:
+            if not queue:
+                queue.append({"block_ids": [], "rows": {}, "cons": []})
+                where, merged = 0, True
+            else:
+                best = -1.0
+                for gi, grp in enumerate(queue):
+                    on_left = (1 if grp["block_ids"][0] > grp["block_ids"][-1] else 0) if len(grp["block_ids"]) > 1 else -1
+                    for flip in (False, True):
+                        ok, ncont = True, 0
+                        for name, rows in maf.items():
+                            if name == cname or name not in grp["rows"]:
+                                continue
+                            found = False
+                            for r in rows:
+                                start = r[3] - (r[0] + r[1]) if flip else r[0]
+                                for m in grp["rows"][name]:
+                                    if (flip != bool(r[2])) != m[2]:
+                                        continue
+                                    if flip != bool(r[2]):
+                                        if m[3] - m[0] == r[3] - (start + r[1]):
+                                            if on_left in (-1, 1):
+                                                on_left, found, ncont = 1, True, ncont + 1
+                                                break
+                                        elif r[3] - start == m[3] - (m[0] + m[1]):
+                                            if on_left in (-1, 0):
+                                                on_left, found, ncont = 0, True, ncont + 1
+                                                break
+                                    else:
+                                        if m[0] + m[1] == start:
+                                            if on_left in (-1, 0):
+                                                on_left, found, ncont = 0, True, ncont + 1
+                                                break
+                                        elif start + r[1] == m[0]:
+                                            if on_left in (-1, 1):
+                                                on_left, found, ncont = 1, True, ncont + 1
+                                                break
+                            if not found:
+                                ok = False
+                                break
+                        if ok:
+                            n_grp = sum(len(rs) for rs in grp["rows"].values())
+                            n_blk = sum(len(rs) for rs in maf.values())
+                            den = n_blk - (1 if add_consensus else 0) + n_grp - ncont
+                            jac = ncont / den if den else float("inf")
+                            if jac >= contiguous_path_jaccard and jac > best:
+                                best, flip_in, where, left_in = jac, flip, gi, on_left
+                below = -1 < best < contiguous_path_jaccard
+            merged = where > -1
+        if merged:
+            _put_block_in_group(queue[where], block_id, maf, cname, left_in == 1, flip_in)
+            if flip_in:
+                flips.add(block_id)
+        else:
+            if len(queue) >= max_groups:
+                out += _write_group(queue.pop(0), st, add_consensus, consensus_base, below, preserve_unmerged)
+            queue.append({"block_ids": [], "rows": {}, "cons": []})
+            _put_block_in_group(queue[-1], block_id, maf, cname, False, bool(groom_flips[block_id]))
+    while queue:
+        out += _write_group(queue.pop(0), st, add_consensus, consensus_base, False, preserve_unmerged)
+    return out, flips, st["groups"], st["in_merged"]
+
+
+def flip_block_graph(G, consensus_name):
+    """src/smooth.cpp:2352-2436 -- by decree the INTENDED flip: the reference looks its edge endpoints up in a table
+    that only holds forward handles (forward_translation[reverse handle] default-constructs), so its edges cannot be
+    restated; here every node keeps its id with the reverse-complement sequence, every edge and every path step
+    toggles its orientation (paths keep spelling their sequence), the consensus keeps its handles in reversed order."""
+    F = OGraph()
+    F.seq = [revcomp(s) for s in G.seq]
+    for (a, b) in G.edges:
+        F.add_edge(a ^ 1, b ^ 1)
+    for nm, st in G.paths:
+        F.paths.append((nm, list(reversed(st)) if nm == consensus_name else [h ^ 1 for h in st]))
+    return F
+
+
+def groom_flip(g, G, consensus_name):
+    """:1826-1842: is the first step of the block path that belongs to the lowest-ranked input path reversed?
+    (the consensus path names no input path: skipped, by decree)"""
+    byname = {nm: k for k, nm in enumerate(g.pname)}
+    best, flip = None, False
+    for nm, st in G.paths:
+        if nm == consensus_name or not st:
+            continue
+        rank = byname[nm[:nm.rfind("_")]]
+        if best is None or rank < best:
+            best, flip = rank, bool(st[0] & 1)
+    return flip

@@ -23,6 +23,7 @@
 #include <queue>
 #include <set>
 #include <cmath>
+#include <deque>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -675,6 +676,267 @@ std::string maf_block_text(const std::vector<maf_row_t>& rows) {  // src/maf.hpp
     return o + "\n";
 }
 
+// ---------------------------------------------------------------------------------------------
+// A13 + 8f-4: MAF block merging, flip decision, flip rebuild (src/smooth.cpp:1091-1544, 1600-1919,
+// 2352-2436).  The reference keeps rows in hash maps and walks them in hash order; here every map is
+// in insertion order (first emission), by decree.  Mirrored by oracle/smooth_oracle.py.
+struct maf_prow_t { uint64_t start, size; bool rev; uint64_t plen; std::string text; };
+struct omap_t {   // insertion-ordered string -> rows
+    std::vector<std::pair<std::string, std::vector<maf_prow_t>>> items;
+    std::vector<maf_prow_t>* find(const std::string& k) { for (auto& it : items) if (it.first == k) return &it.second; return nullptr; }
+    std::vector<maf_prow_t>& get(const std::string& k) { if (auto* f = find(k)) return *f; items.emplace_back(k, std::vector<maf_prow_t>()); return items.back().second; }
+    bool empty() const { return items.empty(); }
+};
+struct maf_group_t { std::vector<uint64_t> block_ids; omap_t rows; std::deque<std::pair<std::string, maf_prow_t>> cons; };
+struct merged_group_info_t { std::string ranges; bool inverted; std::vector<std::pair<uint64_t, uint64_t>> intervals; };
+struct merge_state_t { std::vector<merged_group_info_t> groups; std::vector<char> in_merged; };
+
+omap_t maf_block_map(const std::vector<maf_row_t>& rows) {   // what smooth_spoa hands to the writer thread (:893-905)
+    omap_t m;
+    for (auto& r : rows) m.get(r.src).push_back(maf_prow_t{r.start, r.size, r.rev, r.src_size, r.text});
+    return m;
+}
+std::string revcomp_gapped(const std::string& t) {   // odgi::reverse_complement_in_place: '-' stays '-' (src/dna.cpp table)
+    std::string r(t.size(), '-');
+    for (size_t i = 0; i < t.size(); ++i) { const char c = t[t.size() - 1 - i]; r[i] = c == '-' ? '-' : comp(c); }
+    return r;
+}
+std::string write_maf_rows(const omap_t& maf) {   // src/maf.hpp:35-66 over an ordered map
+    size_t w_src = 0, w_start = 0, w_size = 0, w_ps = 0;
+    for (auto& it : maf.items)
+        for (auto& r : it.second) {
+            w_src = std::max(w_src, it.first.size());
+            w_start = std::max(w_start, std::to_string(r.start).size());
+            w_size = std::max(w_size, std::to_string(r.size).size());
+            w_ps = std::max(w_ps, std::to_string(r.plen).size());
+        }
+    auto setw = [](const std::string& v, size_t w) { return (v.size() < w ? std::string(w - v.size(), ' ') : std::string()) + v; };
+    std::string o;
+    for (auto& it : maf.items)
+        for (auto& r : it.second)
+            o += "s " + it.first + std::string(w_src - it.first.size(), ' ') + setw(std::to_string(r.start), w_start + 1) + setw(std::to_string(r.size), w_size + 1) +
+                 setw(r.rev ? "-" : "+", 2) + setw(std::to_string(r.plen), w_ps + 1) + " " + r.text + "\n";
+    return o + "\n";
+}
+// src/smooth.cpp:1091-1310
+void put_block_in_group(maf_group_t& grp, uint64_t block_id, omap_t& maf, const std::string& consensus_name, bool on_the_left, bool flip) {
+    size_t width = grp.block_ids.empty() ? 0 : grp.rows.items.front().second.front().text.size();
+    std::string gaps(width, '-');
+    for (auto& it : maf.items) {
+        if (it.first == consensus_name) continue;
+        std::vector<maf_prow_t>* have = grp.rows.find(it.first);
+        if (!have) {
+            std::vector<maf_prow_t> fresh;
+            for (auto& r : it.second) {
+                const uint64_t start = flip ? r.plen - (r.start + r.size) : r.start;
+                if (flip) r.text = revcomp_gapped(r.text);
+                fresh.push_back(maf_prow_t{start, r.size, (bool)(flip ^ r.rev), r.plen, on_the_left ? r.text + gaps : gaps + r.text});
+            }
+            grp.rows.get(it.first) = std::move(fresh);
+        } else {
+            std::vector<size_t> unmerged;
+            for (size_t rk = 0; rk < it.second.size(); ++rk) {
+                maf_prow_t& r = it.second[rk];
+                const uint64_t start = flip ? r.plen - (r.start + r.size) : r.start;
+                bool merged = false;
+                for (auto& m : *have) {
+                    if ((bool)(flip ^ r.rev) != m.rev || m.text.size() != width) continue;
+                    if (m.rev) {
+                        if (m.plen - m.start == r.plen - (start + r.size)) {            // new row on the left
+                            m.start -= r.size;
+                            if (flip) r.text = revcomp_gapped(r.text);
+                            m.text = r.text + m.text; m.size += r.size; merged = true; break;
+                        } else if (r.plen - start == m.plen - (m.start + m.size)) {     // new row on the right
+                            if (flip) r.text = revcomp_gapped(r.text);
+                            m.text += r.text; m.size += r.size; merged = true; break;
+                        }
+                    } else {
+                        if (m.start + m.size == start) {                                 // new row on the right
+                            if (flip) r.text = revcomp_gapped(r.text);
+                            m.text += r.text; m.size += r.size; merged = true; break;
+                        } else if (start + r.size == m.start) {                          // new row on the left
+                            m.start -= r.size;
+                            if (flip) r.text = revcomp_gapped(r.text);
+                            m.text = r.text + m.text; m.size += r.size; merged = true; break;
+                        }
+                    }
+                }
+                if (!merged) unmerged.push_back(rk);
+            }
+            for (size_t rk : unmerged) {
+                maf_prow_t& r = it.second[rk];
+                const uint64_t start = flip ? r.plen - (r.start + r.size) : r.start;
+                if (flip) r.text = revcomp_gapped(r.text);
+                have->push_back(maf_prow_t{start, r.size, (bool)(flip ^ r.rev), r.plen, on_the_left ? r.text + gaps : gaps + r.text});
+            }
+        }
+    }
+    if (!consensus_name.empty()) {
+        maf_prow_t& r = (*maf.find(consensus_name))[0];
+        if (flip) r.text = revcomp_gapped(r.text);
+        if (on_the_left) grp.cons.emplace_front(consensus_name, r); else grp.cons.emplace_back(consensus_name, r);
+    }
+    const size_t add = maf.items.front().second.front().text.size();
+    width += add;
+    gaps.assign(add, '-');
+    for (auto& it : grp.rows.items)
+        for (auto& m : it.second)
+            if (m.text.size() < width) m.text = on_the_left ? gaps + m.text : m.text + gaps;
+    if (on_the_left) grp.block_ids.insert(grp.block_ids.begin(), block_id); else grp.block_ids.push_back(block_id);
+}
+// src/smooth.cpp:1312-1544
+std::string write_group(maf_group_t& grp, merge_state_t& st, bool add_consensus, const std::string& base, bool below, bool preserve_unmerged) {
+    const auto& ids = grp.block_ids;
+    const size_t n = ids.size();
+    const uint64_t lo = std::min(ids.front(), ids.back()), hi = std::max(ids.front(), ids.back());
+    std::string ranges = std::to_string(lo), full = std::to_string(ids.front());
+    if (n > 1) {
+        full.clear();
+        ranges += "-" + std::to_string(hi);
+        const bool inverted = ids.front() > ids.back();
+        merged_group_info_t info;
+        info.inverted = inverted;
+        size_t begin = 0;
+        if (add_consensus) st.in_merged[ids[0]] = 1;
+        for (size_t i = 1; i < n; ++i) {
+            const bool contiguous = inverted ? ids[i - 1] - ids[i] == 1 : ids[i] - ids[i - 1] == 1;
+            if (!contiguous) {
+                if (inverted) info.intervals.emplace_back(ids[i - 1], ids[begin] + 1); else info.intervals.emplace_back(ids[begin], ids[i - 1] + 1);
+                full += std::to_string(ids[begin]);
+                if ((i - 1) - begin > 0) full += "-" + std::to_string(ids[i - 1]);
+                full += "_";
+                begin = i;
+            }
+            if (add_consensus) st.in_merged[ids[i]] = 1;
+        }
+        if (inverted) info.intervals.emplace_back(ids[n - 1], ids[begin] + 1); else info.intervals.emplace_back(ids[begin], ids[n - 1] + 1);
+        full += std::to_string(ids[begin]);
+        if ((n - 1) - begin > 0) full += "-" + std::to_string(ids[n - 1]);
+        info.ranges = ranges;
+        st.groups.push_back(info);
+    }
+    bool loops = false;
+    omap_t maf;
+    for (auto& it : grp.rows.items) { if (it.second.size() > 1) loops = true; maf.get(it.first) = it.second; }
+    if (add_consensus) {
+        const size_t length = grp.rows.items.front().second.front().text.size();
+        size_t pos0 = 0;
+        uint64_t m_size = 0, m_plen = 0;
+        std::string m_text;
+        for (auto& c : grp.cons) {
+            if (n == 1 || preserve_unmerged) {
+                std::string gapped = std::string(pos0, '-') + c.second.text;
+                if (gapped.size() < length) gapped.append(length - gapped.size(), '-');
+                maf.get(c.first).push_back(maf_prow_t{c.second.start, c.second.size, c.second.rev, c.second.plen, gapped});
+                pos0 += c.second.text.size();
+            }
+            if (n > 1) { m_size += c.second.size; m_plen += c.second.plen; m_text += c.second.text; }
+        }
+        if (n > 1) maf.get(base + ranges + " ").push_back(maf_prow_t{grp.cons.front().second.start, m_size, grp.cons.front().second.rev, m_plen, m_text});
+    }
+    std::string o = "a blocks=" + full + " loops=" + (loops ? "true" : "false");
+    if (n > 1) { o += " merged=true"; if (below) o += " below_thresh=true"; }
+    return o + "\n" + write_maf_rows(maf);
+}
+// the in-order MAF consumer of smooth_and_lace, src/smooth.cpp:1600-1919
+std::string merge_maf_blocks(std::vector<omap_t>& block_mafs, const std::vector<char>& groom_flips, bool merge_blocks, double jaccard_min,
+                             bool add_consensus, const std::string& base, size_t max_groups, bool preserve_unmerged, const char* header,
+                             std::vector<char>& flips, merge_state_t& st) {
+    const size_t nb = block_mafs.size();
+    flips.assign(nb, 0);
+    st.groups.clear();
+    st.in_merged.assign(nb, 0);
+    std::string out = header ? std::string(header) + "\n" : std::string();
+    std::deque<maf_group_t> queue;
+    for (size_t block_id = 0; block_id < nb; ++block_id) {
+        omap_t& maf = block_mafs[block_id];
+        if (maf.empty()) continue;   // (a block without sequences has no rows: skipped)
+        const std::string cname = add_consensus ? base + std::to_string(block_id) : std::string();
+        bool merged = false, below = false, flip_in = false;
+        int64_t where = -1;
+        int left_in = -1;
+        if (merge_blocks) {
+            if (queue.empty()) { queue.emplace_back(); where = 0; merged = true; }
+            else {
+                double best = -1;
+                for (size_t gi = 0; gi < queue.size(); ++gi) {
+                    maf_group_t& grp = queue[gi];
+                    int on_left = grp.block_ids.size() > 1 ? (grp.block_ids.front() > grp.block_ids.back() ? 1 : 0) : -1;
+                    for (int fl = 0; fl < 2; ++fl) {
+                        const bool flip = fl != 0;
+                        bool ok = true;
+                        uint64_t ncont = 0;
+                        for (auto& it : maf.items) {
+                            if (it.first == cname) continue;
+                            std::vector<maf_prow_t>* have = grp.rows.find(it.first);
+                            if (!have) continue;
+                            bool found = false;
+                            for (auto& r : it.second) {
+                                const uint64_t start = flip ? r.plen - (r.start + r.size) : r.start;
+                                for (auto& m : *have) {
+                                    if ((bool)(flip ^ r.rev) != m.rev) continue;
+                                    if (flip ^ r.rev) {
+                                        if (m.plen - m.start == r.plen - (start + r.size)) { if (on_left == -1 || on_left == 1) { on_left = 1; found = true; ++ncont; break; } }
+                                        else if (r.plen - start == m.plen - (m.start + m.size)) { if (on_left == -1 || on_left == 0) { on_left = 0; found = true; ++ncont; break; } }
+                                    } else {
+                                        if (m.start + m.size == start) { if (on_left == -1 || on_left == 0) { on_left = 0; found = true; ++ncont; break; } }
+                                        else if (start + r.size == m.start) { if (on_left == -1 || on_left == 1) { on_left = 1; found = true; ++ncont; break; } }
+                                    }
+                                }
+                            }
+                            if (!found) { ok = false; break; }
+                        }
+                        if (ok) {
+                            uint64_t n_grp = 0, n_blk = 0;
+                            for (auto& it : grp.rows.items) n_grp += it.second.size();
+                            for (auto& it : maf.items) n_blk += it.second.size();
+                            const double jac = (double)ncont / (double)(n_blk - (add_consensus ? 1 : 0) + n_grp - ncont);
+                            if (jac >= jaccard_min && jac > best) { best = jac; flip_in = flip; where = (int64_t)gi; left_in = on_left; }
+                        }
+                    }
+                }
+                below = best > -1 && best < jaccard_min;
+            }
+            merged = where > -1;
+        }
+        if (merged) {
+            put_block_in_group(queue[(size_t)where], block_id, maf, cname, left_in == 1, flip_in);
+            if (flip_in) flips[block_id] = 1;
+        } else {
+            if (queue.size() >= max_groups) { out += write_group(queue.front(), st, add_consensus, base, below, preserve_unmerged); queue.pop_front(); }
+            queue.emplace_back();
+            put_block_in_group(queue.back(), block_id, maf, cname, false, groom_flips[block_id] != 0);
+        }
+        omap_t().items.swap(maf.items);
+    }
+    while (!queue.empty()) { out += write_group(queue.front(), st, add_consensus, base, false, preserve_unmerged); queue.pop_front(); }
+    return out;
+}
+// src/smooth.cpp:2352-2436 -- by decree the INTENDED flip (the reference looks edge endpoints up in a table that
+// only holds forward handles): ids kept, sequences reverse-complemented, every edge and path step toggles its
+// orientation (paths keep spelling their sequence), the consensus keeps its handles in reversed order.
+void flip_block_graph(ograph_t& G, const std::string& consensus_name) {
+    for (auto& sq : G.seq) sq = revcomp(sq);
+    for (auto& e : G.edges) e = ograph_t::canon(flip(e.first), flip(e.second));
+    G.sort_edges();
+    for (auto& p : G.paths) {
+        if (!consensus_name.empty() && p.first == consensus_name) std::reverse(p.second.begin(), p.second.end());
+        else for (auto& h : p.second) h = flip(h);
+    }
+}
+// :1826-1842: is the first step of the block path that belongs to the lowest-ranked input path reversed?
+bool groom_flip(const std::unordered_map<std::string, size_t>& rank_of, const ograph_t& G, const std::string& consensus_name) {
+    size_t best = (size_t)-1;
+    bool fl = false;
+    for (auto& p : G.paths) {
+        if ((!consensus_name.empty() && p.first == consensus_name) || p.second.empty()) continue;
+        auto it = rank_of.find(p.first.substr(0, p.first.find_last_of('_')));
+        if (it == rank_of.end()) continue;
+        if (it->second < best) { best = it->second; fl = rev(p.second.front()); }
+    }
+    return fl;
+}
+
 std::string cons_name(const sxg_smooth_params& p, int64_t block_id) {
     if (!p.add_consensus) return "";
     return std::string(p.consensus_base_name ? p.consensus_base_name : "Consensus_") + std::to_string(block_id);
@@ -918,9 +1180,11 @@ static int host_threads() {
     return cached;
 }
 
-int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, sxg_poa_run_fn run, sxg_poa_free_fn fre, void* ctx,
-                   char** out_gfa) {
+static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, const sxg_merge_params* mp,
+                            sxg_poa_run_fn run, sxg_poa_free_fn fre, void* ctx, char** out_gfa, char** out_maf, int64_t* n_flipped) {
     if (!g || !b || !p || !run || !out_gfa) return fail(SXG_E_INVALID, "NULL argument");
+    if (out_maf) *out_maf = nullptr;
+    if (n_flipped) *n_flipped = 0;
     omp_set_num_threads(host_threads());
     const int64_t nb = (int64_t)b->blocks.size();
     const bool timing = getenv("SXG_SMOOTH_TIMING") != nullptr;
@@ -975,22 +1239,53 @@ int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_p
     in.bases = B.bases.empty() ? &dummy : B.bases.data(); in.weights = B.weights.data(); in.params = pps.data();
     in.per_block_params = p->adaptive_poa_params && nb > 0 ? 1 : 0;
     in.want_consensus = p->add_consensus;
+    in.want_msa = mp ? 1 : 0;   // the MAF rows (and with them the merge / flip decisions) need the blocks' MSAs
     sxg_poa_batch_out out;
     memset(&out, 0, sizeof(out));
     const int rc = run(ctx, &in, &out);
     if (rc != SXG_OK) { if (fre) fre(&out); return fail(rc, "POA provider failed"); }
+    if (mp && nb > 0 && (!out.msa || !out.msa_off || !out.msa_cols)) { if (fre) fre(&out); return fail(SXG_E_INVALID, "POA provider returned no MSA"); }
     lap("POA provider");
     // phase 3: A9/A10 per block in parallel (the second half of the reference's loop), then the
     // path_mapping rows (src/smooth.cpp:2277-2296)
     struct frag_t { uint64_t path, start, end; int64_t target, block; };
     std::vector<ograph_t> graphs((size_t)nb);
+    std::vector<omap_t> block_mafs(mp ? (size_t)nb : 0);
+    std::vector<char> groom(mp ? (size_t)nb : 0, 0);
+    std::unordered_map<std::string, size_t> rank_of;
+    for (size_t q = 0; q < g->pname.size(); ++q) rank_of[g->pname[q]] = q;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t k = 0; k < nb; ++k) {
         if (col[(size_t)k].seqs.empty()) continue;
         graphs[(size_t)k] = block_graph_from_out(col[(size_t)k], B, out, k, cons_name(*p, k));
+        if (mp) {   // MSA -> MAF rows of the block (src/smooth.cpp:782-905), and its grooming orientation (:1826-1842)
+            const collected_t& c = col[(size_t)k];
+            const size_t nrow = c.seqs.size() + (p->add_consensus ? 1 : 0), cols = (size_t)out.msa_cols[k];
+            std::vector<std::string> msa;
+            for (size_t r = 0; r < nrow; ++r) msa.emplace_back(out.msa + out.msa_off[k] + r * cols, cols);
+            const size_t cons_len = out.cons_off ? (size_t)(out.cons_off[k + 1] - out.cons_off[k]) : 0;
+            block_mafs[(size_t)k] = maf_block_map(maf_rows_from_msa(*g, b->blocks[(size_t)k], c, msa, cons_name(*p, k), cons_len));
+            groom[(size_t)k] = groom_flip(rank_of, graphs[(size_t)k], cons_name(*p, k)) ? 1 : 0;
+        }
         collected_t().seqs.swap(col[(size_t)k].seqs);   // the padded sequences are not needed any more
     }
     if (fre) fre(&out);
+    // the in-order MAF consumer: merges contiguous blocks, decides which block graphs get flipped (-M), writes the MAF
+    merge_state_t mstate;
+    if (mp) {
+        std::vector<char> flips;
+        const std::string maf = merge_maf_blocks(block_mafs, groom, mp->merge_blocks != 0, mp->contiguous_path_jaccard, p->add_consensus != 0,
+                                                 p->consensus_base_name ? p->consensus_base_name : "Consensus_",
+                                                 mp->max_merged_groups_in_memory ? (size_t)mp->max_merged_groups_in_memory : 50,
+                                                 mp->preserve_unmerged_consensus != 0, mp->maf_header, flips, mstate);
+        int64_t nf = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : nf)
+        for (int64_t k = 0; k < nb; ++k)
+            if (flips[(size_t)k] && !graphs[(size_t)k].seq.empty()) { flip_block_graph(graphs[(size_t)k], cons_name(*p, k)); ++nf; }   // A13
+        if (n_flipped) *n_flipped = nf;
+        if (out_maf) *out_maf = dup_out(maf);
+        lap("MAF merge + flips");
+    }
     std::vector<frag_t> mapping;
     for (int64_t k = 0; k < nb; ++k) {
         if (graphs[(size_t)k].seq.empty()) continue;
@@ -1072,14 +1367,35 @@ int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_p
             if (bad[q]) return fail(SXG_E_INVALID, "path " + S.paths[q].first + " was corrupted in the smoothed graph");
     }
     lap("validation");
-    // consensus paths (src/main.cpp:812-870, no merged consensus: -M is out of scope)
-    if (p->add_consensus)
+    // consensus paths (src/main.cpp:812-986): the blocks' own consensus paths -- except, unless they are to be
+    // preserved, those of blocks that went into a merged group -- then one path per merged group that strings the
+    // member blocks' consensus paths together in the group's order
+    if (p->add_consensus) {
+        auto cons_steps = [&](int64_t k, std::vector<handle_t>& steps) {
+            if (graphs[(size_t)k].paths.empty()) return;
+            for (handle_t h : graphs[(size_t)k].paths.back().second) steps.push_back(mk(nid(h) + id_trans[(size_t)k], rev(h)));
+        };
+        const bool preserve = !mp || mp->preserve_unmerged_consensus != 0;
         for (int64_t k = 0; k < nb; ++k) {
             if (graphs[(size_t)k].paths.empty()) continue;
+            if (mp && !mstate.groups.empty() && !preserve && mstate.in_merged[(size_t)k]) continue;
             std::vector<handle_t> steps;
-            for (handle_t h : graphs[(size_t)k].paths.back().second) steps.push_back(mk(nid(h) + id_trans[(size_t)k], rev(h)));
+            cons_steps(k, steps);
             S.paths.emplace_back(graphs[(size_t)k].paths.back().first, steps);
         }
+        if (mp)
+            for (auto& grp : mstate.groups) {
+                std::vector<std::pair<uint64_t, uint64_t>> iv = grp.intervals;   // [start, end)
+                std::sort(iv.begin(), iv.end());
+                std::vector<handle_t> steps;
+                if (!grp.inverted) { for (auto& x : iv) for (uint64_t k = x.first; k < x.second; ++k) cons_steps((int64_t)k, steps); }
+                else for (size_t j = iv.size(); j-- > 0;) for (uint64_t k = iv[j].second; k-- > iv[j].first;) cons_steps((int64_t)k, steps);
+                // (a merged consensus steps from one block's consensus into the next: edges the blocks do not hold)
+                links.emplace_back();
+                for (size_t x = 1; x < steps.size(); ++x) links.back().push_back(ograph_t::canon(steps[x - 1], steps[x]));
+                S.paths.emplace_back(std::string(p->consensus_base_name ? p->consensus_base_name : "Consensus_") + grp.ranges, steps);
+            }
+    }
     std::vector<ograph_t>().swap(graphs);
     // walk every path and make sure its edges exist (src/main.cpp:1002-1016): inside a block they do by
     // construction (A10 keeps exactly the path-supported edges), so only the links between fragments are new
@@ -1255,6 +1571,23 @@ int sxg_blockset_break(const sxg_graph* g, const sxg_blockset* in, uint64_t max_
     }
     *out = bs;
     return SXG_OK;
+}
+
+int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, sxg_poa_run_fn run, sxg_poa_free_fn fre, void* ctx,
+                   char** out_gfa) {
+    return smooth_iteration(g, b, p, nullptr, run, fre, ctx, out_gfa, nullptr, nullptr);
+}
+
+void sxg_merge_default_params(sxg_merge_params* mp) {
+    if (!mp) return;
+    mp->merge_blocks = 0; mp->contiguous_path_jaccard = 1.0; mp->preserve_unmerged_consensus = 0;   // src/main.cpp:282, -M / -J / -N
+    mp->max_merged_groups_in_memory = 50; mp->maf_header = nullptr;                                  // src/main.cpp:297-298
+}
+
+int sxg_smooth_maf_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, const sxg_merge_params* mp, sxg_poa_run_fn run,
+                       sxg_poa_free_fn fre, void* ctx, char** out_gfa, char** out_maf, int64_t* n_flipped) {
+    if (!mp || !out_maf) return fail(SXG_E_INVALID, "NULL argument");
+    return smooth_iteration(g, b, p, mp, run, fre, ctx, out_gfa, out_maf, n_flipped);
 }
 
 // blockset_t from the caller's own blocks (src/blocks.hpp:29-43,70-120): block k owns ranges

@@ -28,7 +28,13 @@ EXPORTS = ["sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_fre
            "sxg_blockset_free", "sxg_blockset_size", "sxg_block_collect_text", "sxg_block_graph_gfa",
            "sxg_smooth_gfa", "sxg_adaptive_poa_scores", "sxg_block_identity_threshold",
            "sxg_block_maf_rows", "sxg_block_maf", "sxg_blockset_from_ranges", "sxg_blockset_block_size",
-           "sxg_blockset_block_ranges", "sxg_blockset_smoothable", "sxg_blockset_break"]
+           "sxg_blockset_block_ranges", "sxg_blockset_smoothable", "sxg_blockset_break", "sxg_merge_default_params", "sxg_smooth_maf_gfa"]
+
+
+class MergeParams(C.Structure):
+    """sxg_merge_params: -M / -J / -N of smoothxg (src/main.cpp:282,297-298)."""
+    _fields_ = [("merge_blocks", C.c_int32), ("contiguous_path_jaccard", C.c_double), ("preserve_unmerged_consensus", C.c_int32),
+                ("max_merged_groups_in_memory", C.c_uint64), ("maf_header", C.c_char_p)]
 
 
 class PathRange(C.Structure):
@@ -67,6 +73,9 @@ def load_library():
     L.sxg_block_collect_text.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), C.POINTER(vp)]
     L.sxg_block_graph_gfa.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
     L.sxg_smooth_gfa.argtypes = [vp, vp, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
+    L.sxg_merge_default_params.argtypes = [C.POINTER(MergeParams)]
+    L.sxg_smooth_maf_gfa.argtypes = [vp, vp, C.POINTER(SmoothParams), C.POINTER(MergeParams), vp, vp, vp, C.POINTER(vp), C.POINTER(vp),
+                                     C.POINTER(C.c_int64)]
     L.sxg_block_maf_rows.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
     L.sxg_block_maf.argtypes = [vp, vp, C.c_int64, C.POINTER(SmoothParams), vp, vp, vp, C.POINTER(vp)]
     L.sxg_adaptive_poa_scores.restype = None
@@ -205,6 +214,24 @@ class Smoother:
         run, fre, ctx = provider
         out = C.c_void_p()
         return self._text(self.L.sxg_block_maf(self.g, self.b, block_id, C.byref(params), run, fre, ctx, C.byref(out)), out)
+
+    def smooth_maf_gfa(self, params, provider, merge_blocks=False, jaccard=1.0, preserve_unmerged=False, max_groups=50, header=None):
+        """The iteration with the in-order MAF consumer (block merging, flips): -> (GFA text, MAF text, flipped blocks)."""
+        run, fre, ctx = provider
+        mp = MergeParams()
+        self.L.sxg_merge_default_params(C.byref(mp))
+        mp.merge_blocks, mp.contiguous_path_jaccard, mp.preserve_unmerged_consensus = int(merge_blocks), jaccard, int(preserve_unmerged)
+        mp.max_merged_groups_in_memory = max_groups
+        mp.maf_header = header.encode() if header is not None else None
+        gfa, maf, nf = C.c_void_p(), C.c_void_p(), C.c_int64()
+        rc = self.L.sxg_smooth_maf_gfa(self.g, self.b, C.byref(params), C.byref(mp), run, fre, ctx, C.byref(gfa), C.byref(maf), C.byref(nf))
+        if rc:
+            raise SmoothError(self.L.sxg_smooth_last_error().decode())
+        try:
+            return C.string_at(gfa).decode(), C.string_at(maf).decode(), nf.value
+        finally:
+            self.L.sxg_smooth_free(gfa)
+            self.L.sxg_smooth_free(maf)
 
     def smooth_gfa(self, params, provider):
         run, fre, ctx = provider

@@ -104,3 +104,21 @@ def test_drb1_real_block_discovery_round_trip_on_gpu(engine, tl):
     out = SO.Graph(got)
     for q, nm in enumerate(g.pname):
         assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+def test_drb1_maf_merging_and_flips_on_gpu(engine):
+    """A13 + 8f-4 with the GPU's MSAs: MAF text (merged groups), flip set and the laced GFA with merged consensus paths
+    equal the oracle stack's on the reference's DRB1 input (-M -J 0.5, consensus on)."""
+    text = open(DRB1).read()
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 900)
+    blocks = SO.blockset_by_path_windows(g, 900)
+    p = S.default_params(add_consensus=1)
+    got = sm.smooth_maf_gfa(p, S.gpu_provider(engine), merge_blocks=True, jaccard=0.5, header="##maf version=1")
+    want = SO.smooth(g, blocks, add_consensus=True, merge=dict(merge_blocks=True, jaccard=0.5, header="##maf version=1"))
+    assert got[1] == want[1]
+    assert got[2] == len(want[2])
+    assert got[0] == want[0]
+    out = SO.Graph(got[0])
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)

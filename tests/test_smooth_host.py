@@ -122,6 +122,32 @@ def haplotype_gfa(seed, n_paths=5, length=900, sub=0.01, node_bp=60):
     return "\n".join(lines + plines) + "\n"
 
 
+def inversion_gfa(seed, n_paths=5, length=900, node_bp=60, lo=300, hi=600):
+    """Collinear haplotypes whose middle window [lo, hi) is stored reverse-complemented and walked with '-' steps:
+    that block is collected in reverse (src/smooth.cpp:707-709) and can only join its neighbours' MAF group flipped."""
+    rng = np.random.default_rng(seed)
+    anc = rng.integers(0, 4, length)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    lines, plines, nid = ["H\tVN:Z:1.0"], [], 1
+    for p in range(n_paths):
+        hap = anc.copy()
+        mut = rng.random(length) < 0.02
+        hap[mut] = (hap[mut] + rng.integers(1, 4, int(mut.sum()))) % 4
+        sq = "".join("ACGT"[x] for x in hap)
+        steps = []
+        for a in range(0, length, node_bp):
+            piece = sq[a:a + node_bp]
+            if lo <= a < hi:
+                lines.append("S\t%d\t%s" % (nid, "".join(comp[c] for c in reversed(piece))))
+                steps.append("%d-" % nid)
+            else:
+                lines.append("S\t%d\t%s" % (nid, piece))
+                steps.append("%d+" % nid)
+            nid += 1
+        plines.append("P\thap%d\t%s\t*" % (p, ",".join(steps)))
+    return "\n".join(lines + plines) + "\n"
+
+
 @pytest.fixture(scope="module")
 def prov():
     return OracleProvider()
@@ -429,3 +455,56 @@ def test_block_discovery_on_the_reference_fixture_and_round_trip(prov):
     assert sorted(out.pname) == sorted(g.pname)
     for q, nm in enumerate(g.pname):
         assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+@pytest.mark.parametrize("cons", [0, 1])
+@pytest.mark.parametrize("merge", [False, True])
+def test_maf_merging_and_flips_match_restatement(prov, cons, merge):
+    """A13 + 8f-4: the in-order MAF consumer (src/smooth.cpp:1600-1919) -- contiguous blocks merged by path Jaccard,
+    blocks joined in the opposite orientation flipped and their graphs rebuilt (src/smooth.cpp:2352-2436), merged
+    consensus paths (src/main.cpp:870-960) -- C++ against oracle/smooth_oracle.py: MAF text, flip set, laced GFA."""
+    n_flips = n_merged = 0
+    for seed, target, jac in ((4, 120, 1.0), (5, 200, 0.5), (6, 90, 0.0), (7, 150, 1.0), (-1, 300, 1.0), (-2, 300, 1.0)):
+        text = synthetic_gfa(seed, n_paths=6, n_nodes=80) if seed >= 0 else (haplotype_gfa(3, n_paths=5, length=1500) if seed == -1 else inversion_gfa(8))
+        g = SO.Graph(text)
+        sm = S.Smoother(text, target)
+        blocks = SO.blockset_by_path_windows(g, target)
+        frac = 0.0 if seed == -2 else 0.001   # (with the default padding the inverted window is outvoted by its forward flanks)
+        p = S.default_params(add_consensus=cons, poa_padding_fraction=frac)
+        want = SO.smooth(g, blocks, add_consensus=bool(cons), fraction=frac,
+                         merge=dict(merge_blocks=merge, jaccard=jac, header="##maf version=1"))
+        got = sm.smooth_maf_gfa(p, prov.provider(), merge_blocks=merge, jaccard=jac, header="##maf version=1")
+        assert got[1] == want[1], (seed, "MAF")
+        assert got[2] == len(want[2]), (seed, "flips")
+        assert got[0] == want[0], (seed, "GFA")
+        n_flips += got[2]
+        out = SO.Graph(got[0])
+        for q, nm in enumerate(g.pname):   # flipped or not, every path still spells its sequence
+            assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+        if merge:
+            n_merged += got[1].count(" merged=true")
+            if cons and " merged=true" in got[1]:
+                assert any(nm.startswith("Consensus_") and "-" in nm for nm in out.pname)
+        else:
+            assert got[2] == 0 and " merged=true" not in got[1]
+            assert got[0] == sm.smooth_gfa(p, prov.provider())     # without -M the GFA is the plain iteration's
+    if merge:
+        assert n_merged > 0, "the fixtures are meant to exercise merging"
+        assert n_flips > 0, "the fixtures are meant to exercise the flip rebuild"
+
+
+def test_flip_changes_the_gfa_exactly_as_the_restatement_says(prov):
+    """A block whose sequences run reverse to its neighbours' joins their group flipped: the laced GFA differs from the
+    unmerged one in that block's nodes (reverse-complemented) and equals the oracle's."""
+    text = synthetic_gfa(21, n_paths=5, n_nodes=70, with_reverse=True)
+    g = SO.Graph(text)
+    for target in (80, 140, 260):
+        sm = S.Smoother(text, target)
+        blocks = SO.blockset_by_path_windows(g, target)
+        p = S.default_params()
+        plain = sm.smooth_gfa(p, prov.provider())
+        got = sm.smooth_maf_gfa(p, prov.provider(), merge_blocks=True, jaccard=0.0)
+        want = SO.smooth(g, blocks, merge=dict(merge_blocks=True, jaccard=0.0))
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == len(want[2])
+        if got[2]:
+            assert got[0] != plain
