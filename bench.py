@@ -31,7 +31,9 @@ WORKLOADS = {
     # name: (blocks, seqs, length, params (m,n,g,e,q,c spoa convention), description)
     "ns": (1000, 64, 5000, (1, -4, -6, -2, -26, -1), "north-star: 1000 blocks x 64 seqs x 5 kbp, convex 1,4,6,2,26,1"),
     "c2": (1000, 16, 1000, (1, -4, -6, -2, -26, -1), "config 2: 1000 blocks x 16 seqs x 1 kbp, convex 1,4,6,2,26,1"),
-    "c3": (5000, 64, 5000, (1, -4, -8, -2, -8, -2), "config 3: 5000 blocks x 64 seqs x 5 kbp, affine (abPOA o+k*e => g=-(o+e))"),
+    "c3": (5000, 64, 5000, (1, -4, -8, -2, -8, -2), "config 3: 5000 blocks x 64 seqs x 5 kbp, affine (abPOA o+k*e => g=-(o+e)), full matrix"),
+    # config 3 as the reference's -A (abPOA) path runs it: banded, wb=311 wf=0.03 (src/smooth.cpp:266-271); cells = band cells
+    "c3b": (5000, 64, 5000, (1, -4, -8, -2, -8, -2), "config 3 banded: 5000 blocks x 64 seqs x 5 kbp, affine, band w = 311 + 0.03 L (abPOA path)"),
     # config 4 is 50 000 mixed blocks over 8 GPUs: 6 250 per GPU; seqs/length are drawn per block (synth mixed=True)
     "c4": (6250, 0, 0, (1, -4, -6, -2, -26, -1), "config 4: mixed blocks, 8-128 seqs x 0.5-10 kbp, 6250 per GPU, convex 1,4,6,2,26,1"),
     "tiny": (64, 8, 400, (1, -4, -6, -2, -26, -1), "smoke: 64 blocks x 8 seqs x 400 bp"),
@@ -267,7 +269,7 @@ def main():
     if a.blocks:
         nb = a.blocks
     mode = 0 if a.mode == "sw" else 1
-    params = S.Params(*prm, mode, 0)
+    params = S.Params(*prm, mode, 1 if a.workload == "c3b" else 0)
     bases, seq_off, blk_off = synth.make_batch(nb, ns, ln, first_block=rank * nb, mixed=(a.workload == "c4"))
     eng = S.PoaEngine(local_rank)
     eng.upload(bases, seq_off, blk_off, None, params)  # inputs resident in HBM from here on
@@ -345,7 +347,7 @@ def main():
             "metric": "POA blocks/sec (+ DP cells/sec) on 1000-block synthetic",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16" if st["dom_row_mode"] == 2 else "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16" if st["dom_row_mode"] >= 2 else "int32", "data": "synthetic",
             "config": {"workload": desc, "blocks_per_gpu": nb, "mode": a.mode,
                        "cells_per_step_per_gpu": cells / a.steps},
             "cells_per_sec": total_cells / dt,
@@ -361,21 +363,21 @@ def main():
                          "traffic": traffic,
                          "kernel": "poa_block_kernel<T=%d, cols/lane=%d, %s>" % (
                              st["dom_threads"], st["dom_cols_per_lane"],
-                             "packed int16 sweep" if st["dom_row_mode"] == 2 else "32-bit sweep"),
+                             {2: "packed int16 sweep", 3: "banded packed int16 sweep (one wave, sliding window)"}.get(st["dom_row_mode"], "32-bit sweep")),
                          "kernel_ms_per_launch": kernel_ms / max(launches, 1),
                          "algo_bytes_per_launch": algo_bytes / max(launches, 1),
                          "bytes_per_cell": algo_bytes / max(cells, 1),
                          "valu": valu, "hbm": hbm},
             "engine": {"slots": st["n_slots"], "retries": st["retries"], "arena_bytes": st["device_bytes"]},
         }
-        if world == 1 and not a.no_e2e and a.workload in ("ns", "c2", "c3", "tiny"):
+        if world == 1 and not a.no_e2e and a.workload in ("ns", "c2", "tiny"):
             e_s, e_bytes = end_to_end(eng, bases, seq_off, blk_off, prm, mode)
             out["end_to_end"] = {"what": "sxg_smooth_gfa on the same %d blocks: host collection + upload + POA kernels + "
                                          "download + block graphs + lacing + validation + unchop + GFA text (padding off)" % nb,
                                  "seconds": e_s, "blocks_per_sec": nb / e_s, "gfa_bytes": e_bytes,
                                  "kernel_only_blocks_per_sec": nb * a.steps / (kernel_ms / 1e3),
                                  "ratio_to_kernel_only": (nb / e_s) / (nb * a.steps / (kernel_ms / 1e3))}
-        if world == 1 and not a.no_cpu_baseline and a.workload != "c4":  # (no fixed shape to sample for c4)
+        if world == 1 and not a.no_cpu_baseline and a.workload not in ("c4", "c3b"):  # (no fixed shape to sample for c4)
             cb = cpu_baseline(a.workload, mode)
             cells_per_block = cells / a.steps / nb
             out["cpu_baseline"] = {"value": cb["cells_per_s"] / cells_per_block, "unit": "blocks/s",

@@ -60,7 +60,11 @@ extern "C" {
 typedef struct sxg_poa_params {
     int8_t m, n, g, e, q, c;
     uint8_t mode;
-    uint8_t reserved;
+    uint8_t banded; /* 0 = full matrix (the spoa path, smooth_spoa); 1 = banded as the abPOA path (smooth_abpoa,
+                       src/smooth.cpp:133-627: wb = 311, wf = 0.03 at :266-271).  The band is this engine's own:
+                       w = 311 + (int)(0.03 L) columns either side of the node's backbone coordinate, in whole
+                       11-column strips (oracle/poa_oracle.c, decrees B1-B3; abPOA is absent from the reference
+                       snapshot).  Local mode only; out->cells then counts band cells.                     */
 } sxg_poa_params;
 
 typedef struct sxg_poa_handle sxg_poa_handle;
@@ -150,7 +154,7 @@ typedef struct sxg_poa_stats {
     double dom_kernel_ms;
     uint64_t dom_cells, dom_algo_bytes;
     int32_t dom_threads, dom_cols_per_lane; /* launch geometry */
-    int32_t dom_row_mode;  /* 0/1 = 32-bit sweep (int16 / int32 row words), 2 = packed-int16 sweep */
+    int32_t dom_row_mode;  /* 0/1 = 32-bit sweep (int16 / int32 row words), 2 = packed-int16 sweep, 3 = banded packed sweep */
     int32_t reserved;
 } sxg_poa_stats;
 

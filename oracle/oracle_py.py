@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "libpoa_oracle.so")
 
 class Params(C.Structure):
     _fields_ = [("m", C.c_int8), ("n", C.c_int8), ("g", C.c_int8), ("e", C.c_int8),
-                ("q", C.c_int8), ("c", C.c_int8), ("mode", C.c_uint8)]
+                ("q", C.c_int8), ("c", C.c_int8), ("mode", C.c_uint8), ("banded", C.c_uint8)]
 
 
 def build(force=False):
@@ -48,6 +48,7 @@ def lib():
         L.poa_graph_nodes.argtypes = [vp, u8p, i32p, i32p]
         L.poa_graph_edges.argtypes = [vp, i32p, i32p, u32p]
         L.poa_graph_rows.argtypes = [vp, u8p, i32p, i32p, u8p, i32p]
+        L.poa_graph_row_hints.argtypes = [vp, i32p]
         L.poa_graph_seq_len.argtypes = [vp, C.c_int]
         L.poa_graph_seq_path.argtypes = [vp, C.c_int, i32p]
         L.poa_consensus.argtypes = [vp, i32p]
@@ -75,8 +76,8 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def mkparams(m=1, n=-4, g=-6, e=-2, q=-26, c=-1, mode=0):
-    return Params(m, n, g, e, q, c, mode)
+def mkparams(m=1, n=-4, g=-6, e=-2, q=-26, c=-1, mode=0, banded=0):
+    return Params(m, n, g, e, q, c, mode, banded)
 
 
 class Graph:
@@ -154,6 +155,11 @@ class Graph:
         lib().poa_graph_rows(self.h, _p(codes, C.c_uint8), _p(off, C.c_int32), _p(pred, C.c_int32),
                              _p(sink, C.c_uint8), _p(row_node, C.c_int32))
         return codes, off, pred[:off[n]].copy(), sink, row_node
+
+    def row_hints(self):
+        out = np.empty(max(self.n_nodes, 1), np.int32)
+        lib().poa_graph_row_hints(self.h, _p(out, C.c_int32))
+        return out[:self.n_nodes].copy()
 
     def seq_path(self, s):
         n = lib().poa_graph_seq_len(self.h, s)

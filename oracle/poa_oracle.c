@@ -46,6 +46,19 @@
  *     order.  new_rank(k-th new node) = slot_k + k.
  *  S8 consensus = heaviest bundle with branch completion; MSA column = aligned group in
  *     rank order.
+ *
+ * BANDED MODE (A11: the reference's abPOA path, src/smooth.cpp:133-627, always runs abPOA with its adaptive
+ * band wb=311, wf=0.03, :266-271; abPOA itself is absent).  By decree:
+ *  B1 w = wb + (int)(wf * L) columns on either side, as abPOA sizes its band.
+ *  B2 the band of a row is CENTRED ON THE BACKBONE COORDINATE x of its node and is a whole number of 11-column
+ *     strips: strips max(0, x - w) / 11 .. (x + w) / 11.  x is kept by AddAlignment: the first sequence's nodes
+ *     get their own column (i + 1); a new sibling takes the x of the node it is aligned to; a run of new
+ *     unaligned nodes continues from the previous aligned position (x + distance), else counts back from the
+ *     next one, else is its own column.  (abPOA moves its band with the best-scoring cells of the predecessor
+ *     rows; a band known before the row is computed is what lets the MI355X sweep slide a one-wave window
+ *     along the diagonal.)  The virtual source row is not banded.
+ *  B3 a cell outside its row's band does not exist: H and both outgoing gap candidates are -inf for every
+ *     reader, in-row gaps start at the band's first column.  Local mode only; cells = sum of band widths.
  */
 #include "poa_oracle.h"
 #include <stdlib.h>
@@ -68,6 +81,7 @@ struct poa_graph {
     int32_t *rank;   /* node -> rank */
     int32_t *order;  /* rank -> node */
     int32_t *leader; /* node -> first node of its aligned group */
+    int32_t *xpos;   /* node -> backbone coordinate (B2) */
     int32_t *gmem;   /* [leader*5 + code] -> node | -1 (valid at leader rows) */
     int32_t *in_head, *in_tail, *out_head, *out_tail, *in_deg, *out_deg;
     int n_edges, cap_edges;
@@ -92,7 +106,7 @@ poa_graph_t *poa_graph_new(void) {
 }
 void poa_graph_free(poa_graph_t *g) {
     if (!g) return;
-    free(g->code); free(g->rank); free(g->order); free(g->leader); free(g->gmem);
+    free(g->code); free(g->rank); free(g->order); free(g->leader); free(g->gmem); free(g->xpos);
     free(g->in_head); free(g->in_tail); free(g->out_head); free(g->out_tail);
     free(g->in_deg); free(g->out_deg);
     free(g->e_tail); free(g->e_head); free(g->e_next_in); free(g->e_next_out); free(g->e_w);
@@ -109,7 +123,7 @@ static void reserve_nodes(poa_graph_t *g, int n) {
     while (c < n) c *= 2;
     g->code = (uint8_t *)xrealloc(g->code, c);
 #define RS(f) g->f = (int32_t *)xrealloc(g->f, sizeof(int32_t) * (size_t)c)
-    RS(rank); RS(order); RS(leader); RS(in_head); RS(in_tail); RS(out_head); RS(out_tail);
+    RS(rank); RS(order); RS(leader); RS(xpos); RS(in_head); RS(in_tail); RS(out_head); RS(out_tail);
     RS(in_deg); RS(out_deg);
 #undef RS
     g->gmem = (int32_t *)xrealloc(g->gmem, sizeof(int32_t) * 5 * (size_t)c);
@@ -131,6 +145,7 @@ static int new_node(poa_graph_t *g, uint8_t code) {
     int v = g->n_nodes++;
     g->code[v] = code;
     g->rank[v] = -1;
+    g->xpos[v] = 0;
     g->leader[v] = v;
     for (int c = 0; c < 5; ++c) g->gmem[5 * v + c] = -1;
     g->gmem[5 * v + code] = v;
@@ -174,7 +189,7 @@ static norm_params_t normalise(const poa_params_t *p) {
  * malloc'ed ~25 MB per alignment: 256 threads then spend their time in mmap/munmap and page faults
  * (4.6 Mcells/s/thread against 70 single-threaded), which measured the allocator, not the DP.       */
 enum { WS_HM, WS_LAST, WS_FHEAD, WS_FNEXT, WS_SPARE, WS_TB, WS_MP, WS_TBX, WS_CODES, WS_SINK, WS_OFF, WS_PRED,
-       WS_ROWNODE, WS_NBUF };
+       WS_ROWNODE, WS_HINT, WS_NBUF };
 struct poa_ws {
     void *buf[WS_NBUF];
     size_t cap[WS_NBUF];
@@ -215,10 +230,11 @@ static int32_t *ws_new_row(poa_ws_t *w) {
     return r;
 }
 
+/* hint != NULL: banded mode (B1-B3), *band_cells receives the number of cells inside the bands */
 static int align_rows(poa_ws_t *ws, int N, const uint8_t *codes, const int32_t *off, const int32_t *pred,
                       const uint8_t *sink, const int32_t *row_node, const uint8_t *seq, int L,
                       const poa_params_t *pp, int32_t *out_node, int32_t *out_pos,
-                      int32_t *score) {
+                      int32_t *score, const int32_t *hint, uint64_t *band_cells) {
     poa_ws_t *own_ws = NULL;
     if (!ws) ws = own_ws = poa_ws_new();
     norm_params_t P = normalise(pp);
@@ -283,7 +299,20 @@ static int align_rows(poa_ws_t *ws, int N, const uint8_t *codes, const int32_t *
         uint16_t *tx = mp_index[i] >= 0 ? tbx + 3 * (size_t)mp_index[i] * W : NULL;
         const int code = codes[i - 1];
         int E = NEG, Q = NEG;
+        int beg = 0, end = L;
+        if (hint) {   /* B1, B2 */
+            const int w = POA_BAND_WB + (int)(POA_BAND_WF * L), x = hint[i - 1];
+            beg = ((x - w > 0 ? x - w : 0) / POA_BAND_STRIP) * POA_BAND_STRIP;
+            end = ((x + w) / POA_BAND_STRIP) * POA_BAND_STRIP + POA_BAND_STRIP - 1;
+            if (end > L) end = L;
+            if (band_cells && beg <= end) *band_cells += (uint64_t)(end - beg + 1);
+        }
         for (int j = 0; j <= L; ++j) {
+            if (j < beg || j > end) {   /* B3 */
+                H[j] = NEG; F[j] = NEG; O[j] = NEG; t[j] = 0; E = NEG; Q = NEG;
+                if (tx) { tx[3 * (size_t)j] = 0; tx[3 * (size_t)j + 1] = 0; tx[3 * (size_t)j + 2] = 0; }
+                continue;
+            }
             int f = 0, o = 0, d = NEG, fo = 0, oo = 0, dd = 0, fx = 0, ox = 0;
             for (int k = 0; k < np; ++k) {
                 const int32_t *Hp = Hm[pl[k]], *Fp = Hp + W, *Op = Fp + W;
@@ -370,7 +399,7 @@ int poa_align_csr(int N, const uint8_t *codes, const int32_t *off, const int32_t
                   int32_t *out_node, int32_t *out_pos, int32_t *score) {
     int32_t *row_node = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N ? N : 1));
     for (int i = 0; i < N; ++i) row_node[i] = i; /* report ranks */
-    int n = align_rows(NULL, N, codes, off, pred, sink, row_node, seq, L, p, out_node, out_pos, score);
+    int n = align_rows(NULL, N, codes, off, pred, sink, row_node, seq, L, p, out_node, out_pos, score, NULL, NULL);
     free(row_node);
     return n;
 }
@@ -403,11 +432,21 @@ int poa_align_ws(poa_ws_t *ws, const poa_graph_t *g, const uint8_t *seq, int len
     int32_t *row_node = (int32_t *)ws_get(ws, WS_ROWNODE, sizeof(int32_t) * (size_t)N);
     poa_graph_rows(g, codes, off, pred, sink, row_node);
     int n = -1;
-    if (ws->impl == POA_IMPL_AVX2) {   /* (-1: no AVX2 on this host, or the scores leave int16: scalar path) */
+    const int banded = p->banded && p->mode == POA_MODE_SW;
+    if (ws->impl == POA_IMPL_AVX2 && !banded) {   /* (-1: no AVX2 on this host, or the scores leave int16: scalar path) */
         if (!ws->simd) ws->simd = poa_simd_ws_new();
         n = poa_align_rows_simd(ws->simd, N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score);
     }
-    if (n < 0) n = align_rows(ws, N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score);
+    if (n < 0) {
+        int32_t *hint = NULL;
+        uint64_t bc = 0;
+        if (banded) {
+            hint = (int32_t *)ws_get(ws, WS_HINT, sizeof(int32_t) * (size_t)N);
+            poa_graph_row_hints(g, hint);
+        }
+        n = align_rows(ws, N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score, hint, &bc);
+        if (banded && cells) *cells = bc;
+    }
     poa_ws_free(own);
     return n;
 }
@@ -458,9 +497,18 @@ void poa_add_alignment(poa_graph_t *g, const int32_t *aln_node, const int32_t *a
                 v = new_node(g, c);
                 g->leader[v] = ld;
                 g->gmem[5 * ld + c] = v;
+                g->xpos[v] = g->xpos[a];
                 target[i] = v; kind[i] = 1;
             }
         } else { target[i] = new_node(g, c); kind[i] = 2; }
+    }
+    /* B2: backbone coordinates of the new unaligned nodes (aligned positions: posnode[.] >= 0, old nodes) */
+    for (int i = 0; i < len; ++i) {
+        if (kind[i] != 2) continue;
+        int p = i - 1, s2 = i + 1;
+        while (p >= 0 && kind[p] == 2) --p;
+        while (s2 < len && kind[s2] == 2) ++s2;
+        g->xpos[target[i]] = p >= 0 ? g->xpos[posnode[p]] + (i - p) : (s2 < len ? g->xpos[posnode[s2]] - (s2 - i) : i + 1);
     }
     /* S7 slots, in sequence order */
     {
@@ -520,6 +568,9 @@ void poa_graph_edges(const poa_graph_t *g, int32_t *tail, int32_t *head, uint32_
         if (head) head[e] = g->e_head[e];
         if (weight) weight[e] = g->e_w[e];
     }
+}
+void poa_graph_row_hints(const poa_graph_t *g, int32_t *hints) {
+    for (int r = 0; r < g->n_nodes; ++r) hints[r] = g->xpos[g->order[r]];
 }
 int poa_graph_seq_len(const poa_graph_t *g, int s) { return (int)(g->seq_off[s + 1] - g->seq_off[s]); }
 void poa_graph_seq_path(const poa_graph_t *g, int s, int32_t *nodes) {

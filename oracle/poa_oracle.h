@@ -38,7 +38,13 @@ typedef struct {
     int8_t m, n, g, e, q, c; /* spoa sign convention: m>0 match, n<=0 mismatch, gaps <=0
                                 (src/smooth.cpp:2098-2106 negates the CLI values)       */
     uint8_t mode;            /* POA_MODE_SW | POA_MODE_NW                               */
+    uint8_t banded;          /* 1 = abPOA-style band wb=311, wf=0.03 (src/smooth.cpp:266-271), decrees B1-B3 in
+                                poa_oracle.c; local mode only (ignored for POA_MODE_NW)                        */
 } poa_params_t;
+
+#define POA_BAND_WB 311
+#define POA_BAND_WF 0.03
+#define POA_BAND_STRIP 11 /* the band is a whole number of 11-column strips (decree B2) */
 
 typedef struct poa_graph poa_graph_t;
 
@@ -100,6 +106,8 @@ void poa_graph_edges(const poa_graph_t *g, int32_t *tail, int32_t *head, uint32_
  * sink[r] = 1 if the node has no out-edge.  pred needs room for num_edges + num_nodes. */
 void poa_graph_rows(const poa_graph_t *g, uint8_t *codes, int32_t *off, int32_t *pred,
                     uint8_t *sink, int32_t *row_node);
+/* backbone coordinate of the node at every rank (decree B2 / the HIP sweep's band hints) */
+void poa_graph_row_hints(const poa_graph_t *g, int32_t *hints);
 int poa_graph_seq_len(const poa_graph_t *g, int s);
 void poa_graph_seq_path(const poa_graph_t *g, int s, int32_t *nodes);
 

@@ -42,7 +42,8 @@ for l in body:
 by_depth = {}
 for b in blocks:
     by_depth.setdefault(b["depth"], []).append(b)
-row_depth = max(d for d, bs in by_depth.items() if sum(i.startswith("s_barrier") for b in bs for i in b["ins"]) >= 2)
+cands = [d for d, bs in by_depth.items() if sum(i.startswith("s_barrier") for b in bs for i in b["ins"]) >= 2]
+row_depth = max(cands) if cands else 1   # (the one-wave banded sweep has no barriers: its row loop is the outermost loop)
 tot = {"valu": 0, "salu": 0, "lds": 0, "vmem": 0, "scratch": 0}
 print("row loop depth", row_depth)
 for b in blocks:

@@ -1,0 +1,382 @@
+// poa_band16.hip.h -- BANDED packed-int16 sweep: the reference's abPOA path (A11, src/smooth.cpp:133-627,
+// band wb=311 / wf=0.03 at :266-271) re-designed for one wavefront.
+//
+// Semantics: decrees B1-B3 of oracle/poa_oracle.c.  The band of a row is a whole number of 11-column strips
+// centred on the backbone coordinate of its node -- known BEFORE the row is computed -- so the sweep does not
+// mask lanes of the 5632-column geometry of poa_dp16.hip.h: ONE wave owns a window of 128 strips (1408 columns,
+// lane t: strips origin+t and origin+64+t in the low / high halves of its registers) that follows the band
+// down the graph.  Consequences:
+//   * no barriers and no LDS exchange: the in-row gap scan is a DPP scan of one wave, the hand-over of the
+//     last column a wave_shr;
+//   * a band of ~925 columns (5 kbp) costs a quarter of the full row, and sixteen one-wave workgroups share a
+//     CU instead of four four-wave ones;
+//   * there is no row ring: every row writes its band to the plane (one dword per cell, slot = strip mod BS,
+//     the layout the traceback of poa_dp16.hip.h reads) and predecessor rows that are not in registers are
+//     fetched from there by ABSOLUTE strip, so a predecessor may have had any window origin;
+//   * the window moves rarely (its 128 strips hold a band of ~86 with slack on both sides): when the band
+//     would leave it, the origin is re-centred, the letters of the new strips are loaded and the previous row,
+//     if needed, is fetched from the plane like any stored row;
+//   * lanes outside the band compute values nobody reads; they are forced to -inf only where the band is about
+//     to change (their strips may enter the next row's band) and kept out of the gap scan, the hand-over, the
+//     end-cell search and the stores.
+// Local alignment only (decree B3); a global alignment asked to be banded runs the full sweep.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "poa_dp16.hip.h"
+
+namespace sxg {
+
+constexpr int BAND_WB = 311;        // abpt->wb, src/smooth.cpp:269
+constexpr double BAND_WF = 0.03;    // abpt->wf, src/smooth.cpp:271
+constexpr int BAND_W = 11;          // strip width = band granularity (decree B2; POA_BAND_STRIP of the oracle)
+constexpr int BAND_WIN = 128;       // strips of the window (two per lane)
+__host__ __device__ inline int band_half_width(int L) { return BAND_WB + (int)(BAND_WF * L); }
+// strips the plane keeps per row: the widest band of a block whose longest sequence has maxlen letters
+__host__ __device__ inline int band_plane_strips(int maxlen) { return 2 * band_half_width(maxlen) / BAND_W + 2; }
+__host__ __device__ constexpr int band_lds_bytes() { return LDS_CTL_BYTES + LDS_META_BYTES / 2 + 64 * BAND_W * 8; }
+
+constexpr unsigned NEGCELL = 0x0000C000u;   // plane cell of a cell that does not exist: H = NEGP, distances 0
+
+__device__ __forceinline__ void band_strips_of(const int hint, const int w, const int last_strip, int& bl, int& bh) {
+    bl = max(hint - w, 0) / BAND_W;
+    bh = min((hint + w) / BAND_W, last_strip);
+}
+
+template <bool CVX>
+__device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView R, const int N_, const uint8_t* seq, const int L_,
+                                               const DpBuffers B, char* smem, unsigned long long* cells_out) {
+    constexpr int W = BAND_W;
+    DpResult res;
+    const int N = __builtin_amdgcn_readfirstlane(N_), L = __builtin_amdgcn_readfirstlane(L_);
+    const int MB = LDS_META_BYTES / 2, CH = MB / 32;
+    const i32x4* lmeta = (const i32x4*)(smem + LDS_CTL_BYTES);
+    const int lane = threadIdx.x;
+    const int g = __builtin_amdgcn_readfirstlane(S.g), e = __builtin_amdgcn_readfirstlane(S.e);
+    const int q = __builtin_amdgcn_readfirstlane(S.q), c = __builtin_amdgcn_readfirstlane(S.c);
+    const int G2 = pk2(g, g), E2 = pk2(e, e), Q2 = pk2(q, q), C2 = pk2(c, c);
+    const int sm = __builtin_amdgcn_readfirstlane(S.m), sn = __builtin_amdgcn_readfirstlane(S.n);
+    const int MN2 = pk2(sn - sm, sn - sm), M2 = pk2(sm, sm), ONE2 = 0x00010001, NEG2 = pk2(NEGP, NEGP);
+    const int We = W * e, Wc = W * c;
+    const int BS = __builtin_amdgcn_readfirstlane(B.band_strips), bw = __builtin_amdgcn_readfirstlane(B.band_w);
+    const int last_strip = L / W;   // the strip that holds column L
+    SXG_GLOBAL uint32_t* const g_tb = sxg_uniform(sxg_global((uint32_t*)B.tb));
+    SXG_GLOBAL const int32_t* const g_meta = sxg_uniform(sxg_global((const int32_t*)R.meta));
+    SXG_GLOBAL const int32_t* const g_preds = sxg_uniform(sxg_global((const int32_t*)R.preds));
+    SXG_GLOBAL const int32_t* const g_hint = sxg_uniform(sxg_global((const int32_t*)R.tbx));
+    SXG_GLOBAL const uint8_t* const g_seq = sxg_global(seq);
+    const bool has_board = __builtin_amdgcn_readfirstlane((int)(B.prio_board != nullptr)) != 0;
+    const int prio_rank = __builtin_amdgcn_readfirstlane(B.prio_rank);
+    constexpr int NL = (W + 1) / 2;
+    typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+
+    int s0 = -1000000;          // window origin (strip); far away: the first row re-centres
+    unsigned let[NL];           // letters of my two strips, one byte per (strip, column): (lo_k, hi_k, lo_k+1, hi_k+1)
+    unsigned so_lo = 0, so_hi = 0;   // byte offsets of my strips' slots in a plane row
+    int Hp[W], Fp[W], Op[W], Hleft = NEG2;
+#pragma unroll
+    for (int k = 0; k < W; ++k) { Hp[k] = NEG2; Fp[k] = NEG2; Op[k] = NEG2; }
+    int pbl = 0, pbh = -1;      // band strips of the row held in Hp/Fp/Op (row i-1); empty: nothing valid in registers
+    bool regs_ok = false;       // Hp/Fp/Op hold row i-1 aligned to the current window
+    bool next_sib = false;
+    int best_lo = 0, best_hi = 0, bi_lo = -1, bi_hi = -1, bj_lo = 0, bj_hi = 0;   // (bj: ABSOLUTE column -- the window moves)
+    unsigned long long cells = 0;
+
+    for (int i = 1; i <= N; ++i) {
+        if (has_board) { if ((i & 127) == 1) sxg_balance_prio(B, (unsigned long long)i * (unsigned long long)(2 * bw)); }
+        else if ((i & 63) == 1) sxg_rotate_prio(prio_rank);
+        const int r = i - 1;
+        if ((r & (CH - 1)) == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            SXG_GLOBAL const i32x4* gm = (SXG_GLOBAL const i32x4*)(g_meta + 8 * (size_t)r);
+            i32x4* lm = (i32x4*)(smem + LDS_CTL_BYTES);
+            const int nrow = min(CH, N - r);
+            for (int x = lane; x < 2 * nrow; x += 64) lm[x] = gm[x];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const i32x4 m0 = lmeta[2 * (r & (CH - 1))], m1 = lmeta[2 * (r & (CH - 1)) + 1];
+        const int pb = __builtin_amdgcn_readfirstlane(m0.x);
+        const int info = __builtin_amdgcn_readfirstlane(m0.y);
+        const int p0 = __builtin_amdgcn_readfirstlane(m0.z);
+        const int h0 = __builtin_amdgcn_readfirstlane(m0.w);    // hint of predecessor #0
+        const int p1 = __builtin_amdgcn_readfirstlane(m1.x);
+        const int h1 = __builtin_amdgcn_readfirstlane(m1.y);    // hint of predecessor #1
+        const int hint = __builtin_amdgcn_readfirstlane(m1.w);
+        const int np = info & 0xffff, code = (info >> 16) & 0xff;
+        const unsigned CODE4 = (unsigned)code * 0x01010101u;
+
+        int bl, bh;
+        band_strips_of(hint, bw, last_strip, bl, bh);
+        if (bh >= bl) cells += (unsigned long long)(min(L, bh * W + W - 1) - bl * W + 1);
+        if (bh >= bl && (bl < s0 || bh >= s0 + BAND_WIN)) {
+            // re-centre the window on this band; registers of the previous row no longer line up with it
+            s0 = max(0, bl - (BAND_WIN - (bh - bl + 1)) / 2);
+            regs_ok = false;
+#pragma unroll
+            for (int k2 = 0; k2 < NL; ++k2) {
+                unsigned v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int kc = 2 * k2 + (b >> 1);
+                    const int j = (s0 + lane + (b & 1 ? 64 : 0)) * W + kc;
+                    const unsigned ch = (kc < W && j >= 1 && j <= L) ? (unsigned)g_seq[j - 1] : 15u;
+                    v |= (ch > 4u && ch != 15u ? 4u : ch) << (8 * b);
+                }
+                let[k2] = v;
+            }
+            so_lo = (unsigned)((s0 + lane) % BS) << 2;
+            so_hi = (unsigned)((s0 + 64 + lane) % BS) << 2;
+        }
+        const int st_lo = s0 + lane, st_hi = s0 + 64 + lane;   // my strips
+        const bool in_lo = st_lo >= bl && st_lo <= bh, in_hi = st_hi >= bl && st_hi <= bh;
+        const int m2 = (in_lo ? 0x0000ffff : 0) | (in_hi ? (int)0xffff0000 : 0);
+
+// cells (packed words as in the ring of poa_dp16.hip.h) of predecessor row p_ (band hint hp_) for my strips, and the
+// column left of them; cells outside that row's band do not exist (NEGCELL); row 0 is not stored: local mode, H = 0
+#define BAND_FETCH(p_, hp_, wr_, hl_)                                                                       \
+    do {                                                                                                    \
+        if ((p_) == 0) {                                                                                    \
+            const int z_ = pk2(st_lo * W <= L ? 0 : NEGP, st_hi * W <= L ? 0 : NEGP);                        \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = p16_pack_row<CVX>(z_, pk_add(z_, G2), CVX ? pk_add(z_, Q2) : NEG2); \
+            hl_ = pk2(st_lo == 0 ? NEGP : 0, 0);                                                            \
+        } else {                                                                                            \
+            int fl_, fh_;                                                                                   \
+            band_strips_of(hp_, bw, last_strip, fl_, fh_);                                                  \
+            const __amdgpu_buffer_rsrc_t rs_ = p16_rsrc((const void*)(g_tb + (size_t)(p_) * (size_t)(W * BS)), W * BS * 4); \
+            const bool a_ = st_lo >= fl_ && st_lo <= fh_, b_ = st_hi >= fl_ && st_hi <= fh_;                 \
+            const bool la_ = st_lo - 1 >= fl_ && st_lo - 1 <= fh_, lb_ = st_hi - 1 >= fl_ && st_hi - 1 <= fh_; \
+            unsigned cl_[W], chh_[W];                                                                       \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
+                cl_[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_, so_lo, k * BS * 4, 0);                   \
+                chh_[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_, so_hi, k * BS * 4, 0);                  \
+            }                                                                                               \
+            const unsigned ll_ = __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)((st_lo + BS - 1) % BS) << 2, (W - 1) * BS * 4, 0); \
+            const unsigned lh_ = __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)((st_hi + BS - 1) % BS) << 2, (W - 1) * BS * 4, 0); \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
+                const unsigned x_ = a_ ? cl_[k] : NEGCELL, y_ = b_ ? chh_[k] : NEGCELL;                     \
+                wr_[k] = u32x2{__builtin_amdgcn_perm(y_, x_, 0x05040100u), __builtin_amdgcn_perm(y_, x_, 0x07060302u)}; \
+            }                                                                                               \
+            hl_ = (int)__builtin_amdgcn_perm(lb_ ? lh_ : NEGCELL, la_ ? ll_ : NEGCELL, 0x05040100u);        \
+        }                                                                                                   \
+    } while (0)
+#define BAND_LROW(ptr_)                                                                                     \
+    int tp_ = lane;                                                                                         \
+    asm volatile("" : "+v"(tp_));                                                                           \
+    lds_u32x2* const ptr_ = (lds_u32x2*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() +            \
+                                                 (unsigned)(LDS_CTL_BYTES + MB) + (unsigned)(tp_ * W) * 8u)
+
+        int Hc[W];
+        const bool sib = next_sib && regs_ok;
+        if (np <= 1 && p0 == i - 1 && regs_ok) {
+            // register predecessor: its outgoing candidates ARE this row's F and O
+#pragma unroll
+            for (int k = 0; k < W; ++k) Hc[k] = k ? Hp[k - 1] : Hleft;
+        } else if (sib) {
+            u32x2 wr[W];
+            int hl;
+            BAND_FETCH(p0, h0, wr, hl);
+            Hc[0] = hl;
+#pragma unroll
+            for (int k = 1; k < W; ++k) Hc[k] = (int)wr[k - 1].x;
+        } else {
+            // general case: maxima over all predecessors; the register row (if it lines up) is folded from LDS
+            BAND_LROW(lrow_t);
+            const bool park = regs_ok && np >= 2 && (p0 == i - 1 || p1 == i - 1 || np >= 3);
+            if (park) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) lrow_t[k] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
+            }
+            const int hleft_reg = Hleft;
+            for (int x = 0; x < max(np, 1); ++x) {
+                int p, hp;
+                if (x == 0) { p = p0; hp = h0; }
+                else if (x == 1) { p = p1; hp = h1; }
+                else {
+                    p = __builtin_amdgcn_readfirstlane(g_preds[pb + x]);
+                    hp = p >= 1 ? __builtin_amdgcn_readfirstlane(g_hint[p - 1]) : 0;
+                }
+                u32x2 wr[W];
+                int hl;
+                if (p == i - 1 && park) {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];
+                    hl = hleft_reg;
+                } else BAND_FETCH(p, hp, wr, hl);
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    int hs, fs, os;
+                    p16_unpack_row(wr[k], hs, fs, os);
+                    if (x == 0) { Fp[k] = fs; Op[k] = os; Hc[k] = hl; }
+                    else { Fp[k] = pk_max(Fp[k], fs); if (CVX) Op[k] = pk_max(Op[k], os); Hc[k] = pk_max(Hc[k], hl); }
+                    hl = hs;
+                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));
+                }
+            }
+        }
+#undef BAND_FETCH
+#undef BAND_LROW
+        if (!CVX) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) Op[k] = NEG2;
+        }
+
+        // ---- pass 1: H before the in-row gaps, strip-local carries
+        int a = NEG2, b = NEG2;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const unsigned x4 = let[k >> 1] ^ CODE4;
+            const int lp = (int)__builtin_amdgcn_perm(0u, x4, (k & 1) ? 0x0c030c02u : 0x0c010c00u);
+            int nm;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(nm) : "v"(lp), "v"(ONE2));
+            int h = pk_mad(nm, MN2, pk_add(Hc[k], M2));
+            h = pk_max(h, Fp[k]);
+            if (CVX) h = pk_max(h, Op[k]);
+            Hc[k] = h;
+            a = pk_max(pk_add(a, E2), h);
+            if (CVX) b = pk_max(pk_add(b, C2), h);
+            SXG_PIN("+v"(Hc[k]), "+v"(a), "+v"(b));
+        }
+        a = pk_max(a, 0); if (CVX) b = pk_max(b, 0);
+        a = pk_add(a, G2);
+        if (CVX) b = pk_add(b, Q2);
+        // ---- carries: strips outside the band contribute nothing; lo strips precede hi strips
+        const int tWe = lane * We, tWc = lane * Wc;
+        int ya_lo = in_lo ? pk_lo(a) - tWe : NEG * 2, ya_hi = in_hi ? pk_hi(a) - tWe - 64 * We : NEG * 2;
+        int yb_lo = CVX && in_lo ? pk_lo(b) - tWc : NEG * 2, yb_hi = CVX && in_hi ? pk_hi(b) - tWc - 64 * Wc : NEG * 2;
+        ya_lo = sxg_wave_incl_max(ya_lo); ya_hi = sxg_wave_incl_max(ya_hi);
+        if (CVX) { yb_lo = sxg_wave_incl_max(yb_lo); yb_hi = sxg_wave_incl_max(yb_hi); }
+        {
+            const int lo_a = __builtin_amdgcn_readlane(ya_lo, 63), lo_b = __builtin_amdgcn_readlane(yb_lo, 63);
+            ya_hi = max(ya_hi, lo_a); yb_hi = max(yb_hi, lo_b);
+            ya_lo = sxg_wave_shr1(ya_lo, NEG * 2); ya_hi = sxg_wave_shr1(ya_hi, lo_a);
+            yb_lo = sxg_wave_shr1(yb_lo, NEG * 2); yb_hi = sxg_wave_shr1(yb_hi, lo_b);
+        }
+        const int Ein_lo = max(ya_lo + tWe - We, NEGP);
+        const int Ein_hi = max(ya_hi + tWe + 63 * We, NEGP);
+        const int Qin_lo = !CVX ? NEGP : max(yb_lo + tWc - Wc, NEGP);
+        const int Qin_hi = !CVX ? NEGP : max(yb_hi + tWc + 63 * Wc, NEGP);
+        int E = pk2(Ein_lo, Ein_hi), Q = pk2(Qin_lo, Qin_hi);
+
+        // ---- pass 2: final H
+        int rowmax = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            int h = pk_max(Hc[k], E);
+            if (CVX) h = pk_max(h, Q);
+            h = pk_max(h, 0);
+            Hc[k] = h;
+            rowmax = pk_max(rowmax, h);
+            E = pk_max(pk_add(h, G2), pk_add(E, E2));
+            if (CVX) Q = pk_max(pk_add(h, Q2), pk_add(Q, C2));
+            SXG_PIN("+v"(Hc[k]), "+v"(E), "+v"(Q), "+v"(rowmax));
+        }
+        // the column left of my strips in THIS row (the next row's diagonal): my left neighbour's last column, the
+        // lo half's last lane feeds lane 0's hi strip; a strip outside the band hands over -inf
+        int lh;
+        {
+            const int mine = (Hc[W - 1] & m2) | (NEG2 & ~m2);
+            lh = sxg_wave_shr1(mine, 0);
+            const int l63 = __builtin_amdgcn_readlane(mine, 63);
+            if (lane == 0) lh = pk2(NEGP, pk_lo(l63));
+        }
+
+        // ---- end cell (local): only cells of the band count
+        rowmax &= m2;
+        {
+            const bool il = pk_lo(rowmax) > best_lo, ih = pk_hi(rowmax) > best_hi;
+            if (__any(il || ih)) {
+                if (il) { best_lo = pk_lo(rowmax); bi_lo = i; }
+                if (ih) { best_hi = pk_hi(rowmax); bi_hi = i; }
+                int bk_lo = 0, bk_hi = 0;
+#pragma unroll
+                for (int k = W - 1; k >= 0; --k) {
+                    if (il && pk_lo(Hc[k]) == best_lo) bk_lo = k;
+                    if (ih && pk_hi(Hc[k]) == best_hi) bk_hi = k;
+                }
+                if (il) bj_lo = st_lo * W + bk_lo;
+                if (ih) bj_hi = st_hi * W + bk_hi;
+            }
+        }
+        // ---- outgoing candidates, band store.  A sibling successor keeps my own F/O instead.
+        next_sib = false;
+        int nbl = -1, nbh = -2;    // the next row's band (unknown at a descriptor-chunk edge)
+        if (i < N && (i & (CH - 1)) != 0) {
+            const i32x4 n0 = lmeta[2 * (i & (CH - 1))], n1 = lmeta[2 * (i & (CH - 1)) + 1];
+            const int nnp = __builtin_amdgcn_readfirstlane(n0.y) & 0xffff, np0 = __builtin_amdgcn_readfirstlane(n0.z);
+            next_sib = np <= 1 && nnp <= 1 && np0 == p0 && np0 != i;
+            band_strips_of(__builtin_amdgcn_readfirstlane(n1.w), bw, last_strip, nbl, nbh);
+        }
+        const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
+#define BAND_STORE(CF, CO)                                                                                  \
+    do {                                                                                                    \
+        if (in_lo) {                                                                                        \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
+                const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                           \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), rs_plane, so_lo, k * BS * 4, 0); \
+            }                                                                                               \
+        }                                                                                                   \
+        if (in_hi) {                                                                                        \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
+                const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                           \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), rs_plane, so_hi, k * BS * 4, 0); \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+        if (!next_sib) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                Fp[k] = pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2));
+                if (CVX) Op[k] = pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2));
+                SXG_PIN("+v"(Fp[k]), "+v"(Op[k]));
+            }
+            BAND_STORE(Fp[k], Op[k]);
+        } else {
+            BAND_STORE(pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2)), (CVX ? pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2)) : NEG2));
+        }
+#undef BAND_STORE
+        // what the next row takes from registers must not exist outside this row's band: forced to -inf only when
+        // the band is about to change (or the next band is unknown) -- otherwise those lanes are never read
+        if (nbl != bl || nbh != bh) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                Hc[k] = (Hc[k] & m2) | (NEG2 & ~m2);
+                Fp[k] = (Fp[k] & m2) | (NEG2 & ~m2);
+                if (CVX) Op[k] = (Op[k] & m2) | (NEG2 & ~m2);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) Hp[k] = Hc[k];
+        Hleft = lh;
+        pbl = bl; pbh = bh;
+        regs_ok = true;
+    }
+    (void)pbl; (void)pbh;
+    if (lane == 0 && cells_out) *cells_out = cells;
+
+    // ---- end cell: greatest score, then smallest row, then smallest column (two candidates per lane)
+    unsigned long long key = 0;
+    if (bi_lo >= 0)
+        key = ((unsigned long long)(unsigned)(best_lo + (1 << 27)) << 35) |
+              ((unsigned long long)(0xFFFFFu - (unsigned)bi_lo) << 15) | (unsigned long long)(0x7FFFu - (unsigned)bj_lo);
+    if (bi_hi >= 0) {
+        const unsigned long long k2 = ((unsigned long long)(unsigned)(best_hi + (1 << 27)) << 35) |
+                                      ((unsigned long long)(0xFFFFFu - (unsigned)bi_hi) << 15) | (unsigned long long)(0x7FFFu - (unsigned)bj_hi);
+        key = k2 > key ? k2 : key;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(key, d);
+        key = o > key ? o : key;
+    }
+    if (key == 0) { res.best = 0; res.bi = -1; res.bj = -1; }
+    else {
+        res.best = (int)(unsigned)(key >> 35) - (1 << 27);
+        res.bi = (int)(0xFFFFFu - (unsigned)((key >> 15) & 0xFFFFFu));
+        res.bj = (int)(0x7FFFu - (unsigned)(key & 0x7FFFu));
+    }
+    return res;
+}
+
+}  // namespace sxg

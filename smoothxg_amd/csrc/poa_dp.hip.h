@@ -158,6 +158,7 @@ struct DpBuffers {
     void* row0;        // [Lpad] packed virtual source row
     void* park;        // [Lpad] parked previous row when it cannot live in LDS
     int band_strips;   // packed sweep: strips per row kept in the traceback plane (see poa_dp16.hip.h)
+    int band_w;        // banded sweep (poa_band16.hip.h): half-width of the band in columns, wb + (int)(wf * L)
     int prio_rank;     // launch rank of this workgroup among its CU's co-residents (see sxg_rotate_prio)
     uint32_t* prio_board;          // this CU's progress board (PRIO_BOARD_SLOTS words) or nullptr
     unsigned long long prio_rem0;  // estimated cells this workgroup still has to do, at row 0 of this sweep

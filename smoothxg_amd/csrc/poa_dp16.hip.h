@@ -572,7 +572,9 @@ static_assert((TBW_ROWS * TBW_STRIDE + TBW_LET) * 4 <= LDS_META_BYTES / 2, "trac
 // words of LDS (control area) through which the walk reports a band miss to the workgroup
 enum : int { TBM_FLAG = 208, TBM_ROW = 209, TBM_DELTA = 210 };
 
-template <bool PAIRS, int W, bool CVX>
+// BANDED (poa_band16.hip.h): a row keeps exactly the strips of its band, max(0, hint - w) / W .. (hint + w) / W, and a
+// cell outside the band does not exist (it reads as -inf and is never a miss).
+template <bool PAIRS, int W, bool CVX, bool BANDED = false>
 // (views by value: a reference to the kernel's private copy trips an AMDGPU back-end assertion on
 // the private-aperture null check for some strip widths)
 __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const Scoring S_, const uint8_t* seq, const int L_,
@@ -591,6 +593,12 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     const int q = __builtin_amdgcn_readfirstlane(S_.q), c = __builtin_amdgcn_readfirstlane(S_.c);
     const int sw = __builtin_amdgcn_readfirstlane(S_.sw);
     const int BS = __builtin_amdgcn_readfirstlane(B.band_strips);
+    const int bw = __builtin_amdgcn_readfirstlane(B.band_w), last_strip = L / W;
+    // is strip s of a row with band hint `hint` kept in the plane?
+    auto kept = [&](int hint, int s) -> bool {
+        if (BANDED) return s >= max(hint - bw, 0) / W && s <= min((hint + bw) / W, last_strip);
+        return (unsigned)(s - band_first_strip(hint, W, BS, T)) < (unsigned)BS;
+    };
     // outputs and letters through global pointers: a FLAT store also counts on lgkmcnt, and the walk
     // waits on lgkmcnt for its LDS reads every step -- i.e. it would wait for the previous step's store to
     // reach HBM
@@ -624,8 +632,9 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     // plane cell (row p >= 1, column col) straight from HBM; a cell outside the row's band is a miss
     auto gcell = [&](int p, int col) -> uint32_t {
         const int hint = (int)TBU(g_meta[8 * (size_t)(p - 1) + 7]);
-        const int s = col / W, k = col - s * W, sb = s - band_first_strip(hint, W, BS, T);
-        if ((unsigned)sb >= (unsigned)BS) {
+        const int s = col / W, k = col - s * W;
+        if (!kept(hint, s)) {
+            if (BANDED) return 0x0000C000u;   // (NEGCELL: H = -inf)
             if (!miss) { miss = true; miss_row = p; miss_delta = col - hint; }
             return 0u;
         }
@@ -682,11 +691,13 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                         const int s = col / W, k = col - s * W;
                         v[x2] = g_plane[((size_t)row * W + k) * BS + s % BS];
                     }
-                    const int bs0 = band_first_strip(d1.w, W, BS, T);
 #pragma unroll
                     for (int x2 = 0; x2 < TBW_COLS; ++x2) {
                         const int col = c0 + x2;
-                        if (col >= 0 && col <= L && (unsigned)(col / W - bs0) < (unsigned)BS) valid |= 1u << x2;
+                        if (col >= 0 && col <= L) {
+                            if (kept(d1.w, col / W)) valid |= 1u << x2;
+                            else if (BANDED) { v[x2] = 0x0000C000u; valid |= 1u << x2; }
+                        }
                     }
                     uint32_t* en = win + lane * TBW_STRIDE;
 #pragma unroll
@@ -756,7 +767,6 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                 // a gap in the graph.  E: smallest k with H[i][j-k] + g + (k-1) e == hv (k <= kmax_e), else Q
                 // likewise with q, c; 64 columns per round trip, straight from the plane.
                 const int hint = (int)TBU(g_meta[8 * (size_t)(i - 1) + 7]);
-                const int bs0 = band_first_strip(hint, W, BS, T);
                 int kk = 0, hnew = 0;
                 for (int piece = 0; piece < (CVX ? 2 : 1) && !kk && !miss; ++piece) {
                     const int go = piece ? q : g, ge = piece ? c : e;
@@ -765,12 +775,12 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                         const int x = base + lane + 1;
                         const bool act = x <= kcap;
                         const int col = j - x;
-                        const int s = col / W, k = col - s * W, sb = s - bs0;
-                        const bool inb = (unsigned)sb < (unsigned)BS;
+                        const int s = col / W, k = col - s * W;
+                        const bool inb = act && kept(hint, s);
                         int hval = 0;
                         if (act && inb) hval = sext(g_plane[((size_t)i * W + k) * BS + s % BS]);
                         const unsigned long long meq = __ballot(act && inb && hval + go + (x - 1) * ge == hv);
-                        const unsigned long long moob = __ballot(act && !inb);
+                        const unsigned long long moob = BANDED ? 0ull : __ballot(act && !inb);
                         const int feq = meq ? (int)__builtin_ctzll(meq) : 64, foob = moob ? (int)__builtin_ctzll(moob) : 64;
                         if (foob < feq) { miss = true; miss_row = i; miss_delta = (j - (base + foob + 1)) - hint; }
                         else if (meq) { kk = base + feq + 1; hnew = __builtin_amdgcn_readlane(hval, feq); }

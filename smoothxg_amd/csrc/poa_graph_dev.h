@@ -208,9 +208,11 @@ struct RowCaps {
 // stand-alone align kernel (caller CSR -> rows).  On entry R.flags holds STORE/SINK bits and
 // R.slot[r] the rank of the last reader of row r.  Assigns ring slots of the row pool and
 // the step-mask plane offset of multi-pred rows.  Returns a status (same on every thread).
-// `hinted`: packed sweep -- R.tbx already holds the band hint of every row and there is no step-mask plane.
+// `hinted`: 1 = packed sweep -- R.tbx already holds the band hint of every row and there is no step-mask plane;
+// 2 = banded sweep -- additionally there is no row ring (every row keeps its band in the plane) and the descriptor
+// carries the hints of the first two predecessors where the ring slots would be.
 template <class Ctx>
-SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps, const bool hinted = false) {
+SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps, const int hinted = 0) {
     const int T = c.nthreads(), t = c.tid();
     c.sync();
     const int n_store = array_excl_sum(c, N, [&](int r) { return (R.flags[r] & ROW_STORE) ? 1 : 0; }, R.sseq);
@@ -225,7 +227,7 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
         R.slot[r] = R.sseq[r] % caps.pool_slots;
     }
     worst = c.reduce_max(worst);
-    if (worst > caps.pool_slots) return ST_POOL_OVERFLOW;
+    if (worst > caps.pool_slots && hinted != 2) return ST_POOL_OVERFLOW;
     if (!hinted) {
         // multi-pred rows: np-1 fold steps each in the step-mask plane
         const int n_steps = array_excl_sum(c, N, [&](int r) {
@@ -246,6 +248,7 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
         m.s0 = (m.p0 >= 1 && m.p0 != r) ? R.slot[m.p0 - 1] : -1;
         m.p1 = np >= 2 ? R.preds[pb + 1] : 0;
         m.s1 = (m.p1 >= 1 && m.p1 != r) ? R.slot[m.p1 - 1] : -1;
+        if (hinted == 2) { m.s0 = m.p0 >= 1 ? R.tbx[m.p0 - 1] : 0; m.s1 = m.p1 >= 1 ? R.tbx[m.p1 - 1] : 0; }
         m.slot = R.slot[r];
         m.tbx = R.tbx[r];
         int32_t* d = R.meta + 8 * (size_t)r;
@@ -258,7 +261,7 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
 // Rank-space CSR + per-row DP metadata of the current graph.  Returns a status code
 // (identical on every thread).
 template <class Ctx>
-SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const RowCaps& caps, const bool hinted = false) {
+SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const RowCaps& caps, const int hinted = 0) {
     const int T = c.nthreads(), t = c.tid();
     c.sync();
     const int N = *G.n_nodes;

@@ -17,6 +17,7 @@
 #include "../../include/sxg_poa.h"
 #include "poa_dp.hip.h"
 #include "poa_dp16.hip.h"
+#include "poa_band16.hip.h"
 #include "poa_graph_dev.h"
 
 using namespace sxg;
@@ -150,7 +151,8 @@ struct BlockArgs {
 // register allocator must leave room for: 8 columns/lane need ~100 VGPRs (4 waves), 16 need
 // ~165 (3 waves); a 1024-thread workgroup is 4 waves per SIMD by itself.
 // RM = row mode: 0 = 32-bit sweep with int16 row words, 1 = 32-bit sweep with int32 row words,
-// 2 = packed-int16 sweep (poa_dp16.hip.h; two strips per lane, W <= 12).
+// 2 = packed-int16 sweep (poa_dp16.hip.h; two strips per lane, W <= 12),
+// 3 = banded packed sweep (poa_band16.hip.h; one wave, a sliding window of 128 strips of 11 columns).
 __host__ __device__ constexpr int sxg_min_waves(int TMAX, int W, int RM) {
 #ifdef SXG_DEV_WAVES
     return SXG_DEV_WAVES;
@@ -161,7 +163,7 @@ __host__ __device__ constexpr int sxg_min_waves(int TMAX, int W, int RM) {
 template <int TMAX, int W, bool CVX, int RM, bool SW>
 __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_kernel(const BlockArgs A) {
     constexpr bool H16 = RM != 1;
-    constexpr int CPL = RM == 2 ? 2 * W : W;  // columns per lane
+    constexpr int CPL = RM >= 2 ? 2 * W : W;  // columns per lane
     const int T = (int)blockDim.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lds = (int*)smem;
@@ -207,21 +209,36 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             __syncthreads();
             const int N = *V.G.n_nodes;
             int score = 0;
-            if (len + 1 > T * CPL) { status = ST_TOO_LONG; break; }
+            if (RM != 3 && len + 1 > T * CPL) { status = ST_TOO_LONG; break; }
             if (N + len > A.lay.nodes_cap) { status = ST_NODES_OVERFLOW; break; }
             if (RM != 1 && !S.sw &&
-                -(sxg_gap_cost(S.g, S.e, S.q, S.c, N) + sxg_gap_cost(S.g, S.e, S.q, S.c, len)) >= (RM == 2 ? 15800 : 30000)) {
+                -(sxg_gap_cost(S.g, S.e, S.q, S.c, N) + sxg_gap_cost(S.g, S.e, S.q, S.c, len)) >= (RM >= 2 ? 15800 : 30000)) {
                 status = ST_RANGE_OVERFLOW;
                 break;
             }
             if (N > 0 && len > 0) {
                 PROF(0);
-                status = prep_rows(ctx, V.G, V.R, caps, RM == 2);
+                status = prep_rows(ctx, V.G, V.R, caps, RM == 3 ? 2 : (RM == 2 ? 1 : 0));
                 if (status != ST_OK) break;
                 PROF(1);
                 DpResult res;
                 V.B.prio_rem0 = est_total > done_cells ? est_total - done_cells : 0ull;
-                if constexpr (RM == 2) {
+                if constexpr (RM == 3) {
+                    // banded sweep (decrees B1-B3): one wave, the band slides with the rows; out-of-band cells do not
+                    // exist, so the traceback cannot leave the kept cells
+                    V.B.band_w = band_half_width(len);
+                    res = dp_fill_band16<CVX>(S, V.R, N, seq, len, V.B, smem, A.cells + s);
+                    __syncthreads();
+                    PROF(2);
+                    if (t == 0) lds[TBM_FLAG] = 0;
+                    __syncthreads();
+                    if (res.bi >= 0)
+                        traceback_p16<false, W, CVX, true>(V.R, V.B, S, seq, len, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj,
+                                                           V.G.posnode, nullptr, nullptr, smem);
+                    __syncthreads();
+                    PROF(3);
+                    if (lds[TBM_FLAG]) { status = ST_BAND_MISS; break; }
+                } else if constexpr (RM == 2) {
                     // The traceback derives the alignment from the band of cells the sweep kept around every
                     // row's hint.  If the walk needs a cell outside (a structural variant moved the alignment
                     // more than half a band away from the backbone coordinates), the hints of the rows not yet
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                 }
                 score = res.bi >= 0 ? res.best : 0;
             }
-            if (t == 0) { A.score[s] = score; A.cells[s] = (unsigned long long)N * (unsigned long long)len; }
+            if (t == 0) { A.score[s] = score; if (RM != 3 || N == 0 || len == 0) A.cells[s] = RM == 3 ? 0ull : (unsigned long long)N * (unsigned long long)len; }
             done_cells += (unsigned long long)N * (unsigned long long)len;
             add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
             PROF(4);
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
                         atomicMax(&V.R.slot[pr - 1], r);
                     }
                 }
-            status = finish_rows(ctx, N, V.R, caps, RM == 2);
+            status = finish_rows(ctx, N, V.R, caps, RM == 2 ? 1 : 0);
             if (status == ST_OK) {
                 DpResult res;
                 if constexpr (RM == 2) res = dp_fill_p16<W, CVX, SW>(S, V.R, N, A.bases + so, len, V.B, smem);
@@ -411,7 +428,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct Variant {
     int W, NW, TMAX, RM;
     int T() const { return 64 * NW; }
-    int Lpad() const { return 64 * NW * W * (RM == 2 ? 2 : 1); }
+    int Lpad() const { return 64 * NW * W * (RM >= 2 ? 2 : 1); }
 };
 
 // Geometry choice.  Inside a workgroup all waves meet at two barriers per row, so the wave
@@ -463,6 +480,7 @@ template <int TMAX, int W, int RM> static KernelFn<AlignArgs> pick_align(bool cv
     do { if (v.TMAX == TM && v.W == Wd && v.RM == 2) return FN<TM, Wd, 2>(cvx, sw); } while (0)
 // SXG_DEV_ONLY_W=<w>: development builds instantiate a single packed class (seconds instead of minutes)
 static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
+    if (v.RM == 3) return cvx ? poa_block_kernel<64, 11, true, 3, true> : poa_block_kernel<64, 11, false, 3, true>;
 #ifdef SXG_DEV_ONLY_W
     SXG_PICK16(pick_block, SXG_DEV_ONLY_TMAX, SXG_DEV_ONLY_W);
 #else
@@ -679,7 +697,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     const int np = in->per_block_params ? nb : 1;
     for (int k = 0; k < np && nb > 0; ++k) {
         const sxg_poa_params& p = in->params[k];
-        if (p.m < 0 || p.n > 0 || p.g > 0 || p.e > 0 || p.q > 0 || p.c > 0 || p.mode > 1)
+        if (p.m < 0 || p.n > 0 || p.g > 0 || p.e > 0 || p.q > 0 || p.c > 0 || p.mode > 1 || p.banded > 1)
             return fail(SXG_E_INVALID, "scores must follow spoa's sign convention (m>=0, others <=0), mode 0|1");
     }
     h->n_blocks = nb; h->n_seqs = ns; h->n_bases = nbases;
@@ -706,6 +724,13 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
         }
         m.rm = row_mode(m.S, m.maxlen, m.maxlen);  // optimistic; the kernel re-checks (see score_floor)
         m.fits = variant_for_len(m.maxlen, m.rm, &m.variant);
+        // A11: the reference's abPOA path is banded (wb=311, wf=0.03); local alignments whose scores fit the packed
+        // sweep run the one-wave banded kernel, everything else asked to be banded runs the full matrix
+        if (h->h_params[in->per_block_params ? b : 0].banded && m.S.sw && m.rm == 2 && m.maxlen <= SXG_POA_MAX_SEQ_LEN) {
+            m.rm = 3;
+            m.variant = Variant{BAND_W, 1, 64, 3};
+            m.fits = true;
+        }
     }
     // letters > 4 are read as N: only a batch that holds one is copied to a staging buffer and fixed there
     // (the unconditional copy was 0.15 s of host time per 320 MB batch)
@@ -790,12 +815,15 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     }
     if (rows_cap >= (1 << 20)) rows_cap = (1 << 20) - 1;
     const int wb = V.RM == 1 ? 8 : 4;
-    P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false, V.RM == 2 ? p16_band_strips(V.T(), V.W) : 0);
+    if (V.RM == 3) pool_slots = 1;   // (the banded sweep has no row ring: predecessors come from the plane)
+    P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false,
+                        V.RM == 3 ? band_plane_strips(maxlen) : (V.RM == 2 ? p16_band_strips(V.T(), V.W) : 0));
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
     if (V.RM == 2) { P.smem = dp16_lds_bytes(V.T(), V.W); P.park_lds = true; }  // packed sweep parks in LDS only
-    P.pf_off = (V.RM != 2 && getenv("SXG_POA_PREFETCH")) ? dp_pf_offset(Lpad, wb, V.T()) : -1;
+    if (V.RM == 3) { P.smem = band_lds_bytes(); P.park_lds = true; }
+    P.pf_off = (V.RM < 2 && getenv("SXG_POA_PREFETCH")) ? dp_pf_offset(Lpad, wb, V.T()) : -1;
     if (P.pf_off >= 0) P.smem += dp_pf_bytes(Lpad, wb, V.T());
     if (P.smem > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)P.kern, hipFuncAttributeMaxDynamicSharedMemorySize, P.smem);
@@ -1082,7 +1110,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             } else if (status[b] == ST_RANGE_OVERFLOW || status[b] == ST_BAND_MISS) {
                 // one step wider at the same capacity tier: packed -> int16 row words -> int32 row words
                 if (m.rm != 1) {
-                    m.rm = row_mode(m.S, m.maxlen, m.maxlen, m.rm == 2 ? 0 : 1);
+                    m.rm = row_mode(m.S, m.maxlen, m.maxlen, m.rm >= 2 ? 0 : 1);
                     m.fits = variant_for_len(m.maxlen, m.rm, &m.variant);
                     if (m.fits) again.push_back(b);  // (the wider sweeps cover every length the packed one does)
                     else status[b] = ST_TOO_LONG;
@@ -1107,7 +1135,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         for (int s = h->h_blk_off[b]; s < h->h_blk_off[b + 1]; ++s) cb += cells[s];
         const BlockMeta& m = h->meta[b];
         const int ncross = m.S.convex ? 3 : (m.S.g == m.S.e ? 1 : 2);
-        const int sz = m.rm == 1 ? 4 : 2;
+        const int sz = m.rm == 1 ? 4 : 2;   // (banded: cells = band cells, as counted by the kernel)
         blk_cells[b] = cb; blk_bytes[b] = cb * (uint64_t)(2 * ncross * sz + 1);
         total += cb;
         bytes += blk_bytes[b];
@@ -1117,7 +1145,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         for (int b : pl.work) if (status[b] == ST_OK) { pl.cells += blk_cells[b]; pl.bytes += blk_bytes[b]; }
         if (pl.cells >= h->stats.dom_cells) {
             h->stats.dom_cells = pl.cells; h->stats.dom_algo_bytes = pl.bytes; h->stats.dom_kernel_ms = pl.ms;
-            h->stats.dom_threads = pl.variant.T(); h->stats.dom_cols_per_lane = pl.variant.W * (pl.variant.RM == 2 ? 2 : 1);
+            h->stats.dom_threads = pl.variant.T(); h->stats.dom_cols_per_lane = pl.variant.W * (pl.variant.RM >= 2 ? 2 : 1);
             h->stats.dom_row_mode = pl.variant.RM;
         }
     }

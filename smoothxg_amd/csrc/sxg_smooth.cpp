@@ -518,7 +518,7 @@ void add_to_batch(batch_t& B, const collected_t& c) {
 sxg_poa_params poa_params(const sxg_smooth_params& p) {  // src/smooth.cpp:2098-2106
     sxg_poa_params q;
     q.m = (int8_t)p.poa_m; q.n = (int8_t)-p.poa_n; q.g = (int8_t)-p.poa_g; q.e = (int8_t)-p.poa_e; q.q = (int8_t)-p.poa_q; q.c = (int8_t)-p.poa_c;
-    q.mode = p.local_alignment ? SXG_MODE_LOCAL : SXG_MODE_GLOBAL; q.reserved = 0;
+    q.mode = p.local_alignment ? SXG_MODE_LOCAL : SXG_MODE_GLOBAL; q.banded = 0;
     return q;
 }
 // ---------------------------------------------------------------------------------------------

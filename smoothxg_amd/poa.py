@@ -18,7 +18,7 @@ MODE_LOCAL, MODE_GLOBAL = 0, 1
 
 class Params(C.Structure):
     _fields_ = [("m", C.c_int8), ("n", C.c_int8), ("g", C.c_int8), ("e", C.c_int8),
-                ("q", C.c_int8), ("c", C.c_int8), ("mode", C.c_uint8), ("reserved", C.c_uint8)]
+                ("q", C.c_int8), ("c", C.c_int8), ("mode", C.c_uint8), ("banded", C.c_uint8)]
 
 
 def params_from_cli(m=1, n=4, g=6, e=2, q=26, c=1, local=True):

@@ -1,0 +1,84 @@
+"""GPU parity of the BANDED sweep (A11: the reference's abPOA path, src/smooth.cpp:133-627, band wb=311 / wf=0.03):
+the one-wave sliding-window kernel of poa_band16.hip.h against the oracle's banded mode (decrees B1-B3 of
+oracle/poa_oracle.c) -- scores, graphs, paths, consensus, and the number of band cells."""
+import numpy as np
+import pytest
+
+from helpers import PARAM_SETS, assert_block_equal, random_block
+from oracle import oracle_py as O
+from smoothxg_amd import Params, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(pname, banded=1):
+    m, n, g, e, q, c = PARAM_SETS[pname]
+    return Params(m, n, g, e, q, c, 0, banded), O.mkparams(m, n, g, e, q, c, mode=0, banded=banded)
+
+
+@pytest.mark.parametrize("pname", ["convex_default", "affine_4param", "linear"])
+def test_banded_blocks_match_banded_oracle(engine, pname):
+    """Blocks of many shapes in one batch: short ones (the band covers the whole matrix), long ones (the window
+    slides), divergent ones (deep bubbles, >= 3 predecessors), structural variants that push the alignment towards
+    the edge of the band."""
+    rng = np.random.default_rng(61)
+    blocks = []
+    for L in (40, 300, 900, 1500, 2600, 4000):
+        blocks.append(random_block(rng, int(rng.integers(3, 9)), L, div=0.04))
+    blocks.append(random_block(rng, 24, 400, div=0.12))
+    anc = rng.integers(0, 4, 3000, dtype=np.uint8)
+    ins = rng.integers(0, 4, 280, dtype=np.uint8)
+    blocks.append([np.concatenate([anc[:1200], ins, anc[1200:]]), anc.copy(), np.concatenate([anc[:700], anc[950:]]),
+                   np.concatenate([anc[:2000], ins[:150], anc[2000:]])])
+    gp, op = _p(pname)
+    res = engine.run_blocks(blocks, gp, want_consensus=True)
+    st = engine.stats()
+    assert st["dom_row_mode"] == 3 and st["dom_threads"] == 64
+    for b, seqs in enumerate(blocks):
+        g, sc, cells = O.block_run(seqs, None, op)
+        assert_block_equal(res[b], g, sc, cells, label=f"banded/{pname}/block{b}")
+        assert (res[b].consensus == g.consensus()).all()
+        full = sum(len(s) for s in seqs[1:])   # the band is narrower than the matrix for the long blocks
+        if len(seqs[0]) > 2000:
+            assert int(res[b].cells.sum()) < 0.8 * int(O.block_run(seqs, None, _p(pname, 0)[1])[2].sum()), full
+
+
+def test_band_changes_results_only_where_it_must(engine):
+    """A block whose alignments stay near the diagonal gives the same graph banded and unbanded; a 700-base insertion
+    (beyond w = 311 + 0.03 L) does not -- and both agree with their oracles."""
+    rng = np.random.default_rng(62)
+    calm = random_block(rng, 5, 2500, div=0.02)
+    anc = rng.integers(0, 4, 2500, dtype=np.uint8)
+    wild = [np.concatenate([anc[:1000], rng.integers(0, 4, 700, dtype=np.uint8), anc[1000:]]), anc.copy(), anc.copy()]
+    for seqs, same in ((calm, True), (wild, False)):
+        rb = engine.run_blocks([seqs], _p("convex_default", 1)[0])[0]
+        ru = engine.run_blocks([seqs], _p("convex_default", 0)[0])[0]
+        gb, sb, cb = O.block_run(seqs, None, _p("convex_default", 1)[1])
+        gu, su, cu = O.block_run(seqs, None, _p("convex_default", 0)[1])
+        assert_block_equal(rb, gb, sb, cb, label="banded")
+        assert_block_equal(ru, gu, su, cu, label="unbanded")
+        assert (rb.scores == ru.scores).all() == same
+
+
+def test_config3_shape_banded_full_block(engine):
+    """BASELINE config 3 as the reference's -A path runs it: 64 x 5 kbp, affine 1,4,8,2 in abPOA's convention, BANDED.
+    Whole block, every sequence, against the banded oracle (~15 s on the host)."""
+    seqs = synth.make_block(0, 64, 5000)
+    gp, op = Params(1, -4, -8, -2, -8, -2, 0, 1), O.mkparams(1, -4, -8, -2, -8, -2, mode=0, banded=1)
+    res = engine.run_blocks([seqs], gp, want_consensus=True)[0]
+    g, sc, cells = O.block_run(seqs, None, op)
+    assert_block_equal(res, g, sc, cells, label="c3-banded")
+    assert (res.consensus == g.consensus()).all()
+    w = 311 + int(0.03 * 5000)
+    assert int(cells.sum()) < 0.25 * sum(len(s) for s in seqs[1:]) * g.n_nodes   # ~(2w+11)/L of the matrix
+    assert w == 461
+
+
+def test_global_alignment_ignores_the_band_flag(engine):
+    rng = np.random.default_rng(63)
+    seqs = random_block(rng, 4, 800, div=0.03)
+    m, n, g, e, q, c = PARAM_SETS["convex_default"]
+    res = engine.run_blocks([seqs], Params(m, n, g, e, q, c, 1, 1))[0]
+    gg, sc, cells = O.block_run(seqs, None, O.mkparams(m, n, g, e, q, c, mode=1, banded=1))
+    assert_block_equal(res, gg, sc, cells, label="global+band flag")
+    assert engine.stats()["dom_row_mode"] != 3

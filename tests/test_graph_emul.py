@@ -33,13 +33,14 @@ def run_emul(L, seqs, weights, params, pool=4096):
     rank, ld, et, eh, paths, cons = i32(), i32(), i32(), i32(), i32(), i32()
     ew = np.zeros(cap, np.uint32)
     sc = np.zeros(len(seqs), np.int32)
+    hints = i32()
     w = np.asarray(weights, np.uint32)
     st = L.emul_block_run(_p(bases, C.c_uint8), _p(off, C.c_int32), len(seqs), _p(w, C.c_uint32), C.byref(params),
                           pool, _p(cnt, C.c_int32), _p(code, C.c_uint8), _p(rank, C.c_int32), _p(ld, C.c_int32),
                           _p(et, C.c_int32), _p(eh, C.c_int32), _p(ew, C.c_uint32), _p(paths, C.c_int32),
-                          _p(sc, C.c_int32), _p(cons, C.c_int32))
+                          _p(sc, C.c_int32), _p(cons, C.c_int32), _p(hints, C.c_int32))
     n, e, nc = cnt
-    return st, (code[:n], rank[:n], ld[:n], et[:e], eh[:e], ew[:e], paths[:off[-1]], sc, cons[:nc])
+    return st, (code[:n], rank[:n], ld[:n], et[:e], eh[:e], ew[:e], paths[:off[-1]], sc, cons[:nc], hints[:n])
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -64,6 +65,7 @@ def test_graph_code_matches_oracle(emul, oracle, mode, pname):
         assert (r[6] == np.concatenate([g.seq_path(s) for s in range(g.n_seqs)])).all()
         assert (r[7] == sc).all()
         assert (r[8] == g.consensus()).all()
+        assert (r[9] == g.row_hints()).all()      # backbone coordinates (band hints, decree B2)
 
 
 def test_row_pool_overflow_is_reported(emul, oracle):
