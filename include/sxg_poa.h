@@ -42,6 +42,7 @@ extern "C" {
 #define SXG_E_NODEVICE (-2)  /* no usable HIP device / HIP runtime error */
 #define SXG_E_NOMEM (-3)     /* device or host allocation failed */
 #define SXG_E_BLOCK (-4)     /* at least one block failed; see out->status[] */
+#define SXG_NOT_ROOT 1        /* sxg_poa_batch_run_sharded on a rank other than 0: its share is done, the results are on rank 0 */
 
 /* per-block status (out->status[b]) */
 #define SXG_ST_OK 0
@@ -190,6 +191,23 @@ typedef struct sxg_poa_device_view {
     const int32_t *score;                                /* [n_seqs] */
 } sxg_poa_device_view;
 int sxg_poa_batch_device_view(sxg_poa_handle *h, sxg_poa_device_view *out);
+
+/* Multi-GPU, one handle (= one GPU) per rank.  Blocks are independent (src/smooth.cpp:1931): every rank aligns its
+ * share and the only exchange is the reassembly of the results on the rank that laces (src/main.cpp:599+), over
+ * RCCL/xGMI.  The communicator is either created here from an id that rank 0 generated and handed to the others
+ * (any side channel: MPI, a file, torch.distributed), or a ncclComm_t the caller already owns.
+ * sxg_poa_batch_run_sharded is sxg_poa_batch_run for that communicator: EVERY rank calls it with the SAME batch;
+ * blocks are dealt by cost (longest first onto the least loaded rank), results travel to rank 0 as one blob per
+ * peer (exact size, grouped ncclSend/ncclRecv) and rank 0 returns them in the batch's block order.  Other ranks
+ * return SXG_NOT_ROOT with an empty result.  Without a communicator it equals sxg_poa_batch_run. */
+#define SXG_POA_COMM_ID_BYTES 128
+int sxg_poa_comm_unique_id(uint8_t *id);                                   /* ncclGetUniqueId (rank 0) */
+int sxg_poa_comm_init(sxg_poa_handle *h, const uint8_t *id, int nranks, int rank);
+int sxg_poa_comm_attach(sxg_poa_handle *h, void *nccl_comm, int nranks, int rank); /* caller-owned ncclComm_t */
+void sxg_poa_comm_destroy(sxg_poa_handle *h);
+int sxg_poa_batch_run_sharded(sxg_poa_handle *h, const sxg_poa_batch_in *in, sxg_poa_batch_out *out);
+/* Test entry: the same partition / packing / assembly with `nranks` simulated ranks on this one GPU. */
+int sxg_poa_batch_run_sharded_local(sxg_poa_handle *h, const sxg_poa_batch_in *in, int nranks, sxg_poa_batch_out *out);
 
 int sxg_poa_align_batch(sxg_poa_handle *h, const sxg_poa_align_in *in, sxg_poa_align_out *out);
 void sxg_poa_align_free(sxg_poa_align_out *out);

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libsxgpoa.so")
 SOURCES = ["sxg_poa.hip"]
-DEPS = SOURCES + ["poa_dp.hip.h", "poa_dp16.hip.h", "poa_graph_dev.h", "poa_types.h",
+DEPS = SOURCES + ["poa_dp.hip.h", "poa_dp16.hip.h", "poa_band16.hip.h", "poa_graph_dev.h", "poa_types.h",
                   os.path.join("..", "..", "include", "sxg_poa.h")]
 
 
@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO] + \
-          os.environ.get("SXG_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
+          os.environ.get("SXG_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-lrccl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

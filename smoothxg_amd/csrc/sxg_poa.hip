@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/sxg_poa.h"
+#include <rccl/rccl.h>
 #include "poa_dp.hip.h"
 #include "poa_dp16.hip.h"
 #include "poa_band16.hip.h"
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             const int N = *V.G.n_nodes;
             int score = 0;
             if (RM != 3 && len + 1 > T * CPL) { status = ST_TOO_LONG; break; }
-            if (N + len > A.lay.nodes_cap) { status = ST_NODES_OVERFLOW; break; }
+            if (N + len > A.lay.nodes_cap || *V.G.n_edges + len > A.lay.nodes_cap) { status = ST_NODES_OVERFLOW; break; }
             if (RM != 1 && !S.sw &&
                 -(sxg_gap_cost(S.g, S.e, S.q, S.c, N) + sxg_gap_cost(S.g, S.e, S.q, S.c, len)) >= (RM >= 2 ? 15800 : 30000)) {
                 status = ST_RANGE_OVERFLOW;
@@ -596,6 +597,12 @@ struct sxg_poa_handle {
         d_paths, d_score, d_cells, d_cons, d_work, d_queue, d_arena;
     DevBuf d_tmp_a, d_tmp_b, d_tmp_c, d_tmp_d;
     sxg_poa_stats stats{};
+    // multi-GPU (sxg_poa_batch_run_sharded): communicator of this rank, result blob of the local shard, and -- on the
+    // root -- the blobs of the other ranks, delivered by RCCL
+    ncclComm_t comm = nullptr;
+    bool own_comm = false;
+    int nranks = 1, rank = 0;
+    DevBuf d_blob, d_recv, d_counts;
 };
 
 extern "C" int sxg_poa_abi_version(void) { return SXG_POA_ABI_VERSION; }
@@ -638,9 +645,12 @@ static void release_all(sxg_poa_handle* h) {
     for (DevBuf* b : bufs) b->release();
 }
 
+extern "C" void sxg_poa_comm_destroy(sxg_poa_handle* h);
 extern "C" void sxg_poa_destroy(sxg_poa_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    sxg_poa_comm_destroy(h);
+    h->d_blob.release(); h->d_recv.release(); h->d_counts.release();
     release_all(h);
     for (PlanRes* r : h->planres) {
         r->arena.release(); r->work.release(); r->queue.release(); r->est.release();
@@ -799,15 +809,22 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
         rows_est = std::max(rows_est, (double)m.maxlen * std::max(2.0, 1.0 + 0.0165 * m.nseq));
     }
     nodes_cap += 8;
+    // The graph arrays (~100 B per node and edge) used to be sized for the worst case -- one node per base of the
+    // block, 34 MB of a 64 x 5 kbp slot whose graph ends at ~10 k nodes and ~14 k edges.  The first two tiers size
+    // them from the row estimate (edges and nodes each stay below twice the rows); a block that outgrows them
+    // answers NODES_OVERFLOW and moves up a tier like any other capacity overflow.
+    const int nodes_full = nodes_cap;
     int rows_cap, pool_slots, step_cap;
     if (attempt == 0) {
         rows_cap = (int)std::min<double>(nodes_cap, rows_est + 1024);
         pool_slots = std::min(rows_cap + 1, 768);
         step_cap = rows_cap;
+        nodes_cap = (int)std::min<int64_t>(nodes_full, 2LL * rows_cap + maxlen + 8);
     } else if (attempt == 1) {
         rows_cap = (int)std::min<double>(nodes_cap, 2.5 * rows_est + 4096);
         pool_slots = std::min(rows_cap + 1, 4096);
         step_cap = 3 * rows_cap;
+        nodes_cap = (int)std::min<int64_t>(nodes_full, 2LL * rows_cap + maxlen + 8);
     } else if (attempt == 2) {
         rows_cap = nodes_cap; pool_slots = std::min(rows_cap + 1, 32768); step_cap = nodes_cap;  // edges <= nodes_cap
     } else {
@@ -1105,7 +1122,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         for (int b : pending) {
             BlockMeta& m = h->meta[b];
             if (std::find(nomem_blocks.begin(), nomem_blocks.end(), b) != nomem_blocks.end()) continue;
-            if (status[b] == ST_ROWS_OVERFLOW || status[b] == ST_POOL_OVERFLOW || status[b] == ST_TBX_OVERFLOW) {
+            if (status[b] == ST_ROWS_OVERFLOW || status[b] == ST_POOL_OVERFLOW || status[b] == ST_TBX_OVERFLOW || status[b] == ST_NODES_OVERFLOW) {
                 if (m.tier < 3) { m.tier += 1; again.push_back(b); }
             } else if (status[b] == ST_RANGE_OVERFLOW || status[b] == ST_BAND_MISS) {
                 // one step wider at the same capacity tier: packed -> int16 row words -> int32 row words
@@ -1322,6 +1339,363 @@ extern "C" int sxg_poa_batch_run(sxg_poa_handle* h, const sxg_poa_batch_in* in, 
     int rc2 = sxg_poa_batch_download(h, out);
     if (rc2) return rc2;
     if (rc) g_err = keep;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+// Multi-GPU: blocks are independent (src/smooth.cpp:1931), so every rank aligns its own share and the only
+// exchange is the reassembly of the per-block results on the rank that laces (src/main.cpp:599+).
+// sxg_poa_batch_run_sharded is sxg_poa_batch_run for a communicator: EVERY rank calls it with the SAME batch,
+// the blocks are dealt by cost (longest processing time first), each rank runs its share, packs its
+// dense results into one device blob, the blob sizes are all-gathered and the blobs travel to the root with ONE
+// grouped ncclSend/ncclRecv per peer of exactly that size -- device to device over xGMI, no padding to the
+// largest rank, buffers kept by the handle.  The root assembles the results in the ORIGINAL block order.
+#define NCCLCHK(x)                                                                                      \
+    do {                                                                                               \
+        ncclResult_t _r = (x);                                                                         \
+        if (_r != ncclSuccess) return fail(SXG_E_NODEVICE, std::string(#x) + ": " + ncclGetErrorString(_r)); \
+    } while (0)
+
+extern "C" int sxg_poa_comm_unique_id(uint8_t* id) {
+    if (!id) return fail(SXG_E_INVALID, "NULL argument");
+    static_assert(sizeof(ncclUniqueId) == SXG_POA_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    NCCLCHK(ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return SXG_OK;
+}
+extern "C" void sxg_poa_comm_destroy(sxg_poa_handle* h) {
+    if (!h) return;
+    if (h->comm && h->own_comm) (void)ncclCommDestroy(h->comm);
+    h->comm = nullptr; h->own_comm = false; h->nranks = 1; h->rank = 0;
+}
+extern "C" int sxg_poa_comm_init(sxg_poa_handle* h, const uint8_t* id, int nranks, int rank) {
+    if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(SXG_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    sxg_poa_comm_destroy(h);
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    NCCLCHK(ncclCommInitRank(&h->comm, nranks, u, rank));
+    h->own_comm = true; h->nranks = nranks; h->rank = rank;
+    return SXG_OK;
+}
+extern "C" int sxg_poa_comm_attach(sxg_poa_handle* h, void* nccl_comm, int nranks, int rank) {
+    if (!h || !nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(SXG_E_INVALID, "bad argument");
+    sxg_poa_comm_destroy(h);
+    h->comm = (ncclComm_t)nccl_comm; h->own_comm = false; h->nranks = nranks; h->rank = rank;
+    return SXG_OK;
+}
+
+namespace {
+// blocks by descending cost (ties: lower id) onto the least-loaded rank (ties: lower rank)
+void lpt_partition(const sxg_poa_batch_in* in, int nranks, std::vector<std::vector<int32_t>>& parts) {
+    const int nb = in->n_blocks;
+    std::vector<double> cost(std::max(nb, 1), 0.0);
+    for (int b = 0; b < nb; ++b) {
+        double prev = 0;
+        const double l1 = in->blk_off[b + 1] > in->blk_off[b] ? (double)(in->seq_off[in->blk_off[b] + 1] - in->seq_off[in->blk_off[b]]) : 0.0;
+        for (int sq = in->blk_off[b]; sq < in->blk_off[b + 1]; ++sq) {
+            const double len = (double)(in->seq_off[sq + 1] - in->seq_off[sq]);
+            if (sq > in->blk_off[b]) cost[b] += len * (l1 + 0.05 * prev);
+            prev += len;
+        }
+    }
+    std::vector<int32_t> order(nb);
+    for (int b = 0; b < nb; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return cost[a] > cost[c]; });
+    parts.assign(nranks, {});
+    std::vector<double> load(nranks, 0.0);
+    for (int b : order) {
+        int r = 0;
+        for (int k = 1; k < nranks; ++k) if (load[k] < load[r]) r = k;
+        parts[r].push_back(b);
+        load[r] += cost[b];
+    }
+    for (auto& pt : parts) std::sort(pt.begin(), pt.end());
+}
+struct LocalBatch {
+    std::vector<int32_t> blk_off{0};
+    std::vector<int64_t> seq_off{0};
+    std::vector<uint8_t> bases;
+    std::vector<uint32_t> weights;
+    std::vector<sxg_poa_params> params;
+    sxg_poa_batch_in in;
+};
+void build_local(const sxg_poa_batch_in* in, const std::vector<int32_t>& part, LocalBatch& L) {
+    for (int b : part) {
+        for (int sq = in->blk_off[b]; sq < in->blk_off[b + 1]; ++sq) {
+            L.bases.insert(L.bases.end(), in->bases + in->seq_off[sq], in->bases + in->seq_off[sq + 1]);
+            L.seq_off.push_back((int64_t)L.bases.size());
+            L.weights.push_back(in->weights ? in->weights[sq] : 1u);
+        }
+        L.blk_off.push_back((int32_t)(L.seq_off.size() - 1));
+        if (in->per_block_params) L.params.push_back(in->params[b]);
+    }
+    if (!in->per_block_params) L.params.push_back(in->params[0]);
+    if (L.bases.empty()) L.bases.push_back(0);
+    if (L.weights.empty()) L.weights.push_back(1);
+    memset(&L.in, 0, sizeof(L.in));
+    L.in.n_blocks = (int32_t)part.size(); L.in.blk_off = L.blk_off.data(); L.in.seq_off = L.seq_off.data();
+    L.in.bases = L.bases.data(); L.in.weights = L.weights.data(); L.in.params = L.params.data();
+    L.in.per_block_params = in->per_block_params; L.in.want_consensus = in->want_consensus; L.in.want_msa = 0;
+}
+// blob of one rank: eight counts, then the arrays, every section 16-byte aligned
+enum { BC_NB = 0, BC_NS, BC_NBASES, BC_NODES, BC_EDGES, BC_CONS, BC_BYTES, BC_PAD, BC_N };
+struct BlobLayout { size_t status, nn, ne, nc, score, cells, code, rank, group, et, eh, ew, paths, cons, total; };
+BlobLayout blob_layout(const int64_t* c) {
+    BlobLayout B;
+    size_t cur = 0;
+    auto sec = [&](size_t bytes) { size_t o = cur; cur += (bytes + 15) & ~(size_t)15; return o; };
+    B.status = sec(4 * (size_t)c[BC_NB]); B.nn = sec(4 * (size_t)c[BC_NB]); B.ne = sec(4 * (size_t)c[BC_NB]); B.nc = sec(4 * (size_t)c[BC_NB]);
+    B.score = sec(4 * (size_t)c[BC_NS]); B.cells = sec(8 * (size_t)c[BC_NS]);
+    B.code = sec((size_t)c[BC_NODES]); B.rank = sec(4 * (size_t)c[BC_NODES]); B.group = sec(4 * (size_t)c[BC_NODES]);
+    B.et = sec(4 * (size_t)c[BC_EDGES]); B.eh = sec(4 * (size_t)c[BC_EDGES]); B.ew = sec(4 * (size_t)c[BC_EDGES]);
+    B.paths = sec(4 * (size_t)c[BC_NBASES]); B.cons = sec(4 * (size_t)c[BC_CONS]);
+    B.total = cur;
+    return B;
+}
+// dense results of the handle's executed batch, packed into h->d_blob on the device
+int pack_blob(sxg_poa_handle* h, int64_t* counts) {
+    const int nb = h->n_blocks;
+    std::vector<int32_t> nn(std::max(nb, 1)), ne(std::max(nb, 1)), nc(std::max(nb, 1));
+    if (nb) {
+        HIPCHK(hipMemcpy(nn.data(), h->d_nn.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ne.data(), h->d_ne.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nc.data(), h->d_nc.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+    }
+    std::vector<int64_t> noff(nb + 1, 0), eoff(nb + 1, 0), coff(nb + 1, 0), soff(nb + 1, 0);
+    for (int b = 0; b < nb; ++b) {
+        noff[b + 1] = noff[b] + nn[b]; eoff[b + 1] = eoff[b] + ne[b]; coff[b + 1] = coff[b] + (h->want_consensus ? nc[b] : 0);
+        soff[b] = h->h_seq_off[h->h_blk_off[b]];
+    }
+    memset(counts, 0, sizeof(int64_t) * BC_N);
+    counts[BC_NB] = nb; counts[BC_NS] = h->n_seqs; counts[BC_NBASES] = h->n_bases;
+    counts[BC_NODES] = noff[nb]; counts[BC_EDGES] = eoff[nb]; counts[BC_CONS] = coff[nb];
+    const BlobLayout B = blob_layout(counts);
+    counts[BC_BYTES] = (int64_t)B.total;
+    int rc;
+    if ((rc = h->d_blob.ensure(B.total + 16))) return rc;
+    if ((rc = h->d_tmp_a.ensure(8 * (size_t)(nb + 1))) || (rc = h->d_tmp_b.ensure(8 * (size_t)(nb + 1)))) return rc;
+    uint8_t* blob = h->d_blob.as<uint8_t>();
+    if (nb) {
+        HIPCHK(hipMemcpyAsync(blob + B.status, h->d_status.p, 4 * (size_t)nb, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(blob + B.nn, h->d_nn.p, 4 * (size_t)nb, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(blob + B.ne, h->d_ne.p, 4 * (size_t)nb, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(blob + B.nc, h->d_nc.p, 4 * (size_t)nb, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (h->n_seqs) {
+        HIPCHK(hipMemcpyAsync(blob + B.score, h->d_score.p, 4 * (size_t)h->n_seqs, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(blob + B.cells, h->d_cells.p, 8 * (size_t)h->n_seqs, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (h->n_bases) HIPCHK(hipMemcpyAsync(blob + B.paths, h->d_paths.p, 4 * (size_t)h->n_bases, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_tmp_a.p, soff.data(), 8 * (size_t)(nb + 1), hipMemcpyHostToDevice, h->stream));
+    auto gather = [&](auto tag, const DevBuf& src, const std::vector<int64_t>& off, size_t at) -> int {
+        typedef decltype(tag) Tv;
+        if (off[nb] == 0) return SXG_OK;
+        HIPCHK(hipMemcpyAsync(h->d_tmp_b.p, off.data(), 8 * (size_t)(nb + 1), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL((gather_kernel<Tv>), dim3((unsigned)std::min(nb, 4096)), dim3(256), 0, h->stream, src.as<Tv>(), (Tv*)(blob + at),
+                           h->d_tmp_a.as<int64_t>(), h->d_tmp_b.as<int64_t>(), nb);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));   // (d_tmp_b is reused by the next array)
+        return SXG_OK;
+    };
+    if ((rc = gather(uint8_t(), h->d_node_code, noff, B.code)) || (rc = gather(int32_t(), h->d_node_rank, noff, B.rank)) ||
+        (rc = gather(int32_t(), h->d_node_group, noff, B.group)) || (rc = gather(int32_t(), h->d_edge_tail, eoff, B.et)) ||
+        (rc = gather(int32_t(), h->d_edge_head, eoff, B.eh)) || (rc = gather(uint32_t(), h->d_edge_w, eoff, B.ew)))
+        return rc;
+    if (h->want_consensus && (rc = gather(int32_t(), h->d_cons, coff, B.cons))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SXG_OK;
+}
+void format_msa(OutOwner* o, const sxg_poa_batch_in* in, bool want_consensus);
+// root: results of all ranks (host copies of their blobs) -> one result set in the batch's block order
+int assemble(const sxg_poa_batch_in* in, const std::vector<std::vector<int32_t>>& parts, const std::vector<std::vector<uint8_t>>& blobs,
+             const std::vector<int64_t>& counts, sxg_poa_batch_out* out) {
+    const int nb = in->n_blocks, nranks = (int)parts.size();
+    const int64_t ns = nb ? in->blk_off[nb] : 0, nbases = ns ? in->seq_off[ns] : 0;
+    OutOwner* o = new OutOwner();
+    out->_owner = o;
+    out->n_blocks = nb; out->n_seqs = ns;
+    o->status.assign(std::max(nb, 1), 0); o->score.assign((size_t)std::max<int64_t>(ns, 1), 0); o->cells.assign((size_t)std::max<int64_t>(ns, 1), 0);
+    o->node_off.assign(nb + 1, 0); o->edge_off.assign(nb + 1, 0); o->cons_off.assign(nb + 1, 0);
+    o->seq_path_nodes = (int32_t*)malloc(4 * (size_t)std::max<int64_t>(nbases, 1));
+    if (!o->seq_path_nodes) return fail(SXG_E_NOMEM, "host allocation of the path array failed");
+    // where every block sits: (rank, index in the rank's shard, offsets inside that rank's arrays)
+    struct Where { int rank, idx; int64_t n0, e0, c0, s0, b0; };
+    std::vector<Where> where(std::max(nb, 1));
+    for (int r = 0; r < nranks; ++r) {
+        const int64_t* c = counts.data() + (size_t)r * BC_N;
+        const BlobLayout B = blob_layout(c);
+        const uint8_t* blob = blobs[r].data();
+        const int32_t *nn = (const int32_t*)(blob + B.nn), *ne = (const int32_t*)(blob + B.ne), *nc = (const int32_t*)(blob + B.nc);
+        int64_t n0 = 0, e0 = 0, c0 = 0, s0 = 0, b0 = 0;
+        for (size_t k = 0; k < parts[r].size(); ++k) {
+            const int b = parts[r][k];
+            where[b] = Where{r, (int)k, n0, e0, c0, s0, b0};
+            o->node_off[b + 1] = nn[k]; o->edge_off[b + 1] = ne[k]; o->cons_off[b + 1] = in->want_consensus ? nc[k] : 0;
+            n0 += nn[k]; e0 += ne[k]; c0 += in->want_consensus ? nc[k] : 0;
+            s0 += in->blk_off[b + 1] - in->blk_off[b];
+            b0 += in->seq_off[in->blk_off[b + 1]] - in->seq_off[in->blk_off[b]];
+        }
+    }
+    for (int b = 0; b < nb; ++b) { o->node_off[b + 1] += o->node_off[b]; o->edge_off[b + 1] += o->edge_off[b]; o->cons_off[b + 1] += o->cons_off[b]; }
+    o->node_code.resize((size_t)std::max<int64_t>(o->node_off[nb], 1)); o->node_rank.resize(o->node_code.size()); o->node_group.resize(o->node_code.size());
+    o->edge_tail.resize((size_t)std::max<int64_t>(o->edge_off[nb], 1)); o->edge_head.resize(o->edge_tail.size()); o->edge_weight.resize(o->edge_tail.size());
+    o->cons_nodes.resize((size_t)std::max<int64_t>(o->cons_off[nb], 1));
+    for (int b = 0; b < nb; ++b) {
+        const Where& wv = where[b];
+        const BlobLayout B = blob_layout(counts.data() + (size_t)wv.rank * BC_N);
+        const uint8_t* blob = blobs[wv.rank].data();
+        o->status[b] = ((const int32_t*)(blob + B.status))[wv.idx];
+        const int64_t nn = o->node_off[b + 1] - o->node_off[b], ne = o->edge_off[b + 1] - o->edge_off[b], nc = o->cons_off[b + 1] - o->cons_off[b];
+        memcpy(o->node_code.data() + o->node_off[b], blob + B.code + wv.n0, (size_t)nn);
+        memcpy(o->node_rank.data() + o->node_off[b], blob + B.rank + 4 * wv.n0, 4 * (size_t)nn);
+        memcpy(o->node_group.data() + o->node_off[b], blob + B.group + 4 * wv.n0, 4 * (size_t)nn);
+        memcpy(o->edge_tail.data() + o->edge_off[b], blob + B.et + 4 * wv.e0, 4 * (size_t)ne);
+        memcpy(o->edge_head.data() + o->edge_off[b], blob + B.eh + 4 * wv.e0, 4 * (size_t)ne);
+        memcpy(o->edge_weight.data() + o->edge_off[b], blob + B.ew + 4 * wv.e0, 4 * (size_t)ne);
+        if (nc) memcpy(o->cons_nodes.data() + o->cons_off[b], blob + B.cons + 4 * wv.c0, 4 * (size_t)nc);
+        const int64_t nsq = in->blk_off[b + 1] - in->blk_off[b], nbs = in->seq_off[in->blk_off[b + 1]] - in->seq_off[in->blk_off[b]];
+        memcpy(o->score.data() + in->blk_off[b], blob + B.score + 4 * wv.s0, 4 * (size_t)nsq);
+        memcpy(o->cells.data() + in->blk_off[b], blob + B.cells + 8 * wv.s0, 8 * (size_t)nsq);
+        memcpy(o->seq_path_nodes + in->seq_off[in->blk_off[b]], blob + B.paths + 4 * wv.b0, 4 * (size_t)nbs);
+    }
+    out->status = o->status.data();
+    out->node_off = o->node_off.data(); out->node_code = o->node_code.data(); out->node_rank = o->node_rank.data();
+    out->node_group = o->node_group.data(); out->edge_off = o->edge_off.data(); out->edge_tail = o->edge_tail.data();
+    out->edge_head = o->edge_head.data(); out->edge_weight = o->edge_weight.data();
+    out->seq_path_nodes = o->seq_path_nodes; out->score = o->score.data(); out->cells = o->cells.data();
+    if (in->want_consensus) { out->cons_off = o->cons_off.data(); out->cons_nodes = o->cons_nodes.data(); }
+    if (in->want_msa) {
+        format_msa(o, in, in->want_consensus != 0);
+        out->msa_off = o->msa_off.data(); out->msa_cols = o->msa_cols.data(); out->msa = o->msa.data();
+    }
+    for (int b = 0; b < nb; ++b)
+        if (o->status[b] != ST_OK) return fail(SXG_E_BLOCK, "block " + std::to_string(b) + " failed with status " + std::to_string(o->status[b]));
+    return SXG_OK;
+}
+// S8: MSA column = aligned group in rank order; pure formatting of the results (same rule as sxg_poa_batch_download)
+void format_msa(OutOwner* o, const sxg_poa_batch_in* in, bool want_consensus) {
+    static const char dec[5] = {'A', 'C', 'G', 'T', 'N'};
+    const int nb = in->n_blocks;
+    o->msa_off.assign(nb + 1, 0); o->msa_cols.assign(std::max(nb, 1), 0);
+    std::vector<std::vector<int32_t>> cols(nb);
+    for (int b = 0; b < nb; ++b) {
+        const int64_t n0 = o->node_off[b];
+        const int n = (int)(o->node_off[b + 1] - n0);
+        std::vector<int32_t> by_rank(n);
+        for (int v = 0; v < n; ++v) by_rank[o->node_rank[n0 + v]] = v;
+        cols[b].assign(n, 0);
+        int ncol = 0;
+        for (int r = 0; r < n; ++r) {
+            const int v = by_rank[r];
+            if (r > 0 && o->node_group[n0 + by_rank[r - 1]] == o->node_group[n0 + v]) cols[b][v] = ncol - 1; else cols[b][v] = ncol++;
+        }
+        o->msa_cols[b] = ncol;
+        const int rows = (in->blk_off[b + 1] - in->blk_off[b]) + (want_consensus ? 1 : 0);
+        o->msa_off[b + 1] = o->msa_off[b] + (o->status[b] == ST_OK ? (int64_t)rows * ncol : 0);
+    }
+    o->msa.assign((size_t)std::max<int64_t>(o->msa_off[nb], 1), '-');
+    for (int b = 0; b < nb; ++b) {
+        if (o->status[b] != ST_OK) continue;
+        const int64_t n0 = o->node_off[b];
+        const int ncol = o->msa_cols[b];
+        char* base = o->msa.data() + o->msa_off[b];
+        int row = 0;
+        for (int sq = in->blk_off[b]; sq < in->blk_off[b + 1]; ++sq, ++row)
+            for (int64_t k = in->seq_off[sq]; k < in->seq_off[sq + 1]; ++k) base[(int64_t)row * ncol + cols[b][o->seq_path_nodes[k]]] = dec[o->node_code[n0 + o->seq_path_nodes[k]]];
+        if (want_consensus)
+            for (int64_t k = o->cons_off[b]; k < o->cons_off[b + 1]; ++k) base[(int64_t)row * ncol + cols[b][o->cons_nodes[k]]] = dec[o->node_code[n0 + o->cons_nodes[k]]];
+    }
+}
+int run_shard(sxg_poa_handle* h, const sxg_poa_batch_in* in, const std::vector<int32_t>& part, int64_t* counts) {
+    LocalBatch L;
+    build_local(in, part, L);
+    int rc = sxg_poa_batch_upload(h, &L.in);
+    if (rc) return rc;
+    rc = sxg_poa_batch_execute(h);
+    if (rc && rc != SXG_E_BLOCK) return rc;   // (per-block failures travel in the status array)
+    return pack_blob(h, counts);
+}
+}  // namespace
+
+static int check_batch(const sxg_poa_batch_in* in) {
+    if (in->n_blocks < 0 || (in->n_blocks > 0 && (!in->blk_off || !in->seq_off || !in->params || !in->bases))) return fail(SXG_E_INVALID, "batch_in has NULL arrays");
+    return SXG_OK;
+}
+
+extern "C" int sxg_poa_batch_run_sharded(sxg_poa_handle* h, const sxg_poa_batch_in* in, sxg_poa_batch_out* out) {
+    if (!h || !in || !out) return fail(SXG_E_INVALID, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    int rc = check_batch(in);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const int nranks = h->comm ? h->nranks : 1, rank = h->comm ? h->rank : 0;
+    std::vector<std::vector<int32_t>> parts;
+    lpt_partition(in, nranks, parts);
+    std::vector<int64_t> counts((size_t)nranks * BC_N, 0);
+    if ((rc = run_shard(h, in, parts[rank], counts.data() + (size_t)rank * BC_N))) return rc;
+    if (nranks > 1) {
+        // sizes first (RCCL has no all-gather-v) ...
+        if ((rc = h->d_counts.ensure(8 * (size_t)BC_N * (size_t)(nranks + 1)))) return rc;
+        int64_t* dc = h->d_counts.as<int64_t>();
+        HIPCHK(hipMemcpyAsync(dc + (size_t)nranks * BC_N, counts.data() + (size_t)rank * BC_N, 8 * BC_N, hipMemcpyHostToDevice, h->stream));
+        NCCLCHK(ncclAllGather(dc + (size_t)nranks * BC_N, dc, BC_N, ncclInt64, h->comm, h->stream));
+        HIPCHK(hipMemcpyAsync(counts.data(), dc, 8 * (size_t)BC_N * nranks, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        // ... then every blob straight to the root, exact sizes, one group: the seven peers use their own xGMI links
+        std::vector<size_t> at(nranks + 1, 0);
+        for (int r = 1; r < nranks; ++r) at[r + 1] = at[r] + (((size_t)counts[(size_t)r * BC_N + BC_BYTES] + 255) & ~(size_t)255);
+        if (rank == 0 && (rc = h->d_recv.ensure(at[nranks] + 256))) return rc;
+        NCCLCHK(ncclGroupStart());
+        if (rank == 0) {
+            for (int r = 1; r < nranks; ++r)
+                if (counts[(size_t)r * BC_N + BC_BYTES] > 0)
+                    NCCLCHK(ncclRecv(h->d_recv.as<uint8_t>() + at[r], (size_t)counts[(size_t)r * BC_N + BC_BYTES], ncclUint8, r, h->comm, h->stream));
+        } else if (counts[(size_t)rank * BC_N + BC_BYTES] > 0)
+            NCCLCHK(ncclSend(h->d_blob.p, (size_t)counts[(size_t)rank * BC_N + BC_BYTES], ncclUint8, 0, h->comm, h->stream));
+        NCCLCHK(ncclGroupEnd());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (rank != 0) return SXG_NOT_ROOT;
+        std::vector<std::vector<uint8_t>> blobs(nranks);
+        for (int r = 0; r < nranks; ++r) {
+            const size_t bytes = (size_t)counts[(size_t)r * BC_N + BC_BYTES];
+            blobs[r].resize(std::max<size_t>(bytes, 16));
+            if (bytes) HIPCHK(hipMemcpy(blobs[r].data(), r == 0 ? h->d_blob.p : (void*)(h->d_recv.as<uint8_t>() + at[r]), bytes, hipMemcpyDeviceToHost));
+        }
+        rc = assemble(in, parts, blobs, counts, out);
+    } else {
+        std::vector<std::vector<uint8_t>> blobs(1);
+        const size_t bytes = (size_t)counts[BC_BYTES];
+        blobs[0].resize(std::max<size_t>(bytes, 16));
+        if (bytes) HIPCHK(hipMemcpy(blobs[0].data(), h->d_blob.p, bytes, hipMemcpyDeviceToHost));
+        rc = assemble(in, parts, blobs, counts, out);
+    }
+    if (rc && rc != SXG_E_BLOCK) sxg_poa_batch_free(out);
+    return rc;
+}
+
+// TEST ENTRY: the sharded run with `nranks` SIMULATED ranks on this one GPU -- every shard is aligned here, one after
+// the other, and its blob is put where RCCL would have delivered it.  Exercises the partition, the blob packing
+// and the root's assembly with more than one rank on a box that has one GPU; only ncclSend/ncclRecv are not taken.
+extern "C" int sxg_poa_batch_run_sharded_local(sxg_poa_handle* h, const sxg_poa_batch_in* in, int nranks, sxg_poa_batch_out* out) {
+    if (!h || !in || !out || nranks < 1) return fail(SXG_E_INVALID, "bad argument");
+    memset(out, 0, sizeof(*out));
+    int rc = check_batch(in);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<std::vector<int32_t>> parts;
+    lpt_partition(in, nranks, parts);
+    std::vector<int64_t> counts((size_t)nranks * BC_N, 0);
+    std::vector<std::vector<uint8_t>> blobs(nranks);
+    for (int r = 0; r < nranks; ++r) {
+        if ((rc = run_shard(h, in, parts[r], counts.data() + (size_t)r * BC_N))) return rc;
+        const size_t bytes = (size_t)counts[(size_t)r * BC_N + BC_BYTES];
+        blobs[r].resize(std::max<size_t>(bytes, 16));
+        if (bytes) HIPCHK(hipMemcpy(blobs[r].data(), h->d_blob.p, bytes, hipMemcpyDeviceToHost));
+    }
+    rc = assemble(in, parts, blobs, counts, out);
+    if (rc && rc != SXG_E_BLOCK) sxg_poa_batch_free(out);
     return rc;
 }
 

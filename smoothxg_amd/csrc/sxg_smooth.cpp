@@ -1243,6 +1243,10 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
     sxg_poa_batch_out out;
     memset(&out, 0, sizeof(out));
     const int rc = run(ctx, &in, &out);
+    if (rc == SXG_NOT_ROOT) {   // multi-GPU provider (sxg_poa_batch_run_sharded) on a rank that does not lace: its share is done
+        if (fre) fre(&out);
+        return fail(SXG_NOT_ROOT, "not the lacing rank");
+    }
     if (rc != SXG_OK) { if (fre) fre(&out); return fail(rc, "POA provider failed"); }
     if (mp && nb > 0 && (!out.msa || !out.msa_off || !out.msa_cols)) { if (fre) fre(&out); return fail(SXG_E_INVALID, "POA provider returned no MSA"); }
     lap("POA provider");

@@ -76,7 +76,10 @@ class DeviceView(C.Structure):
 EXPORTS = ["sxg_poa_batch_device_view", "sxg_poa_abi_version", "sxg_poa_device_count", "sxg_poa_last_error", "sxg_poa_create",
            "sxg_poa_destroy", "sxg_poa_batch_run", "sxg_poa_batch_upload", "sxg_poa_batch_execute",
            "sxg_poa_batch_download", "sxg_poa_batch_free", "sxg_poa_align_batch", "sxg_poa_align_free",
-           "sxg_poa_get_stats", "sxg_poa_set_memory_budget", "sxg_xxh64"]
+           "sxg_poa_get_stats", "sxg_poa_set_memory_budget", "sxg_xxh64", "sxg_poa_comm_unique_id", "sxg_poa_comm_init",
+           "sxg_poa_comm_attach", "sxg_poa_comm_destroy", "sxg_poa_batch_run_sharded", "sxg_poa_batch_run_sharded_local"]
+COMM_ID_BYTES = 128
+NOT_ROOT = 1
 
 _lib = None
 
@@ -106,6 +109,13 @@ def load_library(build_if_missing=True):
     L.sxg_poa_align_free.argtypes = [C.POINTER(AlignOut)]
     L.sxg_poa_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sxg_poa_set_memory_budget.argtypes = [vp, C.c_uint64]
+    L.sxg_poa_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.sxg_poa_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+    L.sxg_poa_comm_attach.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.sxg_poa_comm_destroy.argtypes = [vp]
+    L.sxg_poa_comm_destroy.restype = None
+    L.sxg_poa_batch_run_sharded.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(BatchOut)]
+    L.sxg_poa_batch_run_sharded_local.argtypes = [vp, C.POINTER(BatchIn), C.c_int, C.POINTER(BatchOut)]
     L.sxg_xxh64.restype = C.c_uint64
     L.sxg_xxh64.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
     _lib = L
@@ -267,6 +277,39 @@ class PoaEngine:
         self.upload(bases, seq_off, blk_off, weights, params, want_consensus, want_msa)
         self.execute(check=check)
         return self.download()
+
+    # -- multi-GPU (one engine per rank) ---------------------------------------------------
+    def comm_unique_id(self):
+        """Rank 0: the id every rank passes to comm_init (send it through any side channel)."""
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        if self.lib.sxg_poa_comm_unique_id(buf):
+            raise self._err("sxg_poa_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, comm_id, nranks, rank):
+        buf = (C.c_uint8 * COMM_ID_BYTES)(*comm_id)
+        if self.lib.sxg_poa_comm_init(self.h, buf, nranks, rank):
+            raise self._err("sxg_poa_comm_init")
+
+    def run_flat_sharded(self, bases, seq_off, blk_off, weights, params, want_consensus=False, want_msa=False, check=True,
+                         simulate_ranks=0):
+        """sxg_poa_batch_run_sharded: every rank passes the SAME batch; rank 0 gets all results (list), the others None.
+        simulate_ranks > 0: the test entry that plays that many ranks on this one GPU."""
+        bi = self._mk_in(bases, seq_off, blk_off, weights, params, want_consensus, want_msa)
+        self._shape = (np.asarray(blk_off).copy(), np.asarray(seq_off).copy())
+        out = BatchOut()
+        if simulate_ranks:
+            rc = self.lib.sxg_poa_batch_run_sharded_local(self.h, C.byref(bi), simulate_ranks, C.byref(out))
+        else:
+            rc = self.lib.sxg_poa_batch_run_sharded(self.h, C.byref(bi), C.byref(out))
+        if rc == NOT_ROOT:
+            return None
+        try:
+            if rc and (check or rc != -4):
+                raise self._err("sxg_poa_batch_run_sharded")
+            return self._unpack(out)
+        finally:
+            self.lib.sxg_poa_batch_free(C.byref(out))
 
     def run_blocks(self, blocks, params, weights=None, want_consensus=False, want_msa=False, check=True):
         """blocks: list of lists of uint8 code arrays (one inner list per block, alignment order)."""

@@ -104,10 +104,11 @@ def adaptive_poa_scores(est_identity_threshold, set_scores=(1, 4, 6, 2, 26, 1)):
     return tuple(o)
 
 
-def gpu_provider(engine):
-    """(run, free, ctx) backed by the GPU engine: raw C entry points of libsxgpoa.so."""
+def gpu_provider(engine, sharded=False):
+    """(run, free, ctx) backed by the GPU engine: raw C entry points of libsxgpoa.so.  sharded=True: the multi-GPU
+    entry (sxg_poa_batch_run_sharded over the engine's communicator): every rank runs the same iteration, rank 0 laces."""
     L = engine.lib
-    run = C.cast(L.sxg_poa_batch_run, C.c_void_p)
+    run = C.cast(L.sxg_poa_batch_run_sharded if sharded else L.sxg_poa_batch_run, C.c_void_p)
     fre = C.cast(L.sxg_poa_batch_free, C.c_void_p)
     return run, fre, engine.h
 
@@ -234,6 +235,10 @@ class Smoother:
             self.L.sxg_smooth_free(maf)
 
     def smooth_gfa(self, params, provider):
+        """One smoothing iteration -> GFA text; None on a rank of a multi-GPU provider that does not lace."""
         run, fre, ctx = provider
         out = C.c_void_p()
-        return self._text(self.L.sxg_smooth_gfa(self.g, self.b, C.byref(params), run, fre, ctx, C.byref(out)), out)
+        rc = self.L.sxg_smooth_gfa(self.g, self.b, C.byref(params), run, fre, ctx, C.byref(out))
+        if rc == 1:   # SXG_NOT_ROOT
+            return None
+        return self._text(rc, out)

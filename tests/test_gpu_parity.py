@@ -291,3 +291,41 @@ def test_small_memory_budget_runs_blocks_through_few_slots(engine, oracle):
     for b, seqs in enumerate(blocks):
         g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
         assert_block_equal(res[b], g, sc, cells, label=f"budget {b}")
+
+
+def test_sharded_run_reassembles_in_block_order(engine, oracle):
+    """sxg_poa_batch_run_sharded (the multi-GPU entry of the C ABI): LPT partition by cost, per-rank blobs, assembly on
+    the root in the batch's block order.  Played here with 1, 2, 3 and 5 SIMULATED ranks on the one GPU of the box (the
+    test entry of the ABI: everything but ncclSend/ncclRecv) and with a real one-rank communicator; mixed block sizes,
+    per-block scores, weights, consensus and MSA must all come back as from the single-GPU call."""
+    rng = np.random.default_rng(202)
+    blocks, gp = [], []
+    names = list(PARAM_SETS)
+    for b in range(17):
+        L = int(rng.choice([30, 200, 700, 1600]))
+        blocks.append(random_block(rng, int(rng.integers(1, 9)), L, div=0.05) if b != 6 else [])
+        gp.append(gparams(names[b % len(names)], b % 2))
+    seqs = [s for blk in blocks for s in blk]
+    bases = np.concatenate(seqs)
+    seq_off = np.zeros(len(seqs) + 1, np.int64)
+    seq_off[1:] = np.cumsum([len(s) for s in seqs])
+    blk_off = np.zeros(len(blocks) + 1, np.int32)
+    blk_off[1:] = np.cumsum([len(b) for b in blocks])
+    w = rng.integers(1, 4, len(seqs)).astype(np.uint32)
+    ref = engine.run_flat(bases, seq_off, blk_off, w, gp, want_consensus=True, want_msa=True)
+
+    def same(res):
+        assert len(res) == len(ref)
+        for a, b in zip(res, ref):
+            assert a.status == b.status == 0
+            for f in ("node_code", "node_rank", "node_group", "edge_tail", "edge_head", "edge_weight", "scores", "cells", "consensus"):
+                assert (getattr(a, f) == getattr(b, f)).all(), f
+            assert all((x == y).all() for x, y in zip(a.paths, b.paths)) and a.msa == b.msa
+
+    for nranks in (1, 2, 3, 5):
+        same(engine.run_flat_sharded(bases, seq_off, blk_off, w, gp, want_consensus=True, want_msa=True, simulate_ranks=nranks))
+    engine.comm_init(engine.comm_unique_id(), 1, 0)         # a real RCCL communicator of one rank
+    try:
+        same(engine.run_flat_sharded(bases, seq_off, blk_off, w, gp, want_consensus=True, want_msa=True))
+    finally:
+        engine.lib.sxg_poa_comm_destroy(engine.h)

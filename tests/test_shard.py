@@ -72,3 +72,97 @@ def test_all_gather_v_and_host_reassembly_gloo_world2():
     for p in procs:
         p.join(60)
     assert got == [(0, True), (1, True)]
+
+
+def _lace_worker(rank, world, port, q):
+    """shard -> (mock engine: the C oracle, own blocks only) -> gather -> rank 0 laces -> GFA."""
+    import ctypes as C
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import test_smooth_host as H
+    from oracle import oracle_py as O
+    from smoothxg_amd import smooth as S
+
+    class ShardedOracleProvider(H.OracleProvider):
+        """What sxg_poa_batch_run_sharded does, with the oracle as every rank's engine and gloo as the transport: every
+        rank is handed the same batch, aligns its LPT share, the results meet on rank 0, the others answer NOT_ROOT."""
+
+        def _run(self, ctx, pin, pout):
+            i = pin.contents
+            nb = i.n_blocks
+            blk = np.ctypeslib.as_array(i.blk_off, (nb + 1,)).copy()
+            ns = int(blk[-1])
+            so = np.ctypeslib.as_array(i.seq_off, (ns + 1,)).copy()
+            bases = np.ctypeslib.as_array(i.bases, (max(int(so[-1]), 1),)).copy()
+            w = np.ctypeslib.as_array(i.weights, (max(ns, 1),)).copy()
+            costs = [shard.block_cost(np.diff(so[blk[b]:blk[b + 1] + 1])) for b in range(nb)]
+            mine = shard.partition_blocks(costs, world)[rank]
+            pr = i.params[0]
+            par = O.mkparams(pr.m, pr.n, pr.g, pr.e, pr.q, pr.c, pr.mode)
+            local = {}
+            for b in mine:
+                seqs = [bases[so[s]:so[s + 1]] for s in range(blk[b], blk[b + 1])]
+                if seqs:
+                    g, _, _ = O.block_run(seqs, w[blk[b]:blk[b + 1]], par)
+                    local[b] = (g.nodes()[0], [g.seq_path(k) for k in range(len(seqs))], g.consensus())
+            parts = [None] * world
+            dist.all_gather_object(parts, local)
+            if rank != 0:
+                return 1   # SXG_NOT_ROOT
+            merged = {}
+            for part in parts:
+                merged.update(part)
+            self.merged = merged
+            self.blk = blk
+            return H.OracleProvider._run(self, ctx, pin, pout)
+
+    text = H.haplotype_gfa(5, n_paths=5, length=900)
+    prov = ShardedOracleProvider()
+    # rank 0's lacing must see exactly what the oracle computes for EVERY block: replace block_run with a lookup
+    real = O.block_run
+
+    def looked_up(seqs, weights, params, impl=0):
+        if rank == 0 and hasattr(prov, "merged"):
+            for b, (code, paths, cons) in prov.merged.items():
+                if len(paths) == len(seqs) and all(len(p) == len(s) for p, s in zip(paths, seqs)) and \
+                        all((code[p] == s).all() for p, s in zip(paths, seqs)):
+                    class G:
+                        n_seqs = len(seqs)
+                        def nodes(self_): return code, None, None
+                        def seq_path(self_, k): return paths[k]
+                        def consensus(self_): return cons
+                        def msa(self_, c): raise NotImplementedError
+                    return G(), None, None
+        return real(seqs, weights, params, impl)
+    O.block_run = looked_up
+    sm = S.Smoother(text, 250)
+    got = sm.smooth_gfa(S.default_params(add_consensus=1), prov.provider())
+    O.block_run = real
+    if rank == 0:
+        single = S.Smoother(text, 250).smooth_gfa(S.default_params(add_consensus=1), H.OracleProvider().provider())
+        q.put((rank, got == single and got is not None and len(prov.merged) == sm.n_blocks))
+    else:
+        q.put((rank, got is None))
+    dist.destroy_process_group()
+
+
+def test_shard_gather_lace_equals_single_rank_gloo_world2():
+    """Config 5's shape on CPU: two ranks run the same smoothing iteration through a sharded provider (LPT share each,
+    results gathered on rank 0 over gloo); rank 0's laced GFA equals the single-rank GFA, rank 1 gets NOT_ROOT."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lace_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert got == [(0, True), (1, True)]
