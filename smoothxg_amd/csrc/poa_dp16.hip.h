@@ -618,6 +618,14 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     uint32_t* win = (uint32_t*)(smem + LDS_CTL_BYTES);
     const int WR = TBW_ROWS;  // window rows
     uint32_t* wlet = win + TBW_ROWS * TBW_STRIDE;  // [TBW_LET] query letters of columns jtop, jtop-1, ...
+    // Diagonal steps are precomputed for the whole window by all 64 lanes (lane l: the 8 cells of row wtop - l): a word
+    // per cell saying "from here the walk takes a D step to window cell (l', x')" -- or 0 when the cell needs the
+    // general code below (a gap, three or more predecessors, a cell the window does not hold, the end of a local
+    // alignment).  The serial part of a run of matches/mismatches is then one LDS read per step instead of ~150
+    // scalar instructions, and its outputs are written by 64 lanes at once.  Lives in the parked-row area of the
+    // sweep (free during the walk).
+    uint32_t* trans = (uint32_t*)(smem + LDS_CTL_BYTES + dp16_meta_bytes(T));   // [TBW_ROWS][TBW_COLS]
+    uint32_t* chain = trans + TBW_ROWS * TBW_COLS;                               // [TBW_ROWS] cells of the current run
     const int kmax_e = CVX ? 1 + (g - q) / (c - e) : 0x7fffffff;  // longest gap the first piece can win (poa_vtb.c)
 #define TBU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
     // H of the virtual row 0
@@ -712,9 +720,79 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {   // D transitions of my row's cells (rule D of poa_vtb.c, rows with one or two predecessors)
+                    const int row2 = i - lane;
+                    uint32_t tw[TBW_COLS];
+#pragma unroll
+                    for (int x2 = 0; x2 < TBW_COLS; ++x2) tw[x2] = 0u;
+                    if (row2 >= 1 && lane < WR) {
+                        const uint32_t* me = win + lane * TBW_STRIDE;
+                        const uint32_t nv = me[EO_NODE];
+                        const int inf2 = (int)me[EO_INFO], np2 = inf2 & 0xffff, code2 = (inf2 >> 16) & 0xff;
+                        const int pa = (int)me[EO_Q0], pbb = (int)me[EO_Q1];
+                        const int c0 = wcol0(lane);
+                        if (np2 >= 1 && np2 <= 2 && pa >= 1 && (np2 == 1 || pbb >= 1)) {
+                            const int la = wtop - pa, lb = np2 == 2 ? wtop - pbb : la;
+                            if ((unsigned)la < (unsigned)WR && (unsigned)lb < (unsigned)WR) {
+                                const int ca = wcol0(la), cb = wcol0(lb);
+                                const uint32_t nva = win[la * TBW_STRIDE + EO_NODE], nvb = win[lb * TBW_STRIDE + EO_NODE];
+#pragma unroll
+                                for (int x2 = 0; x2 < TBW_COLS; ++x2) {
+                                    const int col = c0 + x2;
+                                    const int xa = col - 1 - ca, xb = col - 1 - cb, lo = wj - col;
+                                    if (!((nv >> (24 + x2)) & 1u) || col < 1 || (unsigned)xa >= (unsigned)TBW_COLS || (unsigned)xb >= (unsigned)TBW_COLS ||
+                                        (unsigned)lo >= (unsigned)TBW_LET) continue;
+                                    if (!((nva >> (24 + xa)) & 1u) || !((nvb >> (24 + xb)) & 1u)) continue;
+                                    const int hcell = sext(me[x2]);
+                                    if (sw && hcell == 0) continue;
+                                    const int ha = sext(win[la * TBW_STRIDE + xa]), hb = np2 == 2 ? sext(win[lb * TBW_STRIDE + xb]) : ha;
+                                    const bool second = np2 == 2 && hb > ha;    // (first predecessor in list order on ties)
+                                    const int best2 = second ? hb : ha;
+                                    if (best2 + ((int)wlet[lo] == code2 ? sm : sn) == hcell)
+                                        tw[x2] = 0x80000000u | (uint32_t)(second ? lb : la) | ((uint32_t)(second ? xb : xa) << 6);
+                                }
+                            }
+                        }
+                    }
+                    if (lane < WR) {
+#pragma unroll
+                        for (int x2 = 0; x2 < TBW_COLS; ++x2) trans[lane * TBW_COLS + x2] = tw[x2];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
 #ifdef SXG_ROW_PROF
                 tb_ld += __builtin_readcyclecounter() - tl0;
 #endif
+            }
+        }
+        if (st == SRC_STOP) {   // a run of precomputed diagonal steps
+            int cl = wtop - i, cx = j - wcol0(cl), ns = 0;
+            for (;;) {
+                const uint32_t tr = TBU(trans[cl * TBW_COLS + cx]);
+                if (!(tr >> 31)) break;
+                if (lane == 0) chain[ns] = (uint32_t)cl | ((uint32_t)cx << 6);
+                ++ns;
+                cl = (int)(tr & 63u); cx = (int)((tr >> 6) & 7u);
+            }
+            if (ns) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < ns) {   // the run's outputs, one lane per step
+                    const uint32_t ce = chain[lane];
+                    const int l2 = (int)(ce & 63u), col = wcol0(l2) + (int)(ce >> 6);
+                    if (PAIRS) { g_pair_row[n + lane] = wtop - l2; g_pair_pos[n + lane] = col - 1; }
+                    if (posnode) g_posnode[col - 1] = (int)(win[l2 * TBW_STRIDE + EO_NODE] & 0x00ffffffu);
+                }
+                n += ns;
+                i = wtop - cl; j = wcol0(cl) + cx;
+                hv = sext(TBU(win[cl * TBW_STRIDE + cx]));
+#ifdef SXG_ROW_PROF
+                tb_steps += (unsigned long long)(ns - 1);
+#endif
+                continue;
             }
         }
         // Everything the walk reads is the same for all lanes; saying so (readfirstlane) keeps its state

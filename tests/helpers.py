@@ -62,3 +62,66 @@ def assert_block_equal(res, g, scores, cells, label=""):
     assert (res.edge_weight == w).all(), f"{label}: edge weights differ"
     for s in range(g.n_seqs):
         assert (res.paths[s] == g.seq_path(s)).all(), f"{label}: path {s} differs"
+
+
+def heaviest_bundle_independent(code, rank, edge_tail, edge_head, edge_weight):
+    """Lee 2003 heaviest bundle with branch completion, written independently of oracle/poa_oracle.c and of the device
+    code (which share their text): rank-space CSR of in-edges, the best in-edge of a node is the maximum of the key
+    (weight, score of the tail, position in the node's in-list) over the tails that are still alive, scores are
+    accumulated in rank order, and a consensus that ends inside the graph is completed by killing the rival tails
+    of its successors and re-running the relaxation behind it.  Returns node ids in path order."""
+    n = len(code)
+    if n == 0:
+        return np.zeros(0, np.int32)
+    order = np.argsort(rank)
+    ins = [[] for _ in range(n)]          # per node: (weight, tail) in edge-insertion order
+    outs = [[] for _ in range(n)]
+    for t, h, w in zip(edge_tail.tolist(), edge_head.tolist(), edge_weight.tolist()):
+        ins[h].append((w, t))
+        outs[t].append(h)
+    score = [-1] * n
+    back = [-1] * n
+    dead = [False] * n
+
+    def relax(v):
+        cands = [(w, score[t], k, t) for k, (w, t) in enumerate(ins[v]) if not dead[t]]
+        if not cands:
+            score[v], back[v] = -1, -1
+            return
+        w, s, _, t = max(cands)
+        score[v], back[v] = w + s, t
+
+    best = None
+    for v in order.tolist():
+        cands = [(w, score[t], k, t) for k, (w, t) in enumerate(ins[v])]
+        if cands:
+            w, s, _, t = max(cands)
+            score[v], back[v] = w + s, t
+        else:
+            score[v], back[v] = -1, -1
+        if best is None or score[v] > score[best]:
+            best = v
+    while outs[best]:
+        start = best
+        for h in outs[start]:
+            for _, t in ins[h]:
+                if t != start:
+                    dead[t] = True
+                    score[t] = -1
+        nxt, top = None, 0
+        for v in order[rank[start] + 1:].tolist():
+            dead[v] = False
+            relax(v)
+            if score[v] == -1:
+                dead[v] = True
+            if score[v] > top:
+                top, nxt = score[v], v
+        if nxt is None:
+            break
+        best = nxt
+    path = []
+    v = best
+    while v != -1:
+        path.append(v)
+        v = back[v]
+    return np.asarray(path[::-1], np.int32)

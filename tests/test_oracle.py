@@ -321,3 +321,18 @@ def test_threaded_block_driver_with_workspaces(oracle):
         seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[blk], blk_off[blk + 1])]
         g, sc, _ = oracle.block_run(seqs, None, p)
         assert (a[0][blk_off[blk]:blk_off[blk + 1]] == sc).all() and a[2][blk] == g.n_nodes
+
+
+def test_consensus_against_an_independent_heaviest_bundle(oracle):
+    """The oracle's consensus (and the device's, which shares its text) against tests/helpers.heaviest_bundle_independent,
+    written from Lee 2003 in a different form: deep blocks, weights, two-letter alphabets (many weight ties)."""
+    from helpers import heaviest_bundle_independent
+    rng = np.random.default_rng(77)
+    for trial in range(60):
+        S = int(rng.integers(2, 20))
+        seqs = random_block(rng, S, int(rng.integers(5, 200)), div=(0.05, 0.15, 0.3)[trial % 3], alphabet=(2, 4)[trial % 2])
+        w = rng.integers(1, 4, len(seqs))
+        g, _, _ = oracle.block_run(seqs, w, oparams("convex_default", trial % 2))
+        code, rank, _ = g.nodes()
+        t, h, ww = g.edges()
+        assert (heaviest_bundle_independent(code, rank, t, h, ww) == g.consensus()).all(), trial
