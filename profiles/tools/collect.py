@@ -20,10 +20,14 @@ row = [r for r in csv.DictReader(open(stats)) if "poa_block" in r["Name"]][0]
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.path.join(OUT, "prof_pmc_" + c, "*counter_collection.csv"))[0]
-    vals[c] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                  if "poa_block" in r["Kernel_Name"] and r["Counter_Name"] == c)
+    rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "poa_block" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    vals[c] = sum(rows) / len(rows)   # per launch: mean over the run's launches (warm-up + timed)
     shutil.copy(f, os.path.join(dst, "ns_sw_pmc_%s.csv" % c))
 shutil.copy(stats, os.path.join(dst, "ns_sw_kernel_stats.csv"))
+# every launch of the dominant kernel in the stats run (the first one is the warm-up: it first-touches the arenas)
+tr = glob.glob(os.path.join(OUT, "prof_stats", "*kernel_trace.csv"))
+launch_ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(tr[0]))
+             if r["Kernel_Name"] == row["Name"]] if tr else []
 F, W = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 traffic = {"ns_sw": {
     "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python bench.py --workload ns "
@@ -37,14 +41,16 @@ traffic = {"ns_sw": {
     "hbm_bytes_per_launch": (2 * F + W) * 1024, "hbm_bytes_per_launch_uncorrected": (F + W) * 1024}}
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 
-agg = {}
+agg, cnt = {}, {}
 for d in sorted(glob.glob(os.path.join(OUT, "pmc16_*/"))):
     for f in glob.glob(d + "*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if "poa_block" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]] = agg.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                cnt[r["Counter_Name"]] = cnt.get(r["Counter_Name"], 0) + 1
+agg = {k: v / cnt[k] for k, v in agg.items()}   # per launch: mean over the run's launches
 if agg:
-    json.dump({"command": "profiles/run_sq_pmc.sh (one launch of the ns workload, kernel %s)" % row["Name"], "counters": agg},
+    json.dump({"command": "profiles/run_sq_pmc.sh (ns workload, mean over %d launches, kernel %s)" % (max(cnt.values()), row["Name"]), "counters": agg},
               open(os.path.join(dst, "ns_sw_sq_counters.json"), "w"), indent=1)
 b = os.path.join(OUT, "bench_ns_sw.json")
 if os.path.exists(b):
@@ -53,10 +59,10 @@ if os.path.exists(b):
     import bench
     counters = {"source_sha256": bench.source_hash(),
                 "collected_with": "profiles/run_pmc.sh + profiles/run_sq_pmc.sh (rocprofv3 --kernel-trace --pmc, one counter "
-                                  "group per run, one launch of the workload each)",
+                                  "group per run; per-launch means over the warm-up and the timed launch)",
                 "workloads": {"ns_sw": {
                     "kernel": row["Name"], "cells_per_launch": d["config"]["cells_per_step_per_gpu"],
-                    "kernel_ms_avg_rocprof": float(row["AverageNs"]) / 1e6,
+                    "kernel_ms_avg_rocprof": float(row["AverageNs"]) / 1e6, "kernel_ms_per_launch_rocprof": launch_ms,
                     "SQ_INSTS_VALU": agg.get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": agg.get("SQ_INSTS_SALU"),
                     "SQ_WAVE_CYCLES": agg.get("SQ_WAVE_CYCLES"), "SQ_BUSY_CYCLES": agg.get("SQ_BUSY_CYCLES"),
                     "FETCH_SIZE_KB": F, "WRITE_SIZE_KB": W, "hbm_bytes_per_launch": (2 * F + W) * 1024,

@@ -204,6 +204,11 @@ inline uint8_t code_of(char ch) {
 // ---------------------------------------------------------------------------------------------
 // output-side graph (odgi::graph_t's role): nodes, bidirected edges, named paths
 typedef std::pair<handle_t, handle_t> edge_t;
+// graphs above this many nodes take the OpenMP forms of unchop / sort / GFA text (SXG_SMOOTH_PAR_MIN: tests force them on small graphs)
+inline size_t par_min() {
+    static const size_t v = getenv("SXG_SMOOTH_PAR_MIN") ? (size_t)atoll(getenv("SXG_SMOOTH_PAR_MIN")) : 100000;
+    return v;
+}
 struct ograph_t {
     std::vector<std::string> seq;                       // node i has id i+1
     std::vector<edge_t> edges;                          // canonical form, sorted, unique
@@ -214,7 +219,7 @@ struct ograph_t {
     }
     void sort_edges() {
         if (!std::is_sorted(edges.begin(), edges.end())) {
-            if (edges.size() > 200000) __gnu_parallel::sort(edges.begin(), edges.end());
+            if (edges.size() > 2 * par_min()) __gnu_parallel::sort(edges.begin(), edges.end());
             else std::sort(edges.begin(), edges.end());
         }
         edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
@@ -254,11 +259,23 @@ struct edge_acc_t {
 // rewritten in parallel (the laced graph of the headline workload walks 1.6e8 steps).
 void unchop(ograph_t& G) {
     const size_t n = G.seq.size();
+    const int64_t ne = (int64_t)G.edges.size();
+    const bool par = n > par_min();   // (the laced graph of the headline workload: 1.4e7 nodes, 2e7 edges, 1.6e8 steps)
     std::vector<uint32_t> deg(2 * n, 0);
     std::vector<handle_t> only(2 * n, 0);
-    for (auto& e : G.edges) {
-        deg[e.first]++; only[e.first] = e.second;
-        deg[flip(e.second)]++; only[flip(e.second)] = flip(e.first);
+#pragma omp parallel for schedule(static) if (par)
+    for (int64_t x = 0; x < ne; ++x) {
+        const edge_t& e = G.edges[(size_t)x];
+        const handle_t a = e.first, b = flip(e.second);
+#pragma omp atomic
+        deg[a]++;
+#pragma omp atomic
+        deg[b]++;
+        // (`only` is read only where the degree is 1, i.e. where exactly one edge wrote it)
+#pragma omp atomic write
+        only[a] = e.second;
+#pragma omp atomic write
+        only[b] = flip(e.first);
     }
     std::vector<char> start_at(2 * n, 0), end_at(2 * n, 0);
     for (auto& p : G.paths) {
@@ -267,7 +284,10 @@ void unchop(ograph_t& G) {
         end_at[p.second.back()] = 1; start_at[flip(p.second.back())] = 1;
     }
     std::vector<int64_t> next(n, -1), prev(n, -1);
-    for (size_t u = 0; u < n; ++u) {
+    // (a node v is the target of at most one u: v's left side has the single edge from u+)
+#pragma omp parallel for schedule(static) if (par)
+    for (int64_t uu = 0; uu < (int64_t)n; ++uu) {
+        const size_t u = (size_t)uu;
         const handle_t uf = mk(u, false);
         if (deg[uf] != 1) continue;
         const handle_t vf = only[uf];
@@ -277,37 +297,66 @@ void unchop(ograph_t& G) {
         if (end_at[uf] || start_at[vf] || end_at[flip(vf)] || start_at[flip(uf)]) continue;
         next[u] = (int64_t)v; prev[v] = (int64_t)u;
     }
-    // break pure cycles at their smallest member
+    // chains hang off their heads (no predecessor); what no head reaches is a pure cycle, broken at its smallest member
+    std::vector<int64_t> chain_of(n, -1);
+    std::vector<size_t> heads;
     {
-        std::vector<char> seen(n, 0);
-        for (size_t u = 0; u < n; ++u) {
-            if (seen[u] || prev[u] < 0) continue;
-            size_t x = u; bool cyc = false;
-            std::vector<size_t> walk;
-            while (true) { seen[x] = 1; walk.push_back(x); if (prev[x] < 0) break; x = (size_t)prev[x]; if (x == u) { cyc = true; break; } if (seen[x]) break; }
-            if (cyc) { size_t m = *std::min_element(walk.begin(), walk.end()); next[(size_t)prev[m]] = -1; prev[m] = -1; }
+        std::vector<char> reached(n, 0);
+#pragma omp parallel for schedule(dynamic, 4096) if (par)
+        for (int64_t uu = 0; uu < (int64_t)n; ++uu) {
+            if (prev[(size_t)uu] >= 0) continue;
+            for (size_t x = (size_t)uu;; x = (size_t)next[x]) { reached[x] = 1; if (next[x] < 0) break; }
         }
+        for (size_t u = 0; u < n; ++u) {
+            if (reached[u]) continue;
+            size_t m = u;   // u is the smallest member: smaller ones would have been met (and marked) first
+            for (size_t x = (size_t)next[u]; x != u; x = (size_t)next[x]) reached[x] = 1;
+            reached[u] = 1;
+            next[(size_t)prev[m]] = -1; prev[m] = -1;
+        }
+        for (size_t u = 0; u < n; ++u) if (prev[u] < 0) heads.push_back(u);
     }
-    std::vector<int64_t> chain_of(n, -1), first_of, last_of;
-    std::vector<std::string> nseq;
-    for (size_t u = 0; u < n; ++u) {
-        if (prev[u] >= 0) continue;
-        const int64_t c = (int64_t)nseq.size();
-        std::string s;
+    const int64_t nc = (int64_t)heads.size();
+    std::vector<int64_t> first_of((size_t)nc), last_of((size_t)nc);
+    std::vector<std::string> nseq((size_t)nc);
+#pragma omp parallel for schedule(dynamic, 4096) if (par)
+    for (int64_t c = 0; c < nc; ++c) {
+        const size_t u = heads[(size_t)c];
         size_t x = u, last = u;
-        while (true) { chain_of[x] = c; s += G.seq[x]; last = x; if (next[x] < 0) break; x = (size_t)next[x]; }
-        nseq.push_back(std::move(s)); first_of.push_back((int64_t)u); last_of.push_back((int64_t)last);
+        if (next[u] < 0) { chain_of[u] = c; nseq[(size_t)c].swap(G.seq[u]); }
+        else {
+            std::string s;
+            while (true) { chain_of[x] = c; s += G.seq[x]; last = x; if (next[x] < 0) break; x = (size_t)next[x]; }
+            nseq[(size_t)c].swap(s);
+        }
+        first_of[(size_t)c] = (int64_t)u; last_of[(size_t)c] = (int64_t)last;
     }
     auto map_handle = [&](handle_t h) { return mk((uint64_t)chain_of[nid(h)], rev(h)); };
+    // surviving edges, mapped: counted and written per chunk so that the order of G.edges is kept
     std::vector<edge_t> nedges;
-    nedges.reserve(G.edges.size());
-    for (auto& e : G.edges) {
-        const size_t a = nid(e.first), b = nid(e.second);
-        if (!rev(e.first) && !rev(e.second) && next[a] == (int64_t)b) continue;  // interior of a chain
-        nedges.push_back(ograph_t::canon(map_handle(e.first), map_handle(e.second)));
+    {
+        const int64_t CHK = 1 << 16, nch = (ne + CHK - 1) / CHK;
+        std::vector<size_t> cnt((size_t)nch + 1, 0);
+        auto interior = [&](const edge_t& e) { return !rev(e.first) && !rev(e.second) && next[nid(e.first)] == (int64_t)nid(e.second); };
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t q = 0; q < nch; ++q) {
+            size_t k = 0;
+            for (int64_t x = q * CHK; x < std::min(ne, (q + 1) * CHK); ++x) k += interior(G.edges[(size_t)x]) ? 0 : 1;
+            cnt[(size_t)q + 1] = k;
+        }
+        for (int64_t q = 0; q < nch; ++q) cnt[(size_t)q + 1] += cnt[(size_t)q];
+        nedges.resize(cnt[(size_t)nch]);
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t q = 0; q < nch; ++q) {
+            size_t w = cnt[(size_t)q];
+            for (int64_t x = q * CHK; x < std::min(ne, (q + 1) * CHK); ++x) {
+                const edge_t& e = G.edges[(size_t)x];
+                if (!interior(e)) nedges[w++] = ograph_t::canon(map_handle(e.first), map_handle(e.second));
+            }
+        }
     }
     const int64_t np = (int64_t)G.paths.size();
-#pragma omp parallel for schedule(dynamic, 1) if (n > 100000)
+#pragma omp parallel for schedule(dynamic, 1) if (par)
     for (int64_t q = 0; q < np; ++q) {
         auto& st = G.paths[(size_t)q].second;
         size_t w = 0;
@@ -384,7 +433,7 @@ char* to_gfa_c(const ograph_t& G, size_t* out_len) {
     const size_t pieces = 1 + nch + ech + np;
     // pass 1: the exact size of every piece (counting digits touches no output memory)
     std::vector<size_t> off(pieces + 1, 0);
-    const bool par = n > 100000;
+    const bool par = n > par_min();
     static const char head[] = "H\tVN:Z:1.0\n";
     off[1] = sizeof(head) - 1;
 #pragma omp parallel for schedule(dynamic, 1) if (par)

@@ -508,3 +508,22 @@ def test_flip_changes_the_gfa_exactly_as_the_restatement_says(prov):
         assert got[0] == want[0] and got[1] == want[1] and got[2] == len(want[2])
         if got[2]:
             assert got[0] != plain
+
+
+def test_parallel_forms_of_unchop_and_gfa_writer_equal_the_serial_ones():
+    """unchop, the edge sort and the GFA writer switch to their OpenMP forms above 100 000 nodes (the laced graph of the
+    headline workload); SXG_SMOOTH_PAR_MIN=0 forces them on a small graph in a fresh process: same bytes."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_smooth_host as H\nfrom smoothxg_amd import smooth as S\n"
+            "text = H.haplotype_gfa(11, n_paths=6, length=1500)\n"
+            "sm = S.Smoother(text, 300)\n"
+            "sys.stdout.write(sm.smooth_gfa(S.default_params(add_consensus=1), H.OracleProvider().provider()))\n"
+            % (HERE, os.path.dirname(HERE)))
+    outs = []
+    for env in ({}, {"SXG_SMOOTH_PAR_MIN": "0", "OMP_NUM_THREADS": "4"}):
+        e = dict(os.environ)
+        e.update(env)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True, timeout=600).stdout)
+    assert outs[0] == outs[1] and outs[0].startswith("H\tVN:Z:1.0")
