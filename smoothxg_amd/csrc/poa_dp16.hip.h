@@ -263,63 +263,66 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         P16_LOAD_LEFT(rs_, hl_);                                                                            \
     } while (0)
 
+// Every branch that loaded a stored row ends by draining its loads itself.  Otherwise the compiler, which cannot know
+// at the join which branch ran, waits for vmcnt(0) at the top of pass 1 of EVERY row (a loaded register that a branch
+// did not consume is reused there) -- and on gfx9 vmcnt also counts stores, so rows that read nothing waited for the
+// write acknowledgements of the previous row's ring and band stores.
+#define P16_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0), expcnt / lgkmcnt untouched */
+        // The diagonal sources are left WHERE THEY ARE -- Hp[k] = max over the predecessors of their H in column k,
+        // Hleft the column left of the strip -- and pass 1 walks the strip right to left, so that column k's new value
+        // can take the register of Hp[k] (dead once column k+1 has used it): the shifted copy Hc[k] = Hp[k-1] that an
+        // ascending pass needs cost 11-23 v_mov per row.
         if (np <= 1 && p0 == i - 1) {
             // register predecessor: its outgoing candidates ARE this row's F and O
-#pragma unroll
-            for (int k = 0; k < W; ++k) Hc[k] = k ? Hp[k - 1] : Hleft;
         } else if (sib) {
             u32x2 wr[W];
             int hl;
             P16_FETCH(p0, s0, wr, hl);
-            Hc[0] = hl;
+            Hleft = hl;
 #pragma unroll
-            for (int k = 1; k < W; ++k) Hc[k] = (int)wr[k - 1].x;
+            for (int k = 0; k < W; ++k) Hp[k] = (int)wr[k].x;
+            P16_DRAIN();
         } else {
             // Several predecessors: D, F and O are plain maxima over them (which predecessor won is
             // re-derived by the traceback), so the fold order is free: the register row first.
             const bool reg0 = (p0 == i - 1), reg1 = (np == 2 && p1 == i - 1);
             const bool park = np >= 3;
-            P16_LROW(lrow_t);   // my slice of the parked / prefetched row
+            const int Hleft_reg = Hleft;   // the register row's left column (a parked row is folded later)
+            P16_LROW(lrow_t);   // my slice of the parked row
             if (park) {
 #pragma unroll
                 for (int k = 0; k < W; ++k) lrow_t[k] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
             }
-            if ((reg0 || reg1) && !park) {
-#pragma unroll
-                for (int k = 0; k < W; ++k) Hc[k] = k ? Hp[k - 1] : Hleft;
-            } else {
+            if (!reg0 && !(reg1 && !park)) {
                 u32x2 wr[W];
-                int hl = Hleft;
-                if (reg0) {
-#pragma unroll
-                    for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];
-                } else P16_FETCH(p0, s0, wr, hl);
+                int hl;
+                P16_FETCH(p0, s0, wr, hl);
+                Hleft = hl;
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    int hs;
-                    p16_unpack_row(wr[k], hs, Fp[k], Op[k]);
-                    Hc[k] = hl;
-                    hl = hs;
-                    SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));
+                    p16_unpack_row(wr[k], Hp[k], Fp[k], Op[k]);
+                    SXG_PIN("+v"(Hp[k]), "+v"(Fp[k]), "+v"(Op[k]));
                 }
+                P16_DRAIN();
             }
 // fold one more predecessor row (p_, slot sl_) into the running maxima
 #define P16_FOLD(p_, sl_)                                                                                   \
     do {                                                                                                    \
         u32x2 wr[W];                                                                                        \
-        int hl = Hleft;                                                                                     \
+        int hl = Hleft_reg;                                                                                 \
         if ((p_) == i - 1) {                                                                                \
             _Pragma("unroll") for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];                                \
         } else P16_FETCH(p_, sl_, wr, hl);                                                                  \
+        Hleft = pk_max(Hleft, hl);                                                                          \
         _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                     \
             int hs, fs, os;                                                                                 \
             p16_unpack_row(wr[k], hs, fs, os);                                                              \
             Fp[k] = pk_max(Fp[k], fs);                                                                      \
             if (CVX) Op[k] = pk_max(Op[k], os);                                                             \
-            Hc[k] = pk_max(Hc[k], hl);                                                                      \
-            hl = hs;                                                                                        \
-            SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));                                       \
+            Hp[k] = pk_max(Hp[k], hs);                                                                      \
+            SXG_PIN("+v"(Hp[k]), "+v"(Fp[k]), "+v"(Op[k]));                                                 \
         }                                                                                                   \
+        if ((p_) != i - 1) P16_DRAIN();                                                                     \
     } while (0)
             // (the second predecessor in straight-line code: two-predecessor rows -- the closing node of every
             // bubble -- are a third of all rows; the loop form made the allocator spill around them)
@@ -333,6 +336,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
                 P16_FOLD(p, sl);
             }
 #undef P16_FOLD
+#undef P16_DRAIN
         }
 #undef P16_FETCH
         if (!CVX) {
@@ -347,10 +351,10 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
 #pragma unroll
             for (int k2 = 0; k2 < NL; ++k2) let[k2] = ((lds_u32*)(size_t)lo_)[k2];
         }
-        // ---- pass 1: H before the in-row gaps, strip-local carries
+        // ---- pass 1 (right to left): H before the in-row gaps, strip-local carries
         int a = NEG2, b = NEG2;
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
+        for (int k = W - 1; k >= 0; --k) {
             // letters (lo_k, hi_k) of column k as a packed pair; 0 where they equal the node letter
             const unsigned x4 = let[k >> 1] ^ CODE4;
             const int lp = (int)__builtin_amdgcn_perm(0u, x4, (k & 1) ? 0x0c030c02u : 0x0c010c00u);
@@ -358,16 +362,19 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             // rewrites the multiply-add below into two compares, two selects and a byte merge.
             int nm;
             asm("v_pk_min_u16 %0, %1, %2" : "=v"(nm) : "v"(lp), "v"(ONE2));
-            int h = pk_mad(nm, MN2, pk_add(Hc[k], M2));    // diagonal + (match ? m : n)
+            int h = pk_mad(nm, MN2, pk_add(k ? Hp[k - 1] : Hleft, M2));    // diagonal + (match ? m : n)
             h = pk_max(h, Fp[k]);
             if (CVX) h = pk_max(h, Op[k]);
             Hc[k] = h;
-            // a' = max_k (h_k + (W-1-k) e) as a running "extend, or restart here"; the opening cost
-            // and the local-alignment clamp (whose best term is k = W-1) are applied once per row below
-            a = pk_max(pk_add(a, E2), h);
-            if (CVX) b = pk_max(pk_add(b, C2), h);
+            // a = max_k' (h_k' - (k'-k) e) over the columns k' >= k done so far: "the gap is e longer, or restarts here";
+            // shifted by (W-1) e below it is max_k (h_k + (W-1-k) e), the carry the strip hands on.  The opening cost
+            // and the local-alignment clamp (whose best term is k = W-1) are applied once per row
+            a = pk_max(pk_sub(a, E2), h);
+            if (CVX) b = pk_max(pk_sub(b, C2), h);
             SXG_PIN("+v"(Hc[k]), "+v"(a), "+v"(b));
         }
+        a = pk_add(a, pk2((W - 1) * e, (W - 1) * e));
+        if (CVX) b = pk_add(b, pk2((W - 1) * c, (W - 1) * c));
         if (SW) { a = pk_max(a, 0); if (CVX) b = pk_max(b, 0); }
         a = pk_add(a, G2);
         if (CVX) b = pk_add(b, Q2);
