@@ -50,11 +50,15 @@ extern "C" {
 #define SXG_ST_POOL_OVERFLOW 2
 #define SXG_ST_TBX_OVERFLOW 3
 #define SXG_ST_NODES_OVERFLOW 4
-#define SXG_ST_TOO_LONG 5 /* a sequence exceeds SXG_POA_MAX_SEQ_LEN */
+#define SXG_ST_TOO_LONG 5 /* a sequence exceeds SXG_POA_MAX_SEQ_LEN (local) / SXG_POA_MAX_SEQ_LEN_WIDE (see below) */
 #define SXG_ST_RANGE_OVERFLOW 6 /* internal: scores left the narrow sweep's range; the engine re-runs the block wider */
 #define SXG_ST_BAND_MISS 7      /* internal: the packed sweep's traceback left its band of kept cells; re-run wider */
 
-#define SXG_POA_MAX_SEQ_LEN 12287
+/* Longest sequence.  Local alignment (smoothxg's default) with m * length < 30000 runs the packed int16 sweep, whose
+ * largest workgroup covers 2 * 1024 * 13 columns: enough for -l 13k cut at -q 2 * 13k (src/main.cpp:376) plus padding.
+ * Global alignment and score sets outside the int16 range need the 32-bit sweep: 1024 lanes * 12 columns. */
+#define SXG_POA_MAX_SEQ_LEN 26623
+#define SXG_POA_MAX_SEQ_LEN_WIDE 12287
 
 /* The six scores + alignment type that smooth_spoa hands to
  * spoa::AlignmentEngine::Create (src/smooth.cpp:752-755).                                */

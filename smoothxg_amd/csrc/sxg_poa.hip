@@ -437,11 +437,13 @@ struct Variant {
 // (W, NW) pairs that cover the sequence pick the one with the fewest padded columns, then the
 // wider strip (less per-row overhead).  Strip widths are bounded by VGPRs: 32-bit sweep 16
 // columns (~165 VGPRs, <= 512 threads) / 12 (128 VGPRs); packed sweep 12 (~152) / 8 (124).
-static bool variant_for_len(int maxlen, int rm, Variant* v) {
+// Long local alignments (sequences of 12-26 kbp: smoothxg runs with -l 13k cut at 2 * 13k) get 16-wave workgroups of the
+// packed sweep with 10, 12 or 13 columns per strip (128 VGPRs, a handful of spill slots): 20 480 / 24 576 / 26 624 columns.
+static bool variant_for_len(int maxlen, int rm, Variant* v, bool sw = false) {
     static const int kNW[] = {1, 2, 3, 4, 8, 12, 16};
-    static const int kW32[] = {16, 12, 8}, kW16[] = {12, 11, 10, 9, 8};
+    static const int kW32[] = {16, 12, 8}, kW16[] = {13, 12, 11, 10, 9, 8};
     const int* ws = rm == 2 ? kW16 : kW32;
-    const int nws = rm == 2 ? 5 : 3;
+    const int nws = rm == 2 ? 6 : 3;
     const int need = maxlen + 1;
     long best_cols = -1;
     for (int wi = 0; wi < nws; ++wi)
@@ -449,8 +451,10 @@ static bool variant_for_len(int maxlen, int rm, Variant* v) {
             const int W = ws[wi];
             const long cols = 64L * NW * W * (rm == 2 ? 2 : 1);
             if (cols < need) continue;
-            const bool wide = rm == 2 ? W > 8 : W > 12;   // needs > 128 VGPRs
-            if (wide && NW > 8) continue;
+            const bool wide = rm == 2 ? W > 8 : W > 12;   // needs > 128 VGPRs unless squeezed
+            const bool long_class = rm == 2 && sw && NW == 16 && (W == 10 || W == 12 || W == 13);
+            if (W == 13 && !long_class) continue;
+            if (wide && NW > 8 && !long_class) continue;
             if (best_cols < 0 || cols < best_cols) {
                 best_cols = cols;
                 *v = Variant{W, NW, NW <= 4 ? 256 : (NW <= 8 ? 512 : 1024), rm};
@@ -479,6 +483,9 @@ template <int TMAX, int W, int RM> static KernelFn<AlignArgs> pick_align(bool cv
     } while (0)
 #define SXG_PICK16(FN, TM, Wd) \
     do { if (v.TMAX == TM && v.W == Wd && v.RM == 2) return FN<TM, Wd, 2>(cvx, sw); } while (0)
+// (the long classes exist for local alignment only: a global score of such lengths does not fit int16)
+#define SXG_PICK16_SW(KERN, TM, Wd) \
+    do { if (v.TMAX == TM && v.W == Wd && v.RM == 2 && sw) return cvx ? KERN<TM, Wd, true, 2, true> : KERN<TM, Wd, false, 2, true>; } while (0)
 // SXG_DEV_ONLY_W=<w>: development builds instantiate a single packed class (seconds instead of minutes)
 static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
     if (v.RM == 3) return cvx ? poa_block_kernel<64, 11, true, 3, true> : poa_block_kernel<64, 11, false, 3, true>;
@@ -493,6 +500,7 @@ static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
     SXG_PICK16(pick_block, 512, 8); SXG_PICK16(pick_block, 512, 9); SXG_PICK16(pick_block, 512, 10);
     SXG_PICK16(pick_block, 512, 11); SXG_PICK16(pick_block, 512, 12);
     SXG_PICK16(pick_block, 1024, 8);
+    SXG_PICK16_SW(poa_block_kernel, 1024, 10); SXG_PICK16_SW(poa_block_kernel, 1024, 12); SXG_PICK16_SW(poa_block_kernel, 1024, 13);
 #endif
     return nullptr;
 }
@@ -508,6 +516,7 @@ static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool sw) {
     SXG_PICK16(pick_align, 512, 8); SXG_PICK16(pick_align, 512, 9); SXG_PICK16(pick_align, 512, 10);
     SXG_PICK16(pick_align, 512, 11); SXG_PICK16(pick_align, 512, 12);
     SXG_PICK16(pick_align, 1024, 8);
+    SXG_PICK16_SW(poa_align_kernel, 1024, 10); SXG_PICK16_SW(poa_align_kernel, 1024, 12); SXG_PICK16_SW(poa_align_kernel, 1024, 13);
 #endif
     return nullptr;
 }
@@ -531,6 +540,8 @@ static bool p16_safe(const Scoring& S, int maxlen, int rows) {
     if (getenv("SXG_POA_NO_PACKED")) return false;
     // stored rows keep H - max(H+g, F+e) and H - max(H+q, O+c) in one byte each
     if (std::abs(S.g) > 120 || std::abs(S.q) > 120) return false;
+    // local alignment: every existing cell has 0 <= H <= m * L and F, O, E, Q >= -|q|; the range is one-sided
+    if (S.sw) return (long)std::abs(S.m) * maxlen < 30000;
     return (long)std::abs(S.m) * maxlen < 15800 && score_floor(S, maxlen, rows) < 15800;
 }
 // narrowest mode >= `at_least` (2 = packed < 0 = int16 row words < 1 = int32 row words)
@@ -733,7 +744,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
             prev += (double)len;
         }
         m.rm = row_mode(m.S, m.maxlen, m.maxlen);  // optimistic; the kernel re-checks (see score_floor)
-        m.fits = variant_for_len(m.maxlen, m.rm, &m.variant);
+        m.fits = variant_for_len(m.maxlen, m.rm, &m.variant, m.S.sw);
         // A11: the reference's abPOA path is banded (wb=311, wf=0.03); local alignments whose scores fit the packed
         // sweep run the one-wave banded kernel, everything else asked to be banded runs the full matrix
         if (h->h_params[in->per_block_params ? b : 0].banded && m.S.sw && m.rm == 2 && m.maxlen <= SXG_POA_MAX_SEQ_LEN) {
@@ -1128,7 +1139,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
                 // one step wider at the same capacity tier: packed -> int16 row words -> int32 row words
                 if (m.rm != 1) {
                     m.rm = row_mode(m.S, m.maxlen, m.maxlen, m.rm >= 2 ? 0 : 1);
-                    m.fits = variant_for_len(m.maxlen, m.rm, &m.variant);
+                    m.fits = variant_for_len(m.maxlen, m.rm, &m.variant, m.S.sw);
                     if (m.fits) again.push_back(b);  // (the wider sweeps cover every length the packed one does)
                     else status[b] = ST_TOO_LONG;
                 } else status[b] = ST_TOO_LONG;      // (unreachable: the int32 sweep reports neither)
@@ -1782,7 +1793,7 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         const Scoring S = normalise(in->params[in->per_problem_params ? p : 0]);
         const int len = (int)(in->seq_off[p + 1] - in->seq_off[p]), N = (int)(in->row_off[p + 1] - in->row_off[p]);
         Variant v;
-        if (!variant_for_len(len, row_mode(S, len, N), &v)) { o->status[p] = ST_TOO_LONG; continue; }
+        if (!variant_for_len(len, row_mode(S, len, N), &v, S.sw)) { o->status[p] = ST_TOO_LONG; continue; }
         APlan* pl = nullptr;
         for (auto& q : plans)
             if (q.variant.W == v.W && q.variant.NW == v.NW && q.variant.RM == v.RM && q.cvx == (bool)S.convex && q.sw == (bool)S.sw) { pl = &q; break; }

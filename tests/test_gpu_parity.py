@@ -104,6 +104,21 @@ def test_too_long_is_reported_not_crashed(engine):
     assert res[0].status == 5
 
 
+def test_local_alignments_beyond_12_kbp_run_the_16_wave_packed_classes(engine, oracle):
+    """smoothxg with -l 13k cuts ranges at 26 kbp (src/main.cpp:376): local alignments of 12-26 kbp run 1024-thread packed
+    classes (8, 10, 12, 13 columns per strip); a global alignment of such a length has no sweep and is reported."""
+    rng = np.random.default_rng(1213)
+    blocks = [random_block(rng, 3, L, div=0.02) for L in (14000, 18500, 23000, 26300)]
+    res = engine.run_blocks(blocks, gparams("convex_default", 0))
+    st = engine.stats()
+    for b, seqs in enumerate(blocks):
+        g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
+        assert_block_equal(res[b], g, sc, cells, label=f"long-local{len(seqs[0])}")
+    assert st["dom_row_mode"] == 2
+    far = engine.run_blocks([blocks[0]], gparams("convex_default", 1), check=False)
+    assert far[0].status == 5
+
+
 def test_invalid_arguments(engine):
     import smoothxg_amd as S
     with pytest.raises(S.PoaError):
