@@ -82,3 +82,15 @@ def test_global_alignment_ignores_the_band_flag(engine):
     gg, sc, cells = O.block_run(seqs, None, O.mkparams(m, n, g, e, q, c, mode=1, banded=1))
     assert_block_equal(res, gg, sc, cells, label="global+band flag")
     assert engine.stats()["dom_row_mode"] != 3
+
+
+def test_banded_beyond_12_kbp(engine):
+    """The window slides over any length the packed range allows: 15 and 24 kbp blocks in banded mode."""
+    rng = np.random.default_rng(1500)
+    blocks = [random_block(rng, 3, L, div=0.02) for L in (15000, 24000)]
+    gp, op = _p("affine_4param")
+    res = engine.run_blocks(blocks, gp)
+    assert engine.stats()["dom_row_mode"] == 3
+    for b, seqs in enumerate(blocks):
+        g, sc, cells = O.block_run(seqs, None, op)
+        assert_block_equal(res[b], g, sc, cells, label=f"banded-long{len(seqs[0])}")
