@@ -10,9 +10,10 @@ local alignment (the reference's defaults, src/main.cpp:322-327,487).
     python bench.py --gpus N --steps K --warmup W [--workload ns|c2|c3|tiny] [--mode sw|nw]
 
 N>1: launched by torch.distributed.run, one rank per GPU; blocks are independent, so each
-rank owns its own 1000 blocks (weak scaling) and only the per-block result summaries are
-all-gathered over RCCL at the end of every step (reassembly hand-off for lacing).
-Rank 0 prints ONE JSON line.
+rank owns its own 1000 blocks (weak scaling; --scaling strong deals ONE workload by LPT) and the
+only exchange is the reassembly hand-off for lacing at the end of every step: every peer sends its
+per-block summaries and per-base node paths to rank 0, device to device, one exact-size message
+each (grouped ncclSend/ncclRecv over xGMI, shard.RootGather).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -284,10 +285,14 @@ def main():
     eng = S.PoaEngine(local_rank)
     eng.upload(bases, seq_off, blk_off, None, params)  # inputs resident in HBM from here on
 
+    to_root = shard.RootGather() if world > 1 else None
+
     def step():
         eng.execute()
         if world > 1:
-            shard.all_gather_block_summaries(eng, n_local)
+            # the one real exchange of the path: results meet on the rank that laces (rank 0), device to device,
+            # one exact-size message per peer over its own xGMI link; nothing is all-gathered
+            to_root(shard.engine_result_tensors(eng))
 
     def fence():
         torch.cuda.synchronize()

@@ -94,6 +94,61 @@ def all_gather_block_summaries(eng, n_blocks, group=None, with_paths=True):
     return summ, paths
 
 
+class RootGather:
+    """The reassembly hand-off as the lacing needs it: only rank 0 laces, so every peer sends its results to rank 0 and
+    nobody else receives anything.  Point to point (grouped ncclSend / ncclRecv: all 7 xGMI links into rank 0 carry one
+    peer each), one exact-size message per tensor, receive buffers allocated once and reused -- the device-side twin
+    of sxg_poa_batch_run_sharded's host-side blobs.  `__call__` takes the local tensors (any device / backend) and
+    returns, on rank 0, one list of tensors per rank (rank 0's own are the inputs themselves); None elsewhere."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.bufs = {}
+
+    def __call__(self, tensors):
+        import torch
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        dev = tensors[0].device
+        n = torch.tensor([t.numel() for t in tensors], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n, group=self.group)     # a few integers per rank
+        ops, out = [], None
+        if rank == 0:
+            out = [list(tensors)]
+            for r in range(1, world):
+                got = []
+                for k, t in enumerate(tensors):
+                    m = int(sizes[r][k].item())
+                    key = (r, k)
+                    if key not in self.bufs or self.bufs[key].numel() < m:
+                        self.bufs[key] = torch.empty(max(m, 1), dtype=t.dtype, device=dev)
+                    buf = self.bufs[key][:m]
+                    if m:
+                        ops.append(dist.P2POp(dist.irecv, buf, r, group=self.group))
+                    got.append(buf)
+                out.append(got)
+        else:
+            for t in tensors:
+                if t.numel():
+                    ops.append(dist.P2POp(dist.isend, t.contiguous(), 0, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
+
+
+def engine_result_tensors(eng):
+    """Zero-copy views of what the lacing needs of an executed batch: (status | #nodes | #edges) per block, and the
+    per-base node paths -- the dominant payload, SURVEY 8(e)."""
+    import torch
+    v = eng.device_view()
+    st = device_tensor(v.status, v.n_blocks, "<i4")
+    nn = device_tensor(v.n_nodes, v.n_blocks, "<i4")
+    ne = device_tensor(v.n_edges, v.n_blocks, "<i4")
+    return [torch.cat([st, nn, ne]), device_tensor(v.seq_path_nodes, v.n_bases, "<i4")]
+
+
 def gather_results_host(local_block_ids, local_results, group=None):
     """Host-side reassembly (any backend): every rank ends up with {block_id: result-dict}."""
     import torch.distributed as dist

@@ -41,6 +41,17 @@ def _worker(rank, world, port, q):
     outs = shard.all_gather_v(t)
     ok = all((o == torch.arange(3 + 4 * r, dtype=torch.int32) + 100 * r).all() for r, o in enumerate(outs))
 
+    # point-to-point reassembly: rank 0 gets every rank's tensors at their exact sizes, twice through the same buffers
+    rg = shard.RootGather()
+    for rep in range(2):
+        mine = [torch.arange(5 + 3 * rank + rep, dtype=torch.int32) + 1000 * rank, torch.zeros(0, dtype=torch.int32) if rank else torch.ones(2, dtype=torch.int32)]
+        got = rg(mine)
+        if rank == 0:
+            ok = ok and len(got) == world and all((got[r][0] == torch.arange(5 + 3 * r + rep, dtype=torch.int32) + 1000 * r).all() for r in range(world))
+            ok = ok and got[1][1].numel() == 0 and got[0][1].numel() == 2
+        else:
+            ok = ok and got is None
+
     class R:
         pass
     res = []
