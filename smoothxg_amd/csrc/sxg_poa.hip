@@ -158,7 +158,8 @@ __host__ __device__ constexpr int sxg_min_waves(int TMAX, int W, int RM) {
 #ifdef SXG_DEV_WAVES
     return SXG_DEV_WAVES;
 #endif
-    return TMAX > 512 ? 4 : (RM == 2 ? (W <= 8 || TMAX == 256 ? 4 : 3) : (W <= 12 ? 4 : 3));
+    // (packed sweep: 128 VGPRs hold up to 13 columns per strip since round 2 -- two 8-wave workgroups share a CU)
+    return TMAX > 512 ? 4 : (RM == 2 ? 4 : (W <= 12 ? 4 : 3));
 }
 
 template <int TMAX, int W, bool CVX, int RM, bool SW>
@@ -1027,10 +1028,10 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             pl->work.push_back(b);
         }
         std::sort(plans.begin(), plans.end(), [](const LaunchPlan& a, const LaunchPlan& b) { return a.variant.Lpad() > b.variant.Lpad(); });
-        // a geometry with at least 60 % of the columns of a wider one of the same kind joins it: fewer,
-        // fuller launches beat many partial ones (measured on the mixed batch and on 1 kbp blocks:
-        // 0.88 -> 0.60 is +7 % and +10 %; 0.50 is worse again)
-        const double merge_ratio = getenv("SXG_POA_MERGE") ? atof(getenv("SXG_POA_MERGE")) : 0.60;
+        // a geometry with at least 75 % of the columns of a wider one of the same kind joins it: fewer,
+        // fuller launches beat many partial ones, but every joined block sweeps the wider geometry's columns
+        // (measured on the mixed batch, round 2 with over-subscribed launches: 0.60 39.6 s, 0.75 33.8 s, 0.90 34.3 s)
+        const double merge_ratio = getenv("SXG_POA_MERGE") ? atof(getenv("SXG_POA_MERGE")) : 0.75;
         for (size_t i = 0; i < plans.size(); ++i)
             for (size_t j = i + 1; j < plans.size();) {
                 const LaunchPlan &a = plans[i], &b = plans[j];
@@ -1061,9 +1062,12 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         // running side by side should end together, so their WAVES are made proportional to their
         // work (cost model of SURVEY 8e): slots_p = lambda * cost_p / waves_per_slot_p, with the largest
         // lambda that respects the arena budget and the wave capacity of the device.
+        // (a block swept by a wider geometry than its own -- merged launches -- costs the columns of THAT geometry)
         std::vector<double> pcost(plans.size(), 0.0);
         for (size_t i = 0; i < plans.size(); ++i)
-            for (int b : plans[i].work) pcost[i] += std::max(h->meta[b].cost, 1.0);
+            for (int b : plans[i].work)
+                pcost[i] += std::max(h->meta[b].cost, 1.0) * (plans[i].variant.RM == 3 ? 1.0 : (double)plans[i].variant.Lpad() / (double)std::max(h->meta[b].maxlen, 1));
+        const int oversub = getenv("SXG_POA_OVERSUB") ? std::max(1, atoi(getenv("SXG_POA_OVERSUB"))) : 2;
         auto slots_at = [&](size_t i, double lambda) {
             const double s = lambda * pcost[i] / (double)plans[i].variant.NW;
             return (int64_t)std::min<double>((double)plans[i].want_slots, std::max(1.0, std::floor(s)));
@@ -1075,7 +1079,10 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
                 bytes += (uint64_t)n * plans[i].lay.total;
                 waves += (uint64_t)n * (uint64_t)plans[i].variant.NW;
             }
-            return bytes <= budget && (plans.size() == 1 || waves <= (uint64_t)h->num_cu * 16u);
+            // Side by side the launches may ask for up to TWICE the wave slots of the device: workgroups that find no room wait
+            // in their hardware queue and start -- pulling from their launch's block queue -- as soon as another launch
+            // drains, so a launch the cost model under-estimated is not left alone on a half-empty chip at the end.
+            return bytes <= budget && (plans.size() == 1 || waves <= (uint64_t)h->num_cu * 16u * (uint64_t)oversub);
         };
         double lam_lo = 0.0, lam_hi = 1.0;
         while (lam_hi < 1e30 && fits(lam_hi)) {
