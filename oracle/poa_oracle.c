@@ -49,7 +49,8 @@
  *
  * BANDED MODE (A11: the reference's abPOA path, src/smooth.cpp:133-627, always runs abPOA with its adaptive
  * band wb=311, wf=0.03, :266-271; abPOA itself is absent).  By decree:
- *  B1 w = wb + (int)(wf * L) columns on either side, as abPOA sizes its band.
+ *  B1 w = min(wb + (int)(wf * L), 693) columns on either side: abPOA's band size, capped (beyond L = 12 733) so
+ *     that a band never spans more than 128 strips -- what one wavefront's window holds in the device kernel.
  *  B2 the band of a row is CENTRED ON THE BACKBONE COORDINATE x of its node and is a whole number of 11-column
  *     strips: strips max(0, x - w) / 11 .. (x + w) / 11.  x is kept by AddAlignment: the first sequence's nodes
  *     get their own column (i + 1); a new sibling takes the x of the node it is aligned to; a run of new
@@ -301,7 +302,7 @@ static int align_rows(poa_ws_t *ws, int N, const uint8_t *codes, const int32_t *
         int E = NEG, Q = NEG;
         int beg = 0, end = L;
         if (hint) {   /* B1, B2 */
-            const int w = POA_BAND_WB + (int)(POA_BAND_WF * L), x = hint[i - 1];
+            const int w0 = POA_BAND_WB + (int)(POA_BAND_WF * L), w = w0 < POA_BAND_WMAX ? w0 : POA_BAND_WMAX, x = hint[i - 1];
             beg = ((x - w > 0 ? x - w : 0) / POA_BAND_STRIP) * POA_BAND_STRIP;
             end = ((x + w) / POA_BAND_STRIP) * POA_BAND_STRIP + POA_BAND_STRIP - 1;
             if (end > L) end = L;

@@ -44,6 +44,7 @@ typedef struct {
 
 #define POA_BAND_WB 311
 #define POA_BAND_WF 0.03
+#define POA_BAND_WMAX 693 /* decree B1: the half-width is capped so that a band never exceeds 128 strips (L > 12 733) */
 #define POA_BAND_STRIP 11 /* the band is a whole number of 11-column strips (decree B2) */
 
 typedef struct poa_graph poa_graph_t;

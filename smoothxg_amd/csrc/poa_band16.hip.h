@@ -30,7 +30,8 @@ constexpr int BAND_WB = 311;        // abpt->wb, src/smooth.cpp:269
 constexpr double BAND_WF = 0.03;    // abpt->wf, src/smooth.cpp:271
 constexpr int BAND_W = 11;          // strip width = band granularity (decree B2; POA_BAND_STRIP of the oracle)
 constexpr int BAND_WIN = 128;       // strips of the window (two per lane)
-__host__ __device__ inline int band_half_width(int L) { return BAND_WB + (int)(BAND_WF * L); }
+constexpr int BAND_WMAX = 693;      // decree B1: cap of the half-width -- a band never exceeds the window (2 * 693 / 11 + 2 = 128 strips)
+__host__ __device__ inline int band_half_width(int L) { const int w = BAND_WB + (int)(BAND_WF * L); return w < BAND_WMAX ? w : BAND_WMAX; }
 // strips the plane keeps per row: the widest band of a block whose longest sequence has maxlen letters
 __host__ __device__ inline int band_plane_strips(int maxlen) { return 2 * band_half_width(maxlen) / BAND_W + 2; }
 __host__ __device__ constexpr int band_lds_bytes() { return LDS_CTL_BYTES + LDS_META_BYTES / 2 + 64 * BAND_W * 8; }

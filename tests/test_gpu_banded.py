@@ -94,3 +94,18 @@ def test_banded_beyond_12_kbp(engine):
     for b, seqs in enumerate(blocks):
         g, sc, cells = O.block_run(seqs, None, op)
         assert_block_equal(res[b], g, sc, cells, label=f"banded-long{len(seqs[0])}")
+
+
+def test_long_banded_block_with_an_indel_wider_than_the_window_margin(engine):
+    """Beyond 12.7 kbp the half-width is capped at 693 (decree B1) so that the band fits the kernel's window.  A 900-bp
+    insertion at 20 kbp pushes the best alignment ~900 columns off the backbone: outside the band in both the oracle
+    and the kernel, which therefore still agree (before the cap the oracle's band was wider than the kernel's window)."""
+    rng = np.random.default_rng(1501)
+    anc = rng.integers(0, 4, 20000, dtype=np.uint8)
+    ins = rng.integers(0, 4, 900, dtype=np.uint8)
+    blocks = [[np.concatenate([anc[:6000], ins, anc[6000:]]), anc.copy(), np.concatenate([anc[:11000], anc[11800:]])]]
+    gp, op = _p("affine_4param")
+    res = engine.run_blocks(blocks, gp)
+    assert engine.stats()["dom_row_mode"] == 3
+    g, sc, cells = O.block_run(blocks[0], None, op)
+    assert_block_equal(res[0], g, sc, cells, label="banded-long-indel")
