@@ -22,6 +22,13 @@
  *   - every *_out struct is library-owned; release it with the matching *_free.
  *   - a handle is bound to one GPU and one HIP stream; one in-flight batch per handle.
  *     Use one handle per host thread / per rank.
+ *
+ * What "drop-in" does and does not promise: alignment SCORES are those of the published recurrences and are
+ * checked against independent implementations; node ids, topological ranks, tie-breaks between equally good
+ * alignments, the consensus and the MSA column order follow the tie rules written down in oracle/poa_oracle.c
+ * (S1-S8, B1-B3), NOT necessarily spoa's / abPOA's: both are absent from the reference snapshot, so their
+ * choices could not be pinned ("PARITY UNPINNED").  Graphs are valid POA graphs of the same
+ * sequences either way -- every path spells its sequence -- but need not be byte-identical to the reference's.
  */
 #ifndef SXG_POA_H
 #define SXG_POA_H
