@@ -56,7 +56,8 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
     const int q = __builtin_amdgcn_readfirstlane(S.q), c = __builtin_amdgcn_readfirstlane(S.c);
     const int G2 = pk2(g, g), E2 = pk2(e, e), Q2 = pk2(q, q), C2 = pk2(c, c);
     const int sm = __builtin_amdgcn_readfirstlane(S.m), sn = __builtin_amdgcn_readfirstlane(S.n);
-    const int MN2 = pk2(sn - sm, sn - sm), M2 = pk2(sm, sm), ONE2 = 0x00010001, NEG2 = pk2(NEGP, NEGP);
+    const int NEG2 = pk2(NEGP, NEGP);
+    const unsigned SC_N4 = (unsigned)(sn & 0xff) * 0x01010101u, SC_MX = (unsigned)((sm ^ sn) & 0xff);   // score table, see poa_dp16.hip.h
     const int We = W * e, Wc = W * c;
     const int BS = __builtin_amdgcn_readfirstlane(B.band_strips), bw = __builtin_amdgcn_readfirstlane(B.band_w);
     const int last_strip = L / W;   // the strip that holds column L
@@ -71,7 +72,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
     typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 
     int s0 = -1000000;          // window origin (strip); far away: the first row re-centres
-    unsigned let[NL];           // letters of my two strips, one byte per (strip, column): (lo_k, hi_k, lo_k+1, hi_k+1)
+    unsigned let[NL];           // letters of my two strips, one byte per (strip, column): (lo_k+1, lo_k, hi_k+1, hi_k)
     unsigned so_lo = 0, so_hi = 0;   // byte offsets of my strips' slots in a plane row
     int Hp[W], Fp[W], Op[W], Hleft = NEG2;
 #pragma unroll
@@ -106,7 +107,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         const int h1 = __builtin_amdgcn_readfirstlane(m1.y);    // hint of predecessor #1
         const int hint = __builtin_amdgcn_readfirstlane(m1.w);
         const int np = info & 0xffff, code = (info >> 16) & 0xff;
-        const unsigned CODE4 = (unsigned)code * 0x01010101u;
+        const unsigned SC_T0 = SC_N4 ^ (code < 4 ? SC_MX << (8 * code) : 0u), SC_T1 = SC_N4 ^ (code == 4 ? SC_MX : 0u);
 
         int bl, bh;
         band_strips_of(hint, bw, last_strip, bl, bh);
@@ -119,11 +120,12 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             for (int k2 = 0; k2 < NL; ++k2) {
                 unsigned v = 0;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int kc = 2 * k2 + (b >> 1);
-                    const int j = (s0 + lane + (b & 1 ? 64 : 0)) * W + kc;
-                    const unsigned ch = (kc < W && j >= 1 && j <= L) ? (unsigned)g_seq[j - 1] : 15u;
-                    v |= (ch > 4u && ch != 15u ? 4u : ch) << (8 * b);
+                for (int b = 0; b < 4; ++b) {   // bytes (lo_k+1, lo_k, hi_k+1, hi_k): selectors into the row's score table
+                    const int kc = 2 * k2 + ((b & 1) ? 0 : 1);
+                    const int j = (s0 + lane + ((b >> 1) ? 64 : 0)) * W + kc;
+                    const bool valid = kc < W && j >= 1 && j <= L;
+                    const unsigned ch = valid ? (unsigned)g_seq[j - 1] : 5u;
+                    v |= (valid && ch > 4u ? 4u : ch) << (8 * b);
                 }
                 let[k2] = v;
             }
@@ -225,13 +227,12 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
 
         // ---- pass 1: H before the in-row gaps, strip-local carries
         int a = NEG2, b = NEG2;
+        unsigned sc4 = 0;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            const unsigned x4 = let[k >> 1] ^ CODE4;
-            const int lp = (int)__builtin_amdgcn_perm(0u, x4, (k & 1) ? 0x0c030c02u : 0x0c010c00u);
-            int nm;
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(nm) : "v"(lp), "v"(ONE2));
-            int h = pk_mad(nm, MN2, pk_add(Hc[k], M2));
+            if (!(k & 1)) sc4 = __builtin_amdgcn_perm(SC_T1, SC_T0, let[k >> 1]);
+            const int sc = (int)__builtin_amdgcn_perm(0u, (k & 1) ? (sc4 << 8) : sc4, 0x09030801u);
+            int h = pk_add(Hc[k], sc);
             h = pk_max(h, Fp[k]);
             if (CVX) h = pk_max(h, Op[k]);
             Hc[k] = h;

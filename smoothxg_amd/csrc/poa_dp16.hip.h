@@ -109,13 +109,18 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     const int q = __builtin_amdgcn_readfirstlane(S.q), c = __builtin_amdgcn_readfirstlane(S.c);
     const int G2 = pk2(g, g), E2 = pk2(e, e), Q2 = pk2(q, q), C2 = pk2(c, c);
     const int sm = __builtin_amdgcn_readfirstlane(S.m), sn = __builtin_amdgcn_readfirstlane(S.n);
-    const int MN2 = pk2(sn - sm, sn - sm), M2 = pk2(sm, sm), ONE2 = 0x00010001, NEG2 = pk2(NEGP, NEGP);
+    const int NEG2 = pk2(NEGP, NEGP);
+    // substitution scores come out of a per-row byte table (see pass 1): all-mismatch rows of it, and match ^ mismatch
+    const unsigned SC_N4 = (unsigned)(sn & 0xff) * 0x01010101u, SC_MX = (unsigned)((sm ^ sn) & 0xff);
     const int We = W * e, Wc = W * c;
     const int BS = __builtin_amdgcn_readfirstlane(B.band_strips);
     int* tot = lds;            // [4][16]: a_lo, a_hi, b_lo, b_hi inclusive totals per wave
     int* xch = lds + 64;       // [16]: Hc[W-1] (packed) of every wave's last lane
 
-    // query letters, one byte per (strip, column): register c2 holds (lo_k, hi_k, lo_k+1, hi_k+1)
+    // query letters, one byte per (strip, column), as SELECTORS into the row's score table: A,C,G,T,N = 0..4, "no letter"
+    // (padding columns, never a match) = 5.  Register k2 holds the bytes (lo_k+1, lo_k, hi_k+1, hi_k) of columns
+    // k = 2 k2 and k + 1 -- the order in which one v_perm turns them into four scores with column k's pair on the odd
+    // bytes, where a second v_perm can sign-extend them into a packed pair.
     constexpr int NL = (W + 1) / 2;
     unsigned let[NL];
 #pragma unroll
@@ -123,10 +128,11 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         unsigned v = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int kc = 2 * k2 + (b >> 1);  // strip-local column (W odd: one spare byte)
-            const int j = (b & 1 ? TW : 0) + j0 + kc;
-            const unsigned ch = (kc < W && j >= 1 && j <= L) ? (unsigned)seq[j - 1] : 15u;
-            v |= (ch > 4u && ch != 15u ? 4u : ch) << (8 * b);
+            const int kc = 2 * k2 + ((b & 1) ? 0 : 1);  // strip-local column (W odd: one spare pair)
+            const int j = ((b >> 1) ? TW : 0) + j0 + kc;
+            const bool valid = kc < W && j >= 1 && j <= L;
+            const unsigned ch = valid ? (unsigned)seq[j - 1] : 5u;
+            v |= (valid && ch > 4u ? 4u : ch) << (8 * b);
         }
         let[k2] = v;
     }
@@ -187,6 +193,9 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     const int kL_lo = L - j0, kL_hi = L - TW - j0;  // strip-local index of the end column L
 
     bool next_sib = false;      // decided at the end of a row for its successor
+    // (An L2 warm-up for the next row's stored predecessor -- one load per wave touching its 44 cache lines a row ahead,
+    // retired before the stores -- measured 0-5 % SLOWER in round 2: returns are in order, so whatever is in front of the
+    // demand loads holds them back, and a wait behind it stalls.)
     // (A register/LDS prefetch of the next row's stored predecessor, requested after pass 2 and collected before
     // this row's stores, was measured again in round 2 with the spills gone: 2.81 s against 2.68 s.  At this VALU
     // occupancy the co-resident workgroups already hide the round trip; its ~60 extra instructions do not pay.)
@@ -237,7 +246,8 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         const int myslot = __builtin_amdgcn_readfirstlane(m1.z);
         const int hint = __builtin_amdgcn_readfirstlane(m1.w);
         const int np = info & 0xffff, code = (info >> 16) & 0xff, flags = (info >> 24) & 0xff;
-        const unsigned CODE4 = (unsigned)code * 0x01010101u;
+        // score table of this row: byte c = score(node letter, query letter c); c = 5 (no letter) never matches
+        const unsigned SC_T0 = SC_N4 ^ (code < 4 ? SC_MX << (8 * code) : 0u), SC_T1 = SC_N4 ^ (code == 4 ? SC_MX : 0u);
 
 #ifdef SXG_ROW_PROF
         unsigned long long rt_ = __builtin_readcyclecounter();
@@ -353,16 +363,15 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         }
         // ---- pass 1 (right to left): H before the in-row gaps, strip-local carries
         int a = NEG2, b = NEG2;
+        unsigned sc4 = 0;
 #pragma unroll
         for (int k = W - 1; k >= 0; --k) {
-            // letters (lo_k, hi_k) of column k as a packed pair; 0 where they equal the node letter
-            const unsigned x4 = let[k >> 1] ^ CODE4;
-            const int lp = (int)__builtin_amdgcn_perm(0u, x4, (k & 1) ? 0x0c030c02u : 0x0c010c00u);
-            // 0 = match, 1 = mismatch.  Opaque to the optimiser on purpose: knowing the 0/1 range it
-            // rewrites the multiply-add below into two compares, two selects and a byte merge.
-            int nm;
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(nm) : "v"(lp), "v"(ONE2));
-            int h = pk_mad(nm, MN2, pk_add(k ? Hp[k - 1] : Hleft, M2));    // diagonal + (match ? m : n)
+            // four scores per letter register in one table look-up; the odd bytes -- column k's pair, after a byte shift
+            // column k+1's -- are sign-extended into a packed pair by a second permute.  (2 + 1/2 instructions and an
+            // add per column; the compare-free form before -- xor, extract, min with 1, multiply-add, add m -- took 4 1/2)
+            if ((k & 1) || k == W - 1) sc4 = __builtin_amdgcn_perm(SC_T1, SC_T0, let[k >> 1]);
+            const int sc = (int)__builtin_amdgcn_perm(0u, (k & 1) ? (sc4 << 8) : sc4, 0x09030801u);
+            int h = pk_add(k ? Hp[k - 1] : Hleft, sc);    // diagonal + (match ? m : n)
             h = pk_max(h, Fp[k]);
             if (CVX) h = pk_max(h, Op[k]);
             Hc[k] = h;
