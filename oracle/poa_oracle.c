@@ -51,8 +51,10 @@
  * band wb=311, wf=0.03, :266-271; abPOA itself is absent).  By decree:
  *  B1 w = min(wb + (int)(wf * L), 693) columns on either side: abPOA's band size, capped (beyond L = 12 733) so
  *     that a band never spans more than 128 strips -- what one wavefront's window holds in the device kernel.
- *  B2 the band of a row is CENTRED ON THE BACKBONE COORDINATE x of its node and is a whole number of 11-column
- *     strips: strips max(0, x - w) / 11 .. (x + w) / 11.  x is kept by AddAlignment: the first sequence's nodes
+ *  B2 the band of a row is CENTRED ON THE BACKBONE COORDINATE x of its node and is a whole number of s-column
+ *     strips: strips max(0, x - w) / s .. (x + w) / s, where s is the narrowest of 6, 8, 11 with which the band of
+ *     the BLOCK's longest sequence spans at most 128 strips (poa_band_strip_width; a stand-alone alignment: its own
+ *     length).  x is kept by AddAlignment: the first sequence's nodes
  *     get their own column (i + 1); a new sibling takes the x of the node it is aligned to; a run of new
  *     unaligned nodes continues from the previous aligned position (x + distance), else counts back from the
  *     next one, else is its own column.  (abPOA moves its band with the best-scoring cells of the predecessor
@@ -302,9 +304,10 @@ static int align_rows(poa_ws_t *ws, int N, const uint8_t *codes, const int32_t *
         int E = NEG, Q = NEG;
         int beg = 0, end = L;
         if (hint) {   /* B1, B2 */
+            const int strip = pp->banded > 1 ? (int)pp->banded : poa_band_strip_width(L);
             const int w0 = POA_BAND_WB + (int)(POA_BAND_WF * L), w = w0 < POA_BAND_WMAX ? w0 : POA_BAND_WMAX, x = hint[i - 1];
-            beg = ((x - w > 0 ? x - w : 0) / POA_BAND_STRIP) * POA_BAND_STRIP;
-            end = ((x + w) / POA_BAND_STRIP) * POA_BAND_STRIP + POA_BAND_STRIP - 1;
+            beg = ((x - w > 0 ? x - w : 0) / strip) * strip;
+            end = ((x + w) / strip) * strip + strip - 1;
             if (end > L) end = L;
             if (band_cells && beg <= end) *band_cells += (uint64_t)(end - beg + 1);
         }
@@ -683,12 +686,14 @@ poa_graph_t *poa_block_run_ws(poa_ws_t *ws, const uint8_t *bases, const int32_t 
     }
     int32_t *an = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
     int32_t *ap = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
+    poa_params_t pb = *p;   /* B2: one strip width for all alignments of the block, from its longest sequence */
+    if (pb.banded && pb.mode == POA_MODE_SW) pb.banded = (uint8_t)poa_band_strip_width((long)maxlen);
     for (int s = 0; s < n_seqs; ++s) {
         const uint8_t *seq = bases + seq_off[s];
         const int len = seq_off[s + 1] - seq_off[s];
         int32_t sc = 0;
         uint64_t cl = 0;
-        int n = poa_align_ws(ws, g, seq, len, p, an, ap, &sc, &cl);
+        int n = poa_align_ws(ws, g, seq, len, &pb, an, ap, &sc, &cl);
         if (scores) scores[s] = sc;
         if (cells) cells[s] = cl;
         poa_add_alignment(g, an, ap, n, seq, len, weights ? weights[s] : 1);

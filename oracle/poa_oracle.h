@@ -38,14 +38,21 @@ typedef struct {
     int8_t m, n, g, e, q, c; /* spoa sign convention: m>0 match, n<=0 mismatch, gaps <=0
                                 (src/smooth.cpp:2098-2106 negates the CLI values)       */
     uint8_t mode;            /* POA_MODE_SW | POA_MODE_NW                               */
-    uint8_t banded;          /* 1 = abPOA-style band wb=311, wf=0.03 (src/smooth.cpp:266-271), decrees B1-B3 in
-                                poa_oracle.c; local mode only (ignored for POA_MODE_NW)                        */
+    uint8_t banded;          /* != 0: abPOA-style band wb=311, wf=0.03 (src/smooth.cpp:266-271), decrees B1-B3 in
+                                poa_oracle.c; local mode only (ignored for POA_MODE_NW).  1 = the strip width (B2)
+                                follows from the length of the sequence being aligned; 6, 8 or 11 = that strip width
+                                (what poa_block_run sets for every alignment of a block: from the block's longest)  */
 } poa_params_t;
 
 #define POA_BAND_WB 311
 #define POA_BAND_WF 0.03
 #define POA_BAND_WMAX 693 /* decree B1: the half-width is capped so that a band never exceeds 128 strips (L > 12 733) */
-#define POA_BAND_STRIP 11 /* the band is a whole number of 11-column strips (decree B2) */
+/* decree B2: the band is a whole number of strips; the strip is the narrowest of 6, 8, 11 columns with which a band of
+ * the block's longest sequence spans at most 128 strips (2w/strip + 2) -- one wavefront's window in the device kernel */
+static inline int poa_band_strip_width(long maxlen) {
+    const long w0 = POA_BAND_WB + (long)(POA_BAND_WF * (double)maxlen), w = w0 < POA_BAND_WMAX ? w0 : POA_BAND_WMAX;
+    return 2 * w <= 756 ? 6 : (2 * w <= 1008 ? 8 : 11);
+}
 
 typedef struct poa_graph poa_graph_t;
 

@@ -1,9 +1,10 @@
 // poa_band16.hip.h -- BANDED packed-int16 sweep: the reference's abPOA path (A11, src/smooth.cpp:133-627,
 // band wb=311 / wf=0.03 at :266-271) re-designed for one wavefront.
 //
-// Semantics: decrees B1-B3 of oracle/poa_oracle.c.  The band of a row is a whole number of 11-column strips
+// Semantics: decrees B1-B3 of oracle/poa_oracle.c.  The band of a row is a whole number of W-column strips (W = 6, 8
+// or 11: the narrowest with which the band of the block's longest sequence spans at most 128 strips)
 // centred on the backbone coordinate of its node -- known BEFORE the row is computed -- so the sweep does not
-// mask lanes of the 5632-column geometry of poa_dp16.hip.h: ONE wave owns a window of 128 strips (1408 columns,
+// mask lanes of the 5632-column geometry of poa_dp16.hip.h: ONE wave owns a window of 128 strips (128 W columns,
 // lane t: strips origin+t and origin+64+t in the low / high halves of its registers) that follows the band
 // down the graph.  Consequences:
 //   * no barriers and no LDS exchange: the in-row gap scan is a DPP scan of one wave, the hand-over of the
@@ -28,25 +29,29 @@ namespace sxg {
 
 constexpr int BAND_WB = 311;        // abpt->wb, src/smooth.cpp:269
 constexpr double BAND_WF = 0.03;    // abpt->wf, src/smooth.cpp:271
-constexpr int BAND_W = 11;          // strip width = band granularity (decree B2; POA_BAND_STRIP of the oracle)
+constexpr int BAND_W_MAX = 11;      // widest strip (decree B2; poa_band_strip_width of the oracle)
 constexpr int BAND_WIN = 128;       // strips of the window (two per lane)
 constexpr int BAND_WMAX = 693;      // decree B1: cap of the half-width -- a band never exceeds the window (2 * 693 / 11 + 2 = 128 strips)
+// decree B2: strip width of a block whose longest sequence has maxlen letters
+__host__ __device__ inline int band_strip_width(int maxlen) {
+    const int w0 = BAND_WB + (int)(BAND_WF * maxlen), w = w0 < BAND_WMAX ? w0 : BAND_WMAX;
+    return 2 * w <= 756 ? 6 : (2 * w <= 1008 ? 8 : 11);
+}
 __host__ __device__ inline int band_half_width(int L) { const int w = BAND_WB + (int)(BAND_WF * L); return w < BAND_WMAX ? w : BAND_WMAX; }
 // strips the plane keeps per row: the widest band of a block whose longest sequence has maxlen letters
-__host__ __device__ inline int band_plane_strips(int maxlen) { return 2 * band_half_width(maxlen) / BAND_W + 2; }
-__host__ __device__ constexpr int band_lds_bytes() { return LDS_CTL_BYTES + LDS_META_BYTES / 2 + 64 * BAND_W * 8; }
+__host__ __device__ inline int band_plane_strips(int maxlen, int W) { return 2 * band_half_width(maxlen) / W + 2; }
+__host__ __device__ constexpr int band_lds_bytes(int W) { return LDS_CTL_BYTES + LDS_META_BYTES / 2 + 64 * W * 8; }
 
 constexpr unsigned NEGCELL = 0x0000C000u;   // plane cell of a cell that does not exist: H = NEGP, distances 0
 
-__device__ __forceinline__ void band_strips_of(const int hint, const int w, const int last_strip, int& bl, int& bh) {
-    bl = max(hint - w, 0) / BAND_W;
-    bh = min((hint + w) / BAND_W, last_strip);
+__device__ __forceinline__ void band_strips_of(const int hint, const int w, const int W, const int last_strip, int& bl, int& bh) {
+    bl = max(hint - w, 0) / W;
+    bh = min((hint + w) / W, last_strip);
 }
 
-template <bool CVX>
+template <bool CVX, int W>
 __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView R, const int N_, const uint8_t* seq, const int L_,
                                                const DpBuffers B, char* smem, unsigned long long* cells_out) {
-    constexpr int W = BAND_W;
     DpResult res;
     const int N = __builtin_amdgcn_readfirstlane(N_), L = __builtin_amdgcn_readfirstlane(L_);
     const int MB = LDS_META_BYTES / 2, CH = MB / 32;
@@ -110,7 +115,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         const unsigned SC_T0 = SC_N4 ^ (code < 4 ? SC_MX << (8 * code) : 0u), SC_T1 = SC_N4 ^ (code == 4 ? SC_MX : 0u);
 
         int bl, bh;
-        band_strips_of(hint, bw, last_strip, bl, bh);
+        band_strips_of(hint, bw, W, last_strip, bl, bh);
         if (bh >= bl) cells += (unsigned long long)(min(L, bh * W + W - 1) - bl * W + 1);
         if (bh >= bl && (bl < s0 || bh >= s0 + BAND_WIN)) {
             // re-centre the window on this band; registers of the previous row no longer line up with it
@@ -146,7 +151,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             hl_ = pk2(st_lo == 0 ? NEGP : 0, 0);                                                            \
         } else {                                                                                            \
             int fl_, fh_;                                                                                   \
-            band_strips_of(hp_, bw, last_strip, fl_, fh_);                                                  \
+            band_strips_of(hp_, bw, W, last_strip, fl_, fh_);                                                  \
             const __amdgpu_buffer_rsrc_t rs_ = p16_rsrc((const void*)(g_tb + (size_t)(p_) * (size_t)(W * BS)), W * BS * 4); \
             const bool a_ = st_lo >= fl_ && st_lo <= fh_, b_ = st_hi >= fl_ && st_hi <= fh_;                 \
             const bool la_ = st_lo - 1 >= fl_ && st_lo - 1 <= fh_, lb_ = st_hi - 1 >= fl_ && st_hi - 1 <= fh_; \
@@ -308,7 +313,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             const i32x4 n0 = lmeta[2 * (i & (CH - 1))], n1 = lmeta[2 * (i & (CH - 1)) + 1];
             const int nnp = __builtin_amdgcn_readfirstlane(n0.y) & 0xffff, np0 = __builtin_amdgcn_readfirstlane(n0.z);
             next_sib = np <= 1 && nnp <= 1 && np0 == p0 && np0 != i;
-            band_strips_of(__builtin_amdgcn_readfirstlane(n1.w), bw, last_strip, nbl, nbh);
+            band_strips_of(__builtin_amdgcn_readfirstlane(n1.w), bw, W, last_strip, nbl, nbh);
         }
         const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
 #define BAND_STORE(CF, CO)                                                                                  \

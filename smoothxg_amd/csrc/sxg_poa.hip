@@ -153,7 +153,7 @@ struct BlockArgs {
 // ~165 (3 waves); a 1024-thread workgroup is 4 waves per SIMD by itself.
 // RM = row mode: 0 = 32-bit sweep with int16 row words, 1 = 32-bit sweep with int32 row words,
 // 2 = packed-int16 sweep (poa_dp16.hip.h; two strips per lane, W <= 12),
-// 3 = banded packed sweep (poa_band16.hip.h; one wave, a sliding window of 128 strips of 11 columns).
+// 3 = banded packed sweep (poa_band16.hip.h; one wave, a sliding window of 128 strips of W = 6, 8 or 11 columns).
 __host__ __device__ constexpr int sxg_min_waves(int TMAX, int W, int RM) {
 #ifdef SXG_DEV_WAVES
     return SXG_DEV_WAVES;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     // banded sweep (decrees B1-B3): one wave, the band slides with the rows; out-of-band cells do not
                     // exist, so the traceback cannot leave the kept cells
                     V.B.band_w = band_half_width(len);
-                    res = dp_fill_band16<CVX>(S, V.R, N, seq, len, V.B, smem, A.cells + s);
+                    res = dp_fill_band16<CVX, W>(S, V.R, N, seq, len, V.B, smem, A.cells + s);
                     __syncthreads();
                     PROF(2);
                     if (t == 0) lds[TBM_FLAG] = 0;
@@ -489,7 +489,11 @@ template <int TMAX, int W, int RM> static KernelFn<AlignArgs> pick_align(bool cv
     do { if (v.TMAX == TM && v.W == Wd && v.RM == 2 && sw) return cvx ? KERN<TM, Wd, true, 2, true> : KERN<TM, Wd, false, 2, true>; } while (0)
 // SXG_DEV_ONLY_W=<w>: development builds instantiate a single packed class (seconds instead of minutes)
 static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
-    if (v.RM == 3) return cvx ? poa_block_kernel<64, 11, true, 3, true> : poa_block_kernel<64, 11, false, 3, true>;
+    if (v.RM == 3) {   // banded: the strip width is part of the semantics (decree B2), never merged or widened
+        if (v.W == 6) return cvx ? poa_block_kernel<64, 6, true, 3, true> : poa_block_kernel<64, 6, false, 3, true>;
+        if (v.W == 8) return cvx ? poa_block_kernel<64, 8, true, 3, true> : poa_block_kernel<64, 8, false, 3, true>;
+        return cvx ? poa_block_kernel<64, 11, true, 3, true> : poa_block_kernel<64, 11, false, 3, true>;
+    }
 #ifdef SXG_DEV_ONLY_W
     SXG_PICK16(pick_block, SXG_DEV_ONLY_TMAX, SXG_DEV_ONLY_W);
 #else
@@ -750,7 +754,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
         // sweep run the one-wave banded kernel, everything else asked to be banded runs the full matrix
         if (h->h_params[in->per_block_params ? b : 0].banded && m.S.sw && m.rm == 2 && m.maxlen <= SXG_POA_MAX_SEQ_LEN) {
             m.rm = 3;
-            m.variant = Variant{BAND_W, 1, 64, 3};
+            m.variant = Variant{band_strip_width(m.maxlen), 1, 64, 3};   // decree B2: strip width from the block's longest sequence
             m.fits = true;
         }
     }
@@ -846,12 +850,12 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     const int wb = V.RM == 1 ? 8 : 4;
     if (V.RM == 3) pool_slots = 1;   // (the banded sweep has no row ring: predecessors come from the plane)
     P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false,
-                        V.RM == 3 ? band_plane_strips(maxlen) : (V.RM == 2 ? p16_band_strips(V.T(), V.W) : 0));
+                        V.RM == 3 ? band_plane_strips(maxlen, V.W) : (V.RM == 2 ? p16_band_strips(V.T(), V.W) : 0));
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
     if (V.RM == 2) { P.smem = dp16_lds_bytes(V.T(), V.W); P.park_lds = true; }  // packed sweep parks in LDS only
-    if (V.RM == 3) { P.smem = band_lds_bytes(); P.park_lds = true; }
+    if (V.RM == 3) { P.smem = band_lds_bytes(V.W); P.park_lds = true; }
     P.pf_off = (V.RM < 2 && getenv("SXG_POA_PREFETCH")) ? dp_pf_offset(Lpad, wb, V.T()) : -1;
     if (P.pf_off >= 0) P.smem += dp_pf_bytes(Lpad, wb, V.T());
     if (P.smem > 48 * 1024)
@@ -1035,7 +1039,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         for (size_t i = 0; i < plans.size(); ++i)
             for (size_t j = i + 1; j < plans.size();) {
                 const LaunchPlan &a = plans[i], &b = plans[j];
-                if (a.variant.RM == b.variant.RM && a.cvx == b.cvx && a.sw == b.sw && a.tier == b.tier &&
+                if (a.variant.RM == b.variant.RM && a.variant.RM != 3 && a.cvx == b.cvx && a.sw == b.sw && a.tier == b.tier &&
                     (double)b.variant.Lpad() >= merge_ratio * (double)a.variant.Lpad()) {
                     plans[i].work.insert(plans[i].work.end(), b.work.begin(), b.work.end());
                     plans.erase(plans.begin() + (long)j);
