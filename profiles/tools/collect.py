@@ -70,6 +70,17 @@ if os.path.exists(b):
                     "correction": traffic["ns_sw"]["correction"]}}}
     json.dump(counters, open(os.path.join(dst, "counters.json"), "w"), indent=1)
     d["roofline"]["traffic"] = traffic["ns_sw"]["hbm_bytes_per_launch"]
+    # the bench line of this same gpurun call was printed BEFORE these counters existed: restate its VALU roofline with them
+    r = d["roofline"]
+    k_s = r["kernel_ms_per_launch"] / 1e3
+    ipl = agg.get("SQ_INSTS_VALU")
+    if ipl and r.get("valu"):
+        peak = r["valu"]["peak_wave_insts_per_s"]
+        r.update({"bound": "valu", "achieved": ipl / k_s / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+                  "frac": ipl / k_s / peak})
+        r["valu"].update({"wave_insts_per_launch": ipl, "wave_insts_per_cell": ipl / d["config"]["cells_per_step_per_gpu"],
+                          "counter_file": "profiles/%s/counters.json" % rnd, "counters_match_build": True,
+                          "note": "counters collected in the same gpurun call as this bench line, on the same build"})
     open(os.path.join(dst, "bench_ns_sw.json"), "w").write(json.dumps(d) + "\n")
     print("bench: %.1f %s, kernel %.1f ms, frac %.3f" % (d["value"], d["unit"], d["roofline"]["kernel_ms_per_launch"], d["roofline"]["frac"]))
 print("rocprof kernel avg %.1f ms; HBM bytes/launch %.3e (uncorrected %.3e); VALU instrs %.3e" % (
