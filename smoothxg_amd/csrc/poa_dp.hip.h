@@ -48,19 +48,28 @@ struct WgCtx {
         *total = tot;
         return base + x - v;
     }
-    __device__ int scan_incl_max(int v) const {
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __device__ int scan_excl_max(int v, int* total) const {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        const int NONE = -0x7fffffff;
         int x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(x, d);
             if (lane >= d) x = max(x, o);
         }
+        int before = __shfl_up(x, 1);
+        if (lane == 0) before = NONE;
         if (lane == 63) lds[w] = x;
         __syncthreads();
-        for (int i = 0; i < w; ++i) x = max(x, lds[i]);
+        int tot = NONE;
+        for (int i = 0; i < nw; ++i) {
+            const int s = lds[i];
+            if (i < w) before = max(before, s);
+            tot = max(tot, s);
+        }
         __syncthreads();
-        return x;
+        *total = tot;
+        return before;
     }
     __device__ int reduce_max(int v) const {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;

@@ -10,7 +10,7 @@
 // Ctx must provide:
 //   int tid(), nthreads();  void sync();
 //   int scan_excl_add(int v, int* total);   // block-wide exclusive +scan in tid order
-//   int scan_incl_max(int v);               // block-wide inclusive max-scan in tid order
+//   int scan_excl_max(int v, int* total);   // block-wide exclusive max-scan in tid order (-0x7fffffff before thread 0)
 //   int reduce_max(int v);                  // block-wide max, result on every thread
 //   int atomic_add(int32_t* p, int v);
 #pragma once
@@ -18,16 +18,29 @@
 
 namespace sxg {
 
+// The scans below give every thread SCAN_K consecutive elements: the block-wide scan (LDS hop, two barriers) runs
+// once per SCAN_K * T elements, and the SCAN_K loads of a thread are independent -- with one wave per block (1 kbp
+// blocks, the banded sweep) these loops are bound by the latency of dependent HBM loads, not by instructions.
+constexpr int SCAN_K = 4;
+
 template <class Ctx, class F, class P>
 SXG_HD int array_excl_sum(Ctx& c, int n, F get, P out) {
     const int T = c.nthreads(), t = c.tid();
     int carry = 0;
-    for (int base = 0; base < n; base += T) {
-        const int i = base + t;
-        const int v = i < n ? get(i) : 0;
+    for (int base = 0; base < n; base += SCAN_K * T) {
+        const int i0 = base + SCAN_K * t;
+        int v[SCAN_K], s = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_K; ++k) v[k] = i0 + k < n ? get(i0 + k) : 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_K; ++k) s += v[k];
         int tot;
-        const int p = c.scan_excl_add(v, &tot);
-        if (i < n) out[i] = carry + p;
+        int p = carry + c.scan_excl_add(s, &tot);
+#pragma unroll
+        for (int k = 0; k < SCAN_K; ++k) {
+            if (i0 + k < n) out[i0 + k] = p;
+            p += v[k];
+        }
         carry += tot;
     }
     return carry;
@@ -37,14 +50,22 @@ SXG_HD int array_excl_sum(Ctx& c, int n, F get, P out) {
 template <class Ctx, class F, class P>
 SXG_HD void array_incl_max(Ctx& c, int n, F get, P out) {
     const int T = c.nthreads(), t = c.tid();
-    int carry = -0x7fffffff;
-    for (int base = 0; base < n; base += T) {
-        const int i = base + t;
-        int v = i < n ? get(i) : -0x7fffffff;
-        v = c.scan_incl_max(v);
-        if (v < carry) v = carry;
-        if (i < n) out[i] = v;
-        carry = c.reduce_max(v);
+    const int NONE = -0x7fffffff;
+    int carry = NONE;
+    for (int base = 0; base < n; base += SCAN_K * T) {
+        const int i0 = base + SCAN_K * t;
+        int v[SCAN_K];
+#pragma unroll
+        for (int k = 0; k < SCAN_K; ++k) v[k] = i0 + k < n ? get(i0 + k) : NONE;
+#pragma unroll
+        for (int k = 1; k < SCAN_K; ++k) v[k] = v[k] > v[k - 1] ? v[k] : v[k - 1];
+        int tot;
+        int before = c.scan_excl_max(v[SCAN_K - 1], &tot);
+        if (before < carry) before = carry;
+#pragma unroll
+        for (int k = 0; k < SCAN_K; ++k)
+            if (i0 + k < n) out[i0 + k] = v[k] > before ? v[k] : before;
+        if (tot > carry) carry = tot;
     }
 }
 
@@ -52,15 +73,22 @@ SXG_HD void array_incl_max(Ctx& c, int n, F get, P out) {
 template <class Ctx, class F, class P>
 SXG_HD void array_suffix_min(Ctx& c, int n, F get, P out) {
     const int T = c.nthreads(), t = c.tid();
-    int carry = -0x7fffffff;
-    for (int base = 0; base < n; base += T) {
-        const int ir = base + t;          // reversed index
-        const int i = n - 1 - ir;
-        int v = ir < n ? -get(i) : -0x7fffffff;
-        v = c.scan_incl_max(v);
-        if (v < carry) v = carry;
-        if (ir < n) out[i] = -v;
-        carry = c.reduce_max(v);
+    const int NONE = -0x7fffffff;
+    int carry = NONE;
+    for (int base = 0; base < n; base += SCAN_K * T) {
+        const int r0 = base + SCAN_K * t;          // reversed index of my first element
+        int v[SCAN_K];
+#pragma unroll
+        for (int k = 0; k < SCAN_K; ++k) v[k] = r0 + k < n ? -get(n - 1 - (r0 + k)) : NONE;
+#pragma unroll
+        for (int k = 1; k < SCAN_K; ++k) v[k] = v[k] > v[k - 1] ? v[k] : v[k - 1];
+        int tot;
+        int before = c.scan_excl_max(v[SCAN_K - 1], &tot);
+        if (before < carry) before = carry;
+#pragma unroll
+        for (int k = 0; k < SCAN_K; ++k)
+            if (r0 + k < n) out[n - 1 - (r0 + k)] = -(v[k] > before ? v[k] : before);
+        if (tot > carry) carry = tot;
     }
 }
 
@@ -94,16 +122,26 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq_,
     const int BIG = 0x3fffffff;
     c.sync();
     // P1: classify every position: 0 = existing node, 1 = new sibling, 2 = new unaligned
-    for (int i = t; i < len; i += T) {
-        const int cc = seq[i] > 4 ? 4 : seq[i];
-        const int a = G.posnode[i];
-        int kind = 2, tg = -1;
-        if (a >= 0) {
-            const int v = G.gmem[5 * G.leader[a] + cc];
-            if (v >= 0) { kind = 0; tg = v; } else kind = 1;
+    constexpr int GB = 4;   // positions per thread and iteration, stage by stage (see prep_rows)
+    for (int i0 = t; i0 < len; i0 += GB * T) {
+        int cc[GB], a[GB], ld[GB], tg[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int i = i0 + u * T;
+            cc[u] = i < len ? (seq[i] > 4 ? 4 : (int)seq[i]) : 0;
+            a[u] = i < len ? G.posnode[i] : -1;
         }
-        G.kind[i] = (int8_t)kind;
-        G.target[i] = tg;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) ld[u] = a[u] >= 0 ? G.leader[a[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) tg[u] = ld[u] >= 0 ? G.gmem[5 * ld[u] + cc[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int i = i0 + u * T;
+            if (i >= len) continue;
+            G.kind[i] = (int8_t)(a[u] < 0 ? 2 : (tg[u] >= 0 ? 0 : 1));
+            G.target[i] = a[u] >= 0 && tg[u] >= 0 ? tg[u] : -1;
+        }
     }
     c.sync();
     const int n_new = array_excl_sum(c, len, [&](int i) { return G.kind[i] != 0 ? 1 : 0; }, G.newidx);
@@ -157,26 +195,62 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq_,
     // P3: shift the old nodes.  preva is free again: reuse as exclusive slot counts.
     array_excl_sum(c, n_old, [&](int r) { return G.slotadd[r]; }, G.preva);
     c.sync();
-    for (int r = t; r < n_old; r += T) {
-        const int nr = r + G.preva[r] + G.slotadd[r];
-        const int v = G.order[r];
-        G.rank[v] = nr;
-        G.order_tmp[nr] = v;
+    for (int r0 = t; r0 < n_old; r0 += GB * T) {
+        int nr[GB], v[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            nr[u] = r < n_old ? r + G.preva[r] + G.slotadd[r] : 0;
+            v[u] = r < n_old ? G.order[r] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            if (r0 + u * T >= n_old) continue;
+            G.rank[v[u]] = nr[u];
+            G.order_tmp[nr[u]] = v[u];
+        }
     }
     c.sync();
-    for (int r = t; r < n_old + n_new; r += T) G.order[r] = G.order_tmp[r];
+    for (int r0 = t; r0 < n_old + n_new; r0 += GB * T) {
+        int v[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) v[u] = r0 + u * T < n_old + n_new ? G.order_tmp[r0 + u * T] : 0;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) if (r0 + u * T < n_old + n_new) G.order[r0 + u * T] = v[u];
+    }
     // P4: edges between consecutive path nodes, weight += 2*w (S6)
-    for (int i = t; i < len; i += T) {
-        int isnew = 0;
-        if (i >= 1) {
-            const int u = G.target[i - 1], v = G.target[i];
-            int found = -1;
-            if (G.kind[i - 1] == 0 && G.kind[i] == 0)
-                for (int e = G.out_head[u]; e >= 0; e = G.e_next_out[e])
-                    if (G.e_head[e] == v) { found = e; break; }
-            if (found >= 0) G.e_w[found] += 2u * weight; else isnew = 1;
+    for (int i0 = t; i0 < len; i0 += GB * T) {
+        int u_[GB], v_[GB], both[GB], e0[GB], h0[GB], n0[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int i = i0 + u * T;
+            const bool ok = i >= 1 && i < len;
+            u_[u] = ok ? G.target[i - 1] : -1;
+            v_[u] = ok ? G.target[i] : -1;
+            both[u] = ok && G.kind[i - 1] == 0 && G.kind[i] == 0;
         }
-        G.nexta[i] = isnew;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) e0[u] = both[u] ? G.out_head[u_[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {   // the first out-edge (most nodes have one)
+            h0[u] = e0[u] >= 0 ? G.e_head[e0[u]] : -1;
+            n0[u] = e0[u] >= 0 ? G.e_next_out[e0[u]] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int i = i0 + u * T;
+            if (i >= len) continue;
+            int isnew = 0;
+            if (i >= 1) {
+                int found = -1;
+                if (e0[u] >= 0 && h0[u] == v_[u]) found = e0[u];
+                else
+                    for (int e = n0[u]; e >= 0; e = G.e_next_out[e])
+                        if (G.e_head[e] == v_[u]) { found = e; break; }
+                if (found >= 0) G.e_w[found] += 2u * weight; else isnew = 1;
+            }
+            G.nexta[i] = isnew;
+        }
     }
     c.sync();
     const int n_newe = array_excl_sum(c, len, [&](int i) { return G.nexta[i]; }, G.preva);
@@ -218,13 +292,28 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
     const int n_store = array_excl_sum(c, N, [&](int r) { return (R.flags[r] & ROW_STORE) ? 1 : 0; }, R.sseq);
     if (t == 0) R.sseq[N] = n_store;
     c.sync();
+    constexpr int GB = 4;
     int worst = 0;
-    for (int r = t; r < N; r += T) {
-        if (!(R.flags[r] & ROW_STORE)) { R.slot[r] = -1; continue; }
-        const int lu = R.slot[r];
-        const int cnt = R.sseq[lu] - R.sseq[r];  // stored rows in [r, lu): must fit the ring
-        if (cnt > worst) worst = cnt;
-        R.slot[r] = R.sseq[r] % caps.pool_slots;
+    for (int r0 = t; r0 < N; r0 += GB * T) {
+        int fl[GB], lu[GB], sr[GB], sl[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            fl[u] = r < N ? (int)R.flags[r] : 0;
+            lu[u] = r < N ? R.slot[r] : 0;
+            sr[u] = r < N ? R.sseq[r] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) sl[u] = (fl[u] & ROW_STORE) ? R.sseq[lu[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            if (r >= N) continue;
+            if (!(fl[u] & ROW_STORE)) { R.slot[r] = -1; continue; }
+            const int cnt = sl[u] - sr[u];  // stored rows in [r, lu): must fit the ring
+            if (cnt > worst) worst = cnt;
+            R.slot[r] = sr[u] % caps.pool_slots;
+        }
     }
     worst = c.reduce_max(worst);
     if (worst > caps.pool_slots && hinted != 2) return ST_POOL_OVERFLOW;
@@ -239,20 +328,40 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
             if (R.pred_off[r + 1] - R.pred_off[r] <= 1) R.tbx[r] = -1;
         c.sync();
     }
-    for (int r = t; r < N; r += T) {
-        const int pb = R.pred_off[r], np = R.pred_off[r + 1] - pb;
-        RowMeta m;
-        m.pb = pb;
-        m.info = np | ((int)R.code[r] << 16) | ((int)R.flags[r] << 24);
-        m.p0 = np >= 1 ? R.preds[pb] : 0;
-        m.s0 = (m.p0 >= 1 && m.p0 != r) ? R.slot[m.p0 - 1] : -1;
-        m.p1 = np >= 2 ? R.preds[pb + 1] : 0;
-        m.s1 = (m.p1 >= 1 && m.p1 != r) ? R.slot[m.p1 - 1] : -1;
-        if (hinted == 2) { m.s0 = m.p0 >= 1 ? R.tbx[m.p0 - 1] : 0; m.s1 = m.p1 >= 1 ? R.tbx[m.p1 - 1] : 0; }
-        m.slot = R.slot[r];
-        m.tbx = R.tbx[r];
-        int32_t* d = R.meta + 8 * (size_t)r;
-        d[0] = m.pb; d[1] = m.info; d[2] = m.p0; d[3] = m.s0; d[4] = m.p1; d[5] = m.s1; d[6] = m.slot; d[7] = m.tbx;
+    for (int r0 = t; r0 < N; r0 += GB * T) {
+        int pb[GB], np[GB], cf[GB], p0[GB], p1[GB], q0[GB], q1[GB], ms[GB], mt[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            pb[u] = r < N ? R.pred_off[r] : 0;
+            np[u] = r < N ? R.pred_off[r + 1] - pb[u] : 0;
+            cf[u] = r < N ? ((int)R.code[r] << 16) | ((int)R.flags[r] << 24) : 0;
+            ms[u] = r < N ? R.slot[r] : 0;
+            mt[u] = r < N ? R.tbx[r] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            p0[u] = np[u] >= 1 ? R.preds[pb[u]] : 0;
+            p1[u] = np[u] >= 2 ? R.preds[pb[u] + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            if (hinted == 2) {
+                q0[u] = p0[u] >= 1 ? R.tbx[p0[u] - 1] : 0;
+                q1[u] = p1[u] >= 1 ? R.tbx[p1[u] - 1] : 0;
+            } else {
+                q0[u] = (p0[u] >= 1 && p0[u] != r) ? R.slot[p0[u] - 1] : -1;
+                q1[u] = (p1[u] >= 1 && p1[u] != r) ? R.slot[p1[u] - 1] : -1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            if (r >= N) continue;
+            int32_t* d = R.meta + 8 * (size_t)r;
+            d[0] = pb[u]; d[1] = np[u] | cf[u]; d[2] = p0[u]; d[3] = q0[u]; d[4] = p1[u]; d[5] = q1[u]; d[6] = ms[u]; d[7] = mt[u];
+        }
     }
     c.sync();
     return ST_OK;
@@ -266,28 +375,71 @@ SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const 
     c.sync();
     const int N = *G.n_nodes;
     if (N > caps.rows_cap) return ST_ROWS_OVERFLOW;
-    for (int r = t; r < N; r += T) {
-        const int v = G.order[r];
-        R.row_node[r] = v;
-        R.code[r] = G.code[v];
-        if (hinted) R.tbx[r] = G.xpos[v];
+    // (GB rows per thread and iteration, every stage of dependent loads issued for all of them before the next: the chains
+    // order -> in_head -> e_tail -> rank are four HBM round trips deep, and one wave per block has nothing else to hide them)
+    constexpr int GB = 4;
+    for (int r0 = t; r0 < N; r0 += GB * T) {
+        int v[GB], cd[GB], xp[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) v[u] = r0 + u * T < N ? G.order[r0 + u * T] : 0;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) { cd[u] = G.code[v[u]]; xp[u] = hinted ? G.xpos[v[u]] : 0; }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            if (r >= N) continue;
+            R.row_node[r] = v[u];
+            R.code[r] = (uint8_t)cd[u];
+            if (hinted) R.tbx[r] = xp[u];
+        }
     }
     const int E = array_excl_sum(c, N, [&](int r) { return G.in_deg[G.order[r]]; }, R.pred_off);
     if (t == 0) R.pred_off[N] = E;
     c.sync();
     // preds in rank space; store / sink flags; last reader of every row (kept in R.slot)
-    for (int r = t; r < N; r += T) {
-        const int v = G.order[r];
-        int o = R.pred_off[r];
-        for (int e = G.in_head[v]; e >= 0; e = G.e_next_in[e]) R.preds[o++] = G.rank[G.e_tail[e]] + 1;
-        int store = 0, lu = r;
-        for (int e = G.out_head[v]; e >= 0; e = G.e_next_out[e]) {
-            const int hr = G.rank[G.e_head[e]];
-            if (hr != r + 1) store = 1;
-            if (hr > lu) lu = hr;
+    for (int r0 = t; r0 < N; r0 += GB * T) {
+        int v[GB], o[GB], ei[GB], eo[GB], od[GB], ti[GB], ho[GB], ni[GB], no[GB], ri[GB], ro[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            v[u] = r < N ? G.order[r] : -1;
+            o[u] = r < N ? R.pred_off[r] : 0;
         }
-        R.flags[r] = (uint8_t)((store ? ROW_STORE : 0) | (G.out_deg[v] == 0 ? ROW_SINK : 0));
-        R.slot[r] = lu;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            ei[u] = v[u] >= 0 ? G.in_head[v[u]] : -1;
+            eo[u] = v[u] >= 0 ? G.out_head[v[u]] : -1;
+            od[u] = v[u] >= 0 ? G.out_deg[v[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {   // the first edge of either list (most nodes have one of each)
+            ti[u] = ei[u] >= 0 ? G.e_tail[ei[u]] : -1;
+            ni[u] = ei[u] >= 0 ? G.e_next_in[ei[u]] : -1;
+            ho[u] = eo[u] >= 0 ? G.e_head[eo[u]] : -1;
+            no[u] = eo[u] >= 0 ? G.e_next_out[eo[u]] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            ri[u] = ti[u] >= 0 ? G.rank[ti[u]] : -1;
+            ro[u] = ho[u] >= 0 ? G.rank[ho[u]] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            if (r >= N) continue;
+            int oo = o[u];
+            if (ei[u] >= 0) R.preds[oo++] = ri[u] + 1;
+            for (int e = ni[u]; e >= 0; e = G.e_next_in[e]) R.preds[oo++] = G.rank[G.e_tail[e]] + 1;
+            int store = 0, lu = r;
+            if (eo[u] >= 0) { if (ro[u] != r + 1) store = 1; if (ro[u] > lu) lu = ro[u]; }
+            for (int e = no[u]; e >= 0; e = G.e_next_out[e]) {
+                const int hr = G.rank[G.e_head[e]];
+                if (hr != r + 1) store = 1;
+                if (hr > lu) lu = hr;
+            }
+            R.flags[r] = (uint8_t)((store ? ROW_STORE : 0) | (od[u] == 0 ? ROW_SINK : 0));
+            R.slot[r] = lu;
+        }
     }
     return finish_rows(c, N, R, caps, hinted);
 }

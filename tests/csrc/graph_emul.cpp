@@ -15,7 +15,7 @@ struct SerialCtx {
     int nthreads() const { return 1; }
     void sync() {}
     int scan_excl_add(int v, int* total) { *total = v; return 0; }
-    int scan_incl_max(int v) { return v; }
+    int scan_excl_max(int v, int* total) { *total = v; return -0x7fffffff; }
     int reduce_max(int v) { return v; }
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
 };
