@@ -407,6 +407,33 @@ def test_integration_snippet_compiles_and_links_against_the_c_abi(tmp_path):
     assert "abi 1" in r.stdout
 
 
+def test_ready_made_and_multi_gpu_snippets_compile_and_link(tmp_path):
+    """INTEGRATION.md's other two code blocks (block discovery -> sxg_smooth_gfa through the engine; the sharded entry
+    point) are kept in tests/csrc/integration_snippet2.cpp: same text as the document, compiles with -Wall -Werror
+    against both headers, links against both libraries, runs the host-only calls and stops at the missing device."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    src = os.path.join(HERE, "csrc", "integration_snippet2.cpp")
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = open(src).read()
+    n = 0
+    for part in code.split("// ---- INTEGRATION.md snippet begin")[1:]:
+        for line in part[:part.index("// ---- INTEGRATION.md snippet end")].splitlines()[1:]:
+            if line.strip():
+                assert line in md, "INTEGRATION.md and tests/csrc/integration_snippet2.cpp drifted apart: " + line
+                n += 1
+    assert n >= 12
+    P.load_library()
+    S.load_library()
+    exe = str(tmp_path / "snippet2")
+    libdir = os.path.join(root, "smoothxg_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"), src, "-o", exe,
+                           "-L", libdir, "-lsxgsmooth", "-lsxgpoa", "-L/opt/rocm/lib", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "discovery:" in r.stdout
+
+
 def gfa_with_links(text):
     """Adds the L lines the paths imply (a seqwish graph's edges are its path adjacencies)."""
     links = set()
