@@ -442,9 +442,10 @@ struct Variant {
 // packed sweep with 10, 12 or 13 columns per strip (128 VGPRs, a handful of spill slots): 20 480 / 24 576 / 26 624 columns.
 static bool variant_for_len(int maxlen, int rm, Variant* v, bool sw = false) {
     static const int kNW[] = {1, 2, 3, 4, 8, 12, 16};
-    static const int kW32[] = {16, 12, 8}, kW16[] = {13, 12, 11, 10, 9, 8};
+    // (narrow strips, 4-7 columns, for sequences below 1 kbp -- pggb's -l 700 ... 1100 -- in workgroups of up to 4 waves)
+    static const int kW32[] = {16, 12, 8}, kW16[] = {13, 12, 11, 10, 9, 8, 7, 6, 5, 4};
     const int* ws = rm == 2 ? kW16 : kW32;
-    const int nws = rm == 2 ? 6 : 3;
+    const int nws = rm == 2 ? 10 : 3;
     const int need = maxlen + 1;
     long best_cols = -1;
     for (int wi = 0; wi < nws; ++wi)
@@ -455,6 +456,7 @@ static bool variant_for_len(int maxlen, int rm, Variant* v, bool sw = false) {
             const bool wide = rm == 2 ? W > 8 : W > 12;   // needs > 128 VGPRs unless squeezed
             const bool long_class = rm == 2 && sw && NW == 16 && (W == 10 || W == 12 || W == 13);
             if (W == 13 && !long_class) continue;
+            if (rm == 2 && W < 8 && NW > 4) continue;
             if (wide && NW > 8 && !long_class) continue;
             if (best_cols < 0 || cols < best_cols) {
                 best_cols = cols;
@@ -500,6 +502,7 @@ static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
     SXG_PICK(pick_block, 256, 8); SXG_PICK(pick_block, 256, 12); SXG_PICK(pick_block, 256, 16);
     SXG_PICK(pick_block, 512, 8); SXG_PICK(pick_block, 512, 12); SXG_PICK(pick_block, 512, 16);
     SXG_PICK(pick_block, 1024, 8); SXG_PICK(pick_block, 1024, 12);
+    SXG_PICK16(pick_block, 256, 4); SXG_PICK16(pick_block, 256, 5); SXG_PICK16(pick_block, 256, 6); SXG_PICK16(pick_block, 256, 7);
     SXG_PICK16(pick_block, 256, 8); SXG_PICK16(pick_block, 256, 9); SXG_PICK16(pick_block, 256, 10);
     SXG_PICK16(pick_block, 256, 11); SXG_PICK16(pick_block, 256, 12);
     SXG_PICK16(pick_block, 512, 8); SXG_PICK16(pick_block, 512, 9); SXG_PICK16(pick_block, 512, 10);
@@ -516,6 +519,7 @@ static KernelFn<AlignArgs> align_kernel(const Variant& v, bool cvx, bool sw) {
     SXG_PICK(pick_align, 256, 8); SXG_PICK(pick_align, 256, 12); SXG_PICK(pick_align, 256, 16);
     SXG_PICK(pick_align, 512, 8); SXG_PICK(pick_align, 512, 12); SXG_PICK(pick_align, 512, 16);
     SXG_PICK(pick_align, 1024, 8); SXG_PICK(pick_align, 1024, 12);
+    SXG_PICK16(pick_align, 256, 4); SXG_PICK16(pick_align, 256, 5); SXG_PICK16(pick_align, 256, 6); SXG_PICK16(pick_align, 256, 7);
     SXG_PICK16(pick_align, 256, 8); SXG_PICK16(pick_align, 256, 9); SXG_PICK16(pick_align, 256, 10);
     SXG_PICK16(pick_align, 256, 11); SXG_PICK16(pick_align, 256, 12);
     SXG_PICK16(pick_align, 512, 8); SXG_PICK16(pick_align, 512, 9); SXG_PICK16(pick_align, 512, 10);
@@ -1045,6 +1049,19 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
                     plans.erase(plans.begin() + (long)j);
                 } else ++j;
             }
+        // A batch that cannot fill the device with one workgroup per block (1000 blocks of 1 kbp are 1000 waves of 4096)
+        // gives every block twice the waves at half the strip width: the same columns, shorter rows.
+        if (!getenv("SXG_POA_NO_SPREAD")) {
+            uint64_t waves = 0;
+            for (auto& pl : plans) waves += (uint64_t)pl.work.size() * (uint64_t)pl.variant.NW;
+            for (auto& pl : plans) {
+                Variant& v = pl.variant;
+                while (v.RM == 2 && v.NW <= 2 && v.W % 2 == 0 && v.W / 2 >= 4 && 2 * waves <= (uint64_t)h->num_cu * 16u) {
+                    waves += (uint64_t)pl.work.size() * (uint64_t)v.NW;
+                    v = Variant{v.W / 2, 2 * v.NW, 256, 2};
+                }
+            }
+        }
         const uint64_t budget = arena_budget(h);
         uint64_t want_bytes = 0;
         for (auto& pl : plans) {

@@ -208,35 +208,43 @@ def test_mixed_depth_and_length_batch_properties(engine, oracle):
     assert_block_equal(res[b], g, sc, cells, label="mixed-cheapest")
 
 
-def _packed_geometry(length):
+def _packed_geometry(length, spread=False):
     """The (threads, columns per lane) the engine's chooser gives a packed-sweep block whose longest
-    sequence has `length` bases: fewest padded columns, wider strip on ties (sxg_poa.hip)."""
+    sequence has `length` bases: fewest padded columns, wider strip on ties (sxg_poa.hip).  spread: what a batch too
+    small to fill the device gets -- twice the waves at half the strip width while both stay legal."""
     best = None
-    for W in (12, 11, 10, 9, 8):
+    for W in (12, 11, 10, 9, 8, 7, 6, 5, 4):
         for NW in (1, 2, 3, 4, 8, 12, 16):
             cols = 128 * NW * W
             if cols < length + 1:
                 continue
-            if W > 8 and NW > 8:
+            if (W > 8 and NW > 8) or (W < 8 and NW > 4):
                 continue
             if best is None or cols < best[0]:
-                best = (cols, 64 * NW, 2 * W)
+                best = (cols, NW, W)
             break
-    return best
+    cols, NW, W = best
+    while spread and NW <= 2 and W % 2 == 0 and W // 2 >= 4:
+        NW, W = 2 * NW, W // 2
+    return cols, 64 * NW, 2 * W
 
 
-def test_every_packed_strip_width_and_wave_count(engine, oracle):
-    """One block per packed geometry: strip widths 8..12 at 1, 2, 3, 4 and 8 waves; the engine's
-    stats confirm the geometry that ran, the oracle confirms the result."""
+@pytest.mark.parametrize("spread", [False, True])
+def test_every_packed_strip_width_and_wave_count(engine, oracle, monkeypatch, spread):
+    """One block per packed geometry: strip widths 4..12 at 1, 2, 3, 4 and 8 waves (4..7: up to 4 waves); the engine's
+    stats confirm the geometry that ran, the oracle confirms the result.  A one-block batch cannot fill the device, so
+    the engine spreads it over more waves (spread=True); SXG_POA_NO_SPREAD pins the geometry a large batch would get."""
+    if not spread:
+        monkeypatch.setenv("SXG_POA_NO_SPREAD", "1")
     rng = np.random.default_rng(41)
     wanted = {}
-    for W in (8, 9, 10, 11, 12):
+    for W in (4, 5, 6, 7, 8, 9, 10, 11, 12):
         for NW in (1, 2, 3, 4, 8):
             L = 128 * NW * W - 3
             cols, T, cpl = _packed_geometry(L)
             if (T, cpl) == (64 * NW, 2 * W):
                 wanted[(T, cpl)] = L
-    assert {c for (_, c) in wanted} == {16, 18, 20, 22, 24}
+    assert {c for (_, c) in wanted} == {8, 10, 12, 14, 16, 18, 20, 22, 24}
     assert {t for (t, _) in wanted} >= {64, 128, 192, 256, 512}
     for (T, cpl), L in sorted(wanted.items()):
         seqs = random_block(rng, 3, L, div=0.02)
@@ -246,9 +254,9 @@ def test_every_packed_strip_width_and_wave_count(engine, oracle):
         res = engine.run_blocks([seqs], gparams("convex_default", 0))
         st = engine.stats()
         assert st["dom_row_mode"] == 2
-        assert (st["dom_threads"], st["dom_cols_per_lane"]) == _packed_geometry(max(len(s) for s in seqs))[1:]
+        assert (st["dom_threads"], st["dom_cols_per_lane"]) == _packed_geometry(max(len(s) for s in seqs), spread)[1:]
         g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
-        assert_block_equal(res[0], g, sc, cells, label=f"packed T={T} cols/lane={cpl} L={L}")
+        assert_block_equal(res[0], g, sc, cells, label=f"packed T={T} cols/lane={cpl} L={L} spread={spread}")
 
 
 def test_global_alignment_outgrows_the_packed_range_and_is_rerun_wider(engine, oracle):
