@@ -167,7 +167,7 @@ typedef struct sxg_poa_stats {
     uint64_t dom_cells, dom_algo_bytes;
     int32_t dom_threads, dom_cols_per_lane; /* launch geometry */
     int32_t dom_row_mode;  /* 0/1 = 32-bit sweep (int16 / int32 row words), 2 = packed-int16 sweep, 3 = banded packed sweep */
-    int32_t reserved;
+    int32_t dom_clock_mhz; /* shader clock that launch ran at (cycles of its slots / their 100 MHz wall ticks); 0 = unknown */
 } sxg_poa_stats;
 
 int sxg_poa_abi_version(void);

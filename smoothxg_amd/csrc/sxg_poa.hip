@@ -813,6 +813,7 @@ struct LaunchPlan {
     std::vector<unsigned long long> est;  // cost-model cells per work item (priority balancing)
     // filled by prepare_plan
     SlotLayout lay; KernelFn<BlockArgs> kern = nullptr; int per_cu = 1; int64_t want_slots = 0, n_slots = 0;
+    int clock_mhz = 0;   // shader clock this launch ran at, sampled from its slots (see sample_clock)
     int smem = 0, pf_off = -1; bool park_lds = true; uint64_t cells = 0, bytes = 0; float ms = 0;
 };
 
@@ -868,6 +869,22 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&P.per_cu, (const void*)P.kern, V.T(), (size_t)P.smem) != hipSuccess || P.per_cu < 1)
         P.per_cu = 1;
     P.want_slots = std::min<int64_t>((int64_t)P.work.size(), (int64_t)h->num_cu * P.per_cu);
+}
+
+// The shader clock a launch ran at: every slot accumulates its phases in core-clock cycles (s_memtime) between two
+// readings of the constant 100 MHz counter (s_memrealtime); cycles / ticks * 100 MHz, over a sample of slots.  bench.py
+// prices the VALU roof with it -- the boxes of the pool sustain different clocks under this kernel.
+static int sample_clock(const LaunchPlan& P, const PlanRes& R) {
+    unsigned long long cyc = 0, ticks = 0;
+    const int64_t step = std::max<int64_t>(1, P.n_slots / 24);
+    for (int64_t sl = 0; sl < P.n_slots; sl += step) {
+        unsigned long long v[10];
+        if (hipMemcpy(v, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+        if (v[9] <= v[8]) continue;
+        for (int k = 0; k < 6; ++k) cyc += v[k];
+        ticks += v[9] - v[8];
+    }
+    return ticks ? (int)((double)cyc / (double)ticks * 100.0 + 0.5) : 0;
 }
 
 static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
@@ -1140,6 +1157,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         ms_total += ms;
         for (size_t i = 0; i < plans.size(); ++i) {
             HIPCHK(hipEventElapsedTime(&plans[i].ms, h->planres[i]->e0, h->planres[i]->e1));
+            plans[i].clock_mhz = sample_clock(plans[i], *h->planres[i]);
             h->stats.dp_launches += 1;
             h->stats.n_slots += (int)plans[i].n_slots;
             h->stats.device_bytes += (uint64_t)plans[i].n_slots * plans[i].lay.total;
@@ -1203,6 +1221,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             h->stats.dom_cells = pl.cells; h->stats.dom_algo_bytes = pl.bytes; h->stats.dom_kernel_ms = pl.ms;
             h->stats.dom_threads = pl.variant.T(); h->stats.dom_cols_per_lane = pl.variant.W * (pl.variant.RM >= 2 ? 2 : 1);
             h->stats.dom_row_mode = pl.variant.RM;
+            h->stats.dom_clock_mhz = pl.clock_mhz;
         }
     }
     lap("accounting");

@@ -62,7 +62,7 @@ class Stats(C.Structure):
                 ("algo_bytes", C.c_uint64), ("n_slots", C.c_int32), ("retries", C.c_int32),
                 ("device_bytes", C.c_uint64), ("dom_kernel_ms", C.c_double), ("dom_cells", C.c_uint64),
                 ("dom_algo_bytes", C.c_uint64), ("dom_threads", C.c_int32), ("dom_cols_per_lane", C.c_int32),
-                ("dom_row_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("dom_row_mode", C.c_int32), ("dom_clock_mhz", C.c_int32)]
 
 
 class DeviceView(C.Structure):
