@@ -199,7 +199,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
         V.B.row_prof = prof + 28;
         if ((t & 63) == 0) {  // placement of every wave (debug dump): smid | raw HW_ID, and the slot's start
             prof[10 + (t >> 6)] = ((unsigned long long)__smid() << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(GETREG_IMMED(31, 0, HW_ID));
-            if (t == 0 && prof[8] == 0) prof[8] = (unsigned long long)wall_clock64();
+            if (t == 0 && prof[8] == 0) { prof[8] = (unsigned long long)wall_clock64(); prof[6] = (unsigned long long)clock64(); }
         }
         unsigned long long tc0 = clock64(), tc1;
 #define PROF(k) do { if (t == 0) { tc1 = clock64(); prof[k] += tc1 - tc0; tc0 = tc1; } } while (0)
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
         if (t == 0) A.status[b] = status;
         if (t == 0 && V.B.prio_board) __hip_atomic_store(V.B.prio_board + V.B.prio_rank, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PROF(5);
-        if (t == 0) prof[9] = (unsigned long long)wall_clock64();
+        if (t == 0) { prof[9] = (unsigned long long)wall_clock64(); prof[7] = (unsigned long long)clock64(); }
 #undef PROF
     }
 }
@@ -871,8 +871,8 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     P.want_slots = std::min<int64_t>((int64_t)P.work.size(), (int64_t)h->num_cu * P.per_cu);
 }
 
-// The shader clock a launch ran at: every slot accumulates its phases in core-clock cycles (s_memtime) between two
-// readings of the constant 100 MHz counter (s_memrealtime); cycles / ticks * 100 MHz, over a sample of slots.  bench.py
+// The shader clock a launch ran at: every slot reads the core-clock counter (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime) when it starts and when it ends; cycles / ticks * 100 MHz, over a sample of slots.  bench.py
 // prices the VALU roof with it -- the boxes of the pool sustain different clocks under this kernel.
 static int sample_clock(const LaunchPlan& P, const PlanRes& R) {
     unsigned long long cyc = 0, ticks = 0;
@@ -880,8 +880,8 @@ static int sample_clock(const LaunchPlan& P, const PlanRes& R) {
     for (int64_t sl = 0; sl < P.n_slots; sl += step) {
         unsigned long long v[10];
         if (hipMemcpy(v, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
-        if (v[9] <= v[8]) continue;
-        for (int k = 0; k < 6; ++k) cyc += v[k];
+        if (v[9] <= v[8] || v[7] <= v[6]) continue;
+        cyc += v[7] - v[6];
         ticks += v[9] - v[8];
     }
     return ticks ? (int)((double)cyc / (double)ticks * 100.0 + 0.5) : 0;
@@ -938,10 +938,8 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
     A.num_cu = std::max(h->num_cu, 1);
     A.prio_board = getenv("SXG_POA_NO_BALANCE") ? nullptr : (uint32_t*)(R.queue.as<uint8_t>() + 256);
     A.est = R.est.as<unsigned long long>();
-    const bool dbg = getenv("SXG_POA_DEBUG") != nullptr;
-    if (dbg)
-        for (int64_t sl = 0; sl < P.n_slots; ++sl)
-            HIPCHK(hipMemsetAsync(R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr, 0, 512, R.stream));
+    // every slot's header (counters, phase times, clock readings) starts a launch at zero: one strided memset
+    HIPCHK(hipMemset2DAsync(R.arena.as<uint8_t>() + P.lay.hdr, P.lay.total, 0, 512, (size_t)P.n_slots, R.stream));
     HIPCHK(hipStreamWaitEvent(R.stream, h->ev0, 0));
     HIPCHK(hipEventRecord(R.e0, R.stream));
     hipLaunchKernelGGL(P.kern, dim3((unsigned)P.n_slots), dim3(V.T()), (size_t)P.smem, R.stream, A);
