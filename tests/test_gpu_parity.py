@@ -1,4 +1,6 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -352,3 +354,34 @@ def test_sharded_run_reassembles_in_block_order(engine, oracle):
         same(engine.run_flat_sharded(bases, seq_off, blk_off, w, gp, want_consensus=True, want_msa=True))
     finally:
         engine.lib.sxg_poa_comm_destroy(engine.h)
+
+
+def test_device_view_tensors_are_the_downloaded_results():
+    """What bench.py --gpus N hands to the lacing rank (shard.engine_result_tensors: zero-copy torch views of the engine's
+    HBM results) equals what download() returns.  In a process of its own that imports torch FIRST, as bench.py does:
+    torch brings its own HIP runtime, and a process that initialised the system one before finds no GPU through torch."""
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(0)
+import smoothxg_amd as S
+from smoothxg_amd import synth, shard
+eng = S.PoaEngine(0)
+bases, so, bo = synth.make_batch(12, 6, 400)
+eng.upload(bases, so, bo, None, S.Params(1, -4, -6, -2, -26, -1, 0, 0))
+eng.execute()
+ts = shard.engine_result_tensors(eng)
+res = eng.download()
+summ = ts[0].cpu().numpy().reshape(3, -1)
+assert (summ[0] == 0).all() and (summ[1] == [len(r.node_code) for r in res]).all()
+assert (summ[2] == [len(r.edge_tail) for r in res]).all()
+ref = np.concatenate([np.concatenate(r.paths) for r in res])
+assert ts[1].is_cuda and (ts[1].cpu().numpy() == ref).all()
+print("views ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "views ok" in r.stdout, r.stdout + r.stderr
