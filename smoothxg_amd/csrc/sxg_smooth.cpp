@@ -203,26 +203,65 @@ inline uint8_t code_of(char ch) {
 
 // ---------------------------------------------------------------------------------------------
 // output-side graph (odgi::graph_t's role): nodes, bidirected edges, named paths
-typedef std::pair<handle_t, handle_t> edge_t;
+struct edge_t {   // (a pair whose default constructor does not zero-fill: see uvec below)
+    handle_t first, second;
+    edge_t() {}
+    edge_t(handle_t a, handle_t b) : first(a), second(b) {}
+    bool operator<(const edge_t& o) const { return first < o.first || (first == o.first && second < o.second); }
+    bool operator==(const edge_t& o) const { return first == o.first && second == o.second; }
+};
 // graphs above this many nodes take the OpenMP forms of unchop / sort / GFA text (SXG_SMOOTH_PAR_MIN: tests force them on small graphs)
 inline size_t par_min() {
     static const size_t v = getenv("SXG_SMOOTH_PAR_MIN") ? (size_t)atoll(getenv("SXG_SMOOTH_PAR_MIN")) : 100000;
     return v;
 }
+// SXG_SMOOTH_TIMING=2: laps inside the phases of the laced graph (stderr)
+inline void sublap(const char* what) {
+    static const bool on = getenv("SXG_SMOOTH_TIMING") && atoi(getenv("SXG_SMOOTH_TIMING")) >= 2;
+    static auto T0 = std::chrono::steady_clock::now();
+    if (!on) return;
+    const auto T1 = std::chrono::steady_clock::now();
+    if (what) fprintf(stderr, "[sxg_smooth]   . %-28s %.3f s\n", what, std::chrono::duration<double>(T1 - T0).count());
+    T0 = T1;
+}
+// Vectors of the laced graph (1e7-1e8 elements) are allocated WITHOUT the serial zero-fill of std::vector(n) and
+// filled by the OpenMP loop that computes them: on the headline workload the fills and the sortedness checks
+// were a third of unchop's time.
+template <class T> struct noinit_alloc : std::allocator<T> {
+    template <class U> struct rebind { typedef noinit_alloc<U> other; };
+    template <class U> void construct(U* q) noexcept { ::new ((void*)q) U; }   // default-init: no store for trivial U
+    template <class U, class... A> void construct(U* q, A&&... a) { ::new ((void*)q) U(std::forward<A>(a)...); }
+};
+template <class T> using uvec = std::vector<T, noinit_alloc<T>>;
+template <class T> inline uvec<T> filled(size_t n, T v, bool par) {
+    uvec<T> o(n);
+#pragma omp parallel for schedule(static) if (par)
+    for (int64_t i = 0; i < (int64_t)n; ++i) o[(size_t)i] = v;
+    return o;
+}
 struct ograph_t {
     std::vector<std::string> seq;                       // node i has id i+1
-    std::vector<edge_t> edges;                          // canonical form, sorted, unique
+    uvec<edge_t> edges;                                 // canonical form, sorted, unique
     std::vector<std::pair<std::string, std::vector<handle_t>>> paths;
     static edge_t canon(handle_t a, handle_t b) {
         const edge_t x(a, b), y(flip(b), flip(a));
         return y < x ? y : x;
     }
     void sort_edges() {
-        if (!std::is_sorted(edges.begin(), edges.end())) {
-            if (edges.size() > 2 * par_min()) __gnu_parallel::sort(edges.begin(), edges.end());
+        const int64_t ne = (int64_t)edges.size();
+        const bool par = edges.size() > 2 * par_min();
+        // one (parallel) pass: already strictly increasing = sorted and unique, the usual case
+        int64_t unsorted = 0, dups = 0;
+#pragma omp parallel for schedule(static) reduction(+ : unsorted, dups) if (par)
+        for (int64_t x = 1; x < ne; ++x) {
+            if (edges[(size_t)x] < edges[(size_t)x - 1]) ++unsorted;
+            else if (edges[(size_t)x] == edges[(size_t)x - 1]) ++dups;
+        }
+        if (unsorted) {
+            if (par) __gnu_parallel::sort(edges.begin(), edges.end());
             else std::sort(edges.begin(), edges.end());
         }
-        edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+        if (unsorted || dups) edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
     }
 };
 
@@ -241,7 +280,7 @@ struct edge_acc_t {
         pool.push_back(item_t{e.second, head[e.first]});
         head[e.first] = (int32_t)pool.size() - 1;
     }
-    void into(std::vector<edge_t>& out) const {
+    void into(uvec<edge_t>& out) const {
         out.clear();
         out.reserve(pool.size());
         for (size_t h = 0; h < head.size(); ++h) {
@@ -261,8 +300,10 @@ void unchop(ograph_t& G) {
     const size_t n = G.seq.size();
     const int64_t ne = (int64_t)G.edges.size();
     const bool par = n > par_min();   // (the laced graph of the headline workload: 1.4e7 nodes, 2e7 edges, 1.6e8 steps)
-    std::vector<uint32_t> deg(2 * n, 0);
-    std::vector<handle_t> only(2 * n, 0);
+    if (par) sublap(nullptr);
+    uvec<uint32_t> deg = filled<uint32_t>(2 * n, 0, par);
+    uvec<handle_t> only = filled<handle_t>(2 * n, 0, par);
+    if (par) sublap("unchop: alloc deg/only");
 #pragma omp parallel for schedule(static) if (par)
     for (int64_t x = 0; x < ne; ++x) {
         const edge_t& e = G.edges[(size_t)x];
@@ -277,13 +318,14 @@ void unchop(ograph_t& G) {
 #pragma omp atomic write
         only[b] = flip(e.first);
     }
-    std::vector<char> start_at(2 * n, 0), end_at(2 * n, 0);
+    if (par) sublap("unchop: degrees");
+    uvec<char> start_at = filled<char>(2 * n, 0, par), end_at = filled<char>(2 * n, 0, par);
     for (auto& p : G.paths) {
         if (p.second.empty()) continue;
         start_at[p.second.front()] = 1; end_at[flip(p.second.front())] = 1;
         end_at[p.second.back()] = 1; start_at[flip(p.second.back())] = 1;
     }
-    std::vector<int64_t> next(n, -1), prev(n, -1);
+    uvec<int64_t> next = filled<int64_t>(n, -1, par), prev = filled<int64_t>(n, -1, par);
     // (a node v is the target of at most one u: v's left side has the single edge from u+)
 #pragma omp parallel for schedule(static) if (par)
     for (int64_t uu = 0; uu < (int64_t)n; ++uu) {
@@ -298,10 +340,11 @@ void unchop(ograph_t& G) {
         next[u] = (int64_t)v; prev[v] = (int64_t)u;
     }
     // chains hang off their heads (no predecessor); what no head reaches is a pure cycle, broken at its smallest member
-    std::vector<int64_t> chain_of(n, -1);
-    std::vector<size_t> heads;
+    if (par) sublap("unchop: links");
+    uvec<int64_t> chain_of = filled<int64_t>(n, -1, par);
+    uvec<size_t> heads;
     {
-        std::vector<char> reached(n, 0);
+        uvec<char> reached = filled<char>(n, 0, par);
 #pragma omp parallel for schedule(dynamic, 4096) if (par)
         for (int64_t uu = 0; uu < (int64_t)n; ++uu) {
             if (prev[(size_t)uu] >= 0) continue;
@@ -314,10 +357,26 @@ void unchop(ograph_t& G) {
             reached[u] = 1;
             next[(size_t)prev[m]] = -1; prev[m] = -1;
         }
-        for (size_t u = 0; u < n; ++u) if (prev[u] < 0) heads.push_back(u);
+        // heads in id order: counted and written per chunk
+        const int64_t CHK = 1 << 16, nch = ((int64_t)n + CHK - 1) / CHK;
+        std::vector<size_t> cnt((size_t)nch + 1, 0);
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t q = 0; q < nch; ++q) {
+            size_t k = 0;
+            for (int64_t u = q * CHK; u < std::min((int64_t)n, (q + 1) * CHK); ++u) k += prev[(size_t)u] < 0 ? 1 : 0;
+            cnt[(size_t)q + 1] = k;
+        }
+        for (int64_t q = 0; q < nch; ++q) cnt[(size_t)q + 1] += cnt[(size_t)q];
+        heads.resize(cnt[(size_t)nch]);
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t q = 0; q < nch; ++q) {
+            size_t w = cnt[(size_t)q];
+            for (int64_t u = q * CHK; u < std::min((int64_t)n, (q + 1) * CHK); ++u) if (prev[(size_t)u] < 0) heads[w++] = (size_t)u;
+        }
     }
+    if (par) sublap("unchop: heads");
     const int64_t nc = (int64_t)heads.size();
-    std::vector<int64_t> first_of((size_t)nc), last_of((size_t)nc);
+    uvec<int64_t> first_of((size_t)nc), last_of((size_t)nc);
     std::vector<std::string> nseq((size_t)nc);
 #pragma omp parallel for schedule(dynamic, 4096) if (par)
     for (int64_t c = 0; c < nc; ++c) {
@@ -331,9 +390,10 @@ void unchop(ograph_t& G) {
         }
         first_of[(size_t)c] = (int64_t)u; last_of[(size_t)c] = (int64_t)last;
     }
+    if (par) sublap("unchop: chain sequences");
     auto map_handle = [&](handle_t h) { return mk((uint64_t)chain_of[nid(h)], rev(h)); };
     // surviving edges, mapped: counted and written per chunk so that the order of G.edges is kept
-    std::vector<edge_t> nedges;
+    uvec<edge_t> nedges;
     {
         const int64_t CHK = 1 << 16, nch = (ne + CHK - 1) / CHK;
         std::vector<size_t> cnt((size_t)nch + 1, 0);
@@ -355,6 +415,7 @@ void unchop(ograph_t& G) {
             }
         }
     }
+    if (par) sublap("unchop: edges");
     const int64_t np = (int64_t)G.paths.size();
 #pragma omp parallel for schedule(dynamic, 1) if (par)
     for (int64_t q = 0; q < np; ++q) {
@@ -369,9 +430,11 @@ void unchop(ograph_t& G) {
         }
         st.resize(w);
     }
+    if (par) sublap("unchop: paths");
     G.seq.swap(nseq);
     G.edges.swap(nedges);
     G.sort_edges();
+    if (par) sublap("unchop: sort edges");
 }
 
 // topological order, by decree (odgi::algorithms::topological_order is absent): Kahn over the
@@ -512,15 +575,17 @@ ograph_t build_block_graph(const collected_t& c, const uint8_t* node_code, int64
         const int64_t len = (int64_t)c.seqs[i].size();
         for (size_t j = 0; j < c.dup_seq_names[i].size(); ++j) {
             std::vector<handle_t> st;
+            st.reserve((size_t)std::max<int64_t>(0, len - 2 * (int64_t)c.poa_padding));
             for (int64_t k = c.poa_padding; k < len - c.poa_padding; ++k) st.push_back(mk((uint64_t)seq_paths[i][k], false));
             if (c.dup_is_revs[i][j]) { std::reverse(st.begin(), st.end()); for (auto& h : st) h = flip(h); }
-            by_name.emplace_back(c.dup_seq_names[i][j], st);
+            by_name.emplace_back(c.dup_seq_names[i][j], std::move(st));
         }
     }
     if (!consensus_name.empty()) {
         std::vector<handle_t> st;
+        st.reserve((size_t)std::max<int64_t>(0, n_cons));
         for (int64_t k = 0; k < n_cons; ++k) st.push_back(mk((uint64_t)cons[k], false));
-        by_name.emplace_back(consensus_name, st);
+        by_name.emplace_back(consensus_name, std::move(st));
     }
     // :2639-2653 drop nodes no path visits; A10 :980-994 keeps only path-supported edges, so the
     // edge set IS the set of consecutive step pairs
@@ -1449,7 +1514,9 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
                 S.paths.emplace_back(std::string(p->consensus_base_name ? p->consensus_base_name : "Consensus_") + grp.ranges, steps);
             }
     }
+    sublap(nullptr);
     std::vector<ograph_t>().swap(graphs);
+    sublap("free block graphs");
     // walk every path and make sure its edges exist (src/main.cpp:1002-1016): inside a block they do by
     // construction (A10 keeps exactly the path-supported edges), so only the links between fragments are new
     {
@@ -1457,13 +1524,40 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         for (auto& l : links) lk.insert(lk.end(), l.begin(), l.end());
         std::sort(lk.begin(), lk.end());
         lk.erase(std::unique(lk.begin(), lk.end()), lk.end());
-        std::vector<edge_t> merged(S.edges.size() + lk.size());
-        // (the block edges are sorted: canonical and sorted inside a block, blocks at increasing id offsets)
-        merged.resize((size_t)(std::set_union(S.edges.begin(), S.edges.end(), lk.begin(), lk.end(), merged.begin()) - merged.begin()));
-        S.edges.swap(merged);
-        S.sort_edges();   // (no-op check)
+        // (the block edges are sorted and unique: canonical and sorted inside a block, blocks at increasing id offsets.
+        //  The few links -- one per fragment boundary -- are merged in by position: chunks of the block edges are
+        //  copied in parallel, each preceded by the new links that sort in front of its elements.)
+        std::vector<size_t> pos;   // new link j goes in front of block edge pos[j]
+        {
+            size_t w = 0;
+            for (size_t j = 0; j < lk.size(); ++j) {
+                const size_t at = (size_t)(std::lower_bound(S.edges.begin(), S.edges.end(), lk[j]) - S.edges.begin());
+                if (at < S.edges.size() && S.edges[at] == lk[j]) continue;   // the blocks hold it already
+                lk[w++] = lk[j];
+                pos.push_back(at);
+            }
+            lk.resize(w);
+        }
+        if (!lk.empty()) {
+            const int64_t ne0 = (int64_t)S.edges.size(), CHK = 1 << 16, nch = std::max<int64_t>(1, (ne0 + CHK - 1) / CHK);
+            uvec<edge_t> merged((size_t)ne0 + lk.size());
+#pragma omp parallel for schedule(static)
+            for (int64_t q = 0; q < nch; ++q) {
+                const int64_t lo = q * CHK, hi = q + 1 == nch ? ne0 : (q + 1) * CHK;
+                size_t j = (size_t)(std::lower_bound(pos.begin(), pos.end(), (size_t)lo) - pos.begin());
+                size_t w = (size_t)lo + j;
+                for (int64_t x = lo; x < hi; ++x) {
+                    while (j < pos.size() && pos[j] == (size_t)x) merged[w++] = lk[j++];
+                    merged[w++] = S.edges[(size_t)x];
+                }
+                if (q + 1 == nch) while (j < pos.size()) merged[w++] = lk[j++];   // links behind every block edge
+            }
+            S.edges.swap(merged);
+        }
     }
+    sublap("link edges");
     unchop(S);          // :1021
+    sublap(nullptr);
     lap("unchop");
     *out_gfa = to_gfa_c(S, nullptr);
     lap("GFA text");
