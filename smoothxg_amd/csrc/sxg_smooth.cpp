@@ -13,6 +13,7 @@
 #include "../../include/sxg_smooth.h"
 
 #include <omp.h>
+#include <sys/mman.h>
 #include <algorithm>
 #include <parallel/algorithm>
 #include <chrono>
@@ -227,12 +228,30 @@ inline void sublap(const char* what) {
 // Vectors of the laced graph (1e7-1e8 elements) are allocated WITHOUT the serial zero-fill of std::vector(n) and
 // filled by the OpenMP loop that computes them: on the headline workload the fills and the sortedness checks
 // were a third of unchop's time.
+// Allocations of 8 MiB and more are 2 MiB-aligned and marked for transparent huge pages: the iteration touches
+// ~10 GB of fresh memory on the headline workload, and 4 KiB first-touch faults (and their unmapping) are a
+// measurable part of every phase.  free() releases either kind.
+inline void* big_alloc(size_t bytes) {
+    if (bytes < ((size_t)8 << 20)) return malloc(bytes ? bytes : 1);
+    void* q = nullptr;
+    if (posix_memalign(&q, (size_t)2 << 20, bytes)) return nullptr;
+    static const bool thp = getenv("SXG_SMOOTH_NO_THP") == nullptr;   // (for A/B measurements)
+    if (thp) madvise(q, bytes, MADV_HUGEPAGE);
+    return q;
+}
 template <class T> struct noinit_alloc : std::allocator<T> {
     template <class U> struct rebind { typedef noinit_alloc<U> other; };
+    T* allocate(size_t n) {
+        void* q = big_alloc(n * sizeof(T));
+        if (!q) throw std::bad_alloc();
+        return (T*)q;
+    }
+    void deallocate(T* q, size_t) noexcept { free(q); }
     template <class U> void construct(U* q) noexcept { ::new ((void*)q) U; }   // default-init: no store for trivial U
     template <class U, class... A> void construct(U* q, A&&... a) { ::new ((void*)q) U(std::forward<A>(a)...); }
 };
 template <class T> using uvec = std::vector<T, noinit_alloc<T>>;
+typedef uvec<handle_t> steps_t;   // the steps of an output path
 template <class T> inline uvec<T> filled(size_t n, T v, bool par) {
     uvec<T> o(n);
 #pragma omp parallel for schedule(static) if (par)
@@ -240,9 +259,9 @@ template <class T> inline uvec<T> filled(size_t n, T v, bool par) {
     return o;
 }
 struct ograph_t {
-    std::vector<std::string> seq;                       // node i has id i+1
+    uvec<std::string> seq;                       // node i has id i+1
     uvec<edge_t> edges;                                 // canonical form, sorted, unique
-    std::vector<std::pair<std::string, std::vector<handle_t>>> paths;
+    std::vector<std::pair<std::string, steps_t>> paths;
     static edge_t canon(handle_t a, handle_t b) {
         const edge_t x(a, b), y(flip(b), flip(a));
         return y < x ? y : x;
@@ -377,7 +396,7 @@ void unchop(ograph_t& G) {
     if (par) sublap("unchop: heads");
     const int64_t nc = (int64_t)heads.size();
     uvec<int64_t> first_of((size_t)nc), last_of((size_t)nc);
-    std::vector<std::string> nseq((size_t)nc);
+    uvec<std::string> nseq((size_t)nc);
 #pragma omp parallel for schedule(dynamic, 4096) if (par)
     for (int64_t c = 0; c < nc; ++c) {
         const size_t u = heads[(size_t)c];
@@ -458,7 +477,7 @@ void topo_renumber(ograph_t& G) {
         for (uint32_t x = off[u]; x < off[u + 1]; ++x) if (--indeg[succ[x]] == 0) q.push(succ[x]);
     }
     for (size_t u = 0; u < n; ++u) if (newid[u] < 0) newid[u] = (int64_t)k++;
-    std::vector<std::string> nseq(n);
+    uvec<std::string> nseq(n);
     for (size_t u = 0; u < n; ++u) nseq[(size_t)newid[u]].swap(G.seq[u]);
     for (auto& e : G.edges) e = ograph_t::canon(mk((uint64_t)newid[nid(e.first)], rev(e.first)), mk((uint64_t)newid[nid(e.second)], rev(e.second)));
     G.sort_edges();
@@ -517,7 +536,7 @@ char* to_gfa_c(const ograph_t& G, size_t* out_len) {
         off[(size_t)q + 1] = bytes;
     }
     for (size_t q = 0; q < pieces; ++q) off[q + 1] += off[q];
-    char* buf = (char*)malloc(off.back() + 1);
+    char* buf = (char*)big_alloc(off.back() + 1);
     if (!buf) return nullptr;
     memcpy(buf, head, sizeof(head) - 1);
     // pass 2: every piece is written in place
@@ -570,11 +589,11 @@ ograph_t build_block_graph(const collected_t& c, const uint8_t* node_code, int64
     ograph_t G;
     // A9 (src/smooth.cpp:2583-2637): one node per POA node; a path per duplicate name, padding steps
     // trimmed at both ends, reversed and flipped when the range was collected in reverse
-    std::vector<std::pair<std::string, std::vector<handle_t>>> by_name;
+    std::vector<std::pair<std::string, steps_t>> by_name;
     for (size_t i = 0; i < c.seqs.size(); ++i) {
         const int64_t len = (int64_t)c.seqs[i].size();
         for (size_t j = 0; j < c.dup_seq_names[i].size(); ++j) {
-            std::vector<handle_t> st;
+            steps_t st;
             st.reserve((size_t)std::max<int64_t>(0, len - 2 * (int64_t)c.poa_padding));
             for (int64_t k = c.poa_padding; k < len - c.poa_padding; ++k) st.push_back(mk((uint64_t)seq_paths[i][k], false));
             if (c.dup_is_revs[i][j]) { std::reverse(st.begin(), st.end()); for (auto& h : st) h = flip(h); }
@@ -582,7 +601,7 @@ ograph_t build_block_graph(const collected_t& c, const uint8_t* node_code, int64
         }
     }
     if (!consensus_name.empty()) {
-        std::vector<handle_t> st;
+        steps_t st;
         st.reserve((size_t)std::max<int64_t>(0, n_cons));
         for (int64_t k = 0; k < n_cons; ++k) st.push_back(mk((uint64_t)cons[k], false));
         by_name.emplace_back(consensus_name, std::move(st));
@@ -607,7 +626,7 @@ ograph_t build_block_graph(const collected_t& c, const uint8_t* node_code, int64
     for (auto& nm : c.all_names_in_original_order) {
         const size_t k = idx[nm];
         if (!taken[k] && (consensus_name.empty() || k + 1 != by_name.size())) { G.paths.push_back(std::move(by_name[k])); taken[k] = 1; G.paths.back().first = nm; }
-        else G.paths.push_back(taken[k] ? *std::find_if(G.paths.begin(), G.paths.end(), [&](const std::pair<std::string, std::vector<handle_t>>& q) { return q.first == nm; }) : by_name[k]);
+        else G.paths.push_back(taken[k] ? *std::find_if(G.paths.begin(), G.paths.end(), [&](const std::pair<std::string, steps_t>& q) { return q.first == nm; }) : by_name[k]);
     }
     if (!consensus_name.empty()) G.paths.push_back(std::move(by_name.back()));
     unchop(G);          // :935
@@ -1447,7 +1466,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         const size_t a = runs[(size_t)q].first, z = runs[(size_t)q].second;
         size_t total = 0;
         for (size_t f = a; f < z; ++f) total += graphs[(size_t)mapping[f].block].paths[(size_t)mapping[f].target].second.size();
-        std::vector<handle_t> steps;
+        steps_t steps;
         steps.reserve(total);
         uint64_t last_end = 0;
         for (size_t f = a; f < z; ++f) {
@@ -1489,7 +1508,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
     // preserved, those of blocks that went into a merged group -- then one path per merged group that strings the
     // member blocks' consensus paths together in the group's order
     if (p->add_consensus) {
-        auto cons_steps = [&](int64_t k, std::vector<handle_t>& steps) {
+        auto cons_steps = [&](int64_t k, steps_t& steps) {
             if (graphs[(size_t)k].paths.empty()) return;
             for (handle_t h : graphs[(size_t)k].paths.back().second) steps.push_back(mk(nid(h) + id_trans[(size_t)k], rev(h)));
         };
@@ -1497,7 +1516,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         for (int64_t k = 0; k < nb; ++k) {
             if (graphs[(size_t)k].paths.empty()) continue;
             if (mp && !mstate.groups.empty() && !preserve && mstate.in_merged[(size_t)k]) continue;
-            std::vector<handle_t> steps;
+            steps_t steps;
             cons_steps(k, steps);
             S.paths.emplace_back(graphs[(size_t)k].paths.back().first, steps);
         }
@@ -1505,7 +1524,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
             for (auto& grp : mstate.groups) {
                 std::vector<std::pair<uint64_t, uint64_t>> iv = grp.intervals;   // [start, end)
                 std::sort(iv.begin(), iv.end());
-                std::vector<handle_t> steps;
+                steps_t steps;
                 if (!grp.inverted) { for (auto& x : iv) for (uint64_t k = x.first; k < x.second; ++k) cons_steps((int64_t)k, steps); }
                 else for (size_t j = iv.size(); j-- > 0;) for (uint64_t k = iv[j].second; k-- > iv[j].first;) cons_steps((int64_t)k, steps);
                 // (a merged consensus steps from one block's consensus into the next: edges the blocks do not hold)
@@ -1562,6 +1581,21 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
     *out_gfa = to_gfa_c(S, nullptr);
     lap("GFA text");
     if (!*out_gfa) return fail(SXG_E_NOMEM, "out of memory for the GFA text");
+    if (timing) {   // (the destructors, run here so that they show up as a phase)
+        sublap(nullptr);
+        { uvec<std::string> x; x.swap(S.seq); }
+        sublap("free S.seq");
+        { decltype(S.paths) x; x.swap(S.paths); }
+        sublap("free S.paths");
+        { decltype(S.edges) x; x.swap(S.edges); }
+        sublap("free S.edges");
+        { std::vector<collected_t> x; x.swap(col); }
+        sublap("free collected");
+        { batch_t x; std::swap(x, B); }
+        sublap("free batch");
+        { std::vector<frag_t> x; x.swap(mapping); }
+        lap("teardown");
+    }
     return SXG_OK;
 }
 
