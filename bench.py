@@ -353,15 +353,16 @@ def main():
         if pc:
             # per-cell figures from the counter passes (one launch of the same workload), scaled to THIS run's cells
             ipc = pc["SQ_INSTS_VALU"] / pc["cells_per_launch"]
-            bpc = pc["hbm_bytes_per_launch"] / pc["cells_per_launch"]
             valu_rate = ipc * cells / k_s
             valu_frac = valu_rate / valu_peak
-            traffic = bpc * launch_cells if pc["matches_build"] else None
             valu.update({"wave_insts_per_cell": ipc, "wave_insts_per_launch": ipc * launch_cells, "counter_file": pc["file"],
                          "counters_match_build": pc["matches_build"]})
-            hbm.update({"counter_bytes_per_cell": bpc, "counter_GBps": bpc * cells / k_s / 1e9,
-                        "counter_frac_of_peak": bpc * cells / k_s / 1e9 / HBM_PEAK_GBS,
-                        "counter_correction": pc.get("correction")})
+            if pc.get("hbm_bytes_per_launch"):
+                bpc = pc["hbm_bytes_per_launch"] / pc["cells_per_launch"]
+                traffic = bpc * launch_cells if pc["matches_build"] else None
+                hbm.update({"counter_bytes_per_cell": bpc, "counter_GBps": bpc * cells / k_s / 1e9,
+                            "counter_frac_of_peak": bpc * cells / k_s / 1e9 / HBM_PEAK_GBS,
+                            "counter_correction": pc.get("correction")})
         out = {
             "metric": "POA blocks/sec (+ DP cells/sec) on 1000-block synthetic",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -383,7 +384,7 @@ def main():
                          "kernel": "poa_block_kernel<T=%d, cols/lane=%d, %s>" % (
                              st["dom_threads"], st["dom_cols_per_lane"],
                              {2: "packed int16 sweep", 3: "banded packed int16 sweep (one wave, sliding window)"}.get(st["dom_row_mode"], "32-bit sweep")),
-                         "kernel_ms_per_launch": kernel_ms / max(launches, 1),
+                         "kernel_ms_per_launch": kernel_ms / max(launches, 1), "kernel_ms_total": kernel_ms,
                          "algo_bytes_per_launch": algo_bytes / max(launches, 1),
                          "bytes_per_cell": algo_bytes / max(cells, 1),
                          "valu": valu, "hbm": hbm},

@@ -68,7 +68,55 @@ if os.path.exists(b):
                     "FETCH_SIZE_KB": F, "WRITE_SIZE_KB": W, "hbm_bytes_per_launch": (2 * F + W) * 1024,
                     "hbm_bytes_per_launch_uncorrected": (F + W) * 1024,
                     "correction": traffic["ns_sw"]["correction"]}}}
+    # the other BASELINE shapes (profiles/run_wl_pmc.sh): counters summed over EVERY poa_block dispatch of one step
+    for d_v in sorted(glob.glob(os.path.join(OUT, "wl_*_SQ_INSTS_VALU"))):
+        wl = os.path.basename(d_v)[3:-len("_SQ_INSTS_VALU")]
+        tot = {}
+        for c in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+            f = glob.glob(os.path.join(OUT, "wl_%s_%s" % (wl, c), "*counter_collection.csv"))
+            if not f:
+                continue
+            tot[c] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "poa_block" in r["Kernel_Name"] and r["Counter_Name"] == c)
+        log = os.path.join(OUT, "wl_%s_SQ_INSTS_VALU.log" % wl)
+        line = [l for l in open(log).read().splitlines() if l.startswith("{") and '"metric"' in l]
+        if "SQ_INSTS_VALU" not in tot or not line:
+            continue
+        bl = json.loads(line[-1])
+        e = {"kernel": "every poa_block_kernel dispatch of one step (%s)" % bl["roofline"]["kernel"],
+             "cells_per_launch": bl["config"]["cells_per_step_per_gpu"], "per": "step (all launches and retry rounds)",
+             "SQ_INSTS_VALU": tot["SQ_INSTS_VALU"]}
+        if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+            e.update({"FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"],
+                      "hbm_bytes_per_launch": (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024,
+                      "hbm_bytes_per_launch_uncorrected": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024,
+                      "correction": traffic["ns_sw"]["correction"]})
+        counters["workloads"][wl.replace("+", "_") if "+" in wl else "%s_sw" % wl] = e
+        print("workload %s: VALU instrs/step %.3e, %.3f per cell" % (wl, tot["SQ_INSTS_VALU"], tot["SQ_INSTS_VALU"] / e["cells_per_launch"]))
     json.dump(counters, open(os.path.join(dst, "counters.json"), "w"), indent=1)
+    # bench lines of those shapes (gpurun_out/bench_<workload>[_nw].json): lines printed before their counters existed are
+    # restated with them, exactly as bench.py does when it finds the counters
+    for key, e in counters["workloads"].items():
+        name = key[:-3] if key.endswith("_sw") else key
+        src = os.path.join(OUT, "bench_%s.json" % name)
+        if key == "ns_sw" or not os.path.exists(src):
+            continue
+        txt = [l for l in open(src).read().splitlines() if l.startswith("{")]
+        if not txt:
+            continue
+        bl = json.loads(txt[-1])
+        r = bl["roofline"]
+        if r.get("bound") != "valu" and r.get("valu"):
+            cells = bl["config"]["cells_per_step_per_gpu"] * bl["steps"]
+            k_s = bl["roofline"]["kernel_ms_total"] / 1e3 if "kernel_ms_total" in bl["roofline"] else None
+            if k_s:
+                ipc = e["SQ_INSTS_VALU"] / e["cells_per_launch"]
+                peak = r["valu"]["peak_wave_insts_per_s"]
+                r.update({"bound": "valu", "achieved": ipc * cells / k_s / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+                          "frac": ipc * cells / k_s / peak})
+                r["valu"].update({"wave_insts_per_cell": ipc, "counter_file": "profiles/%s/counters.json" % rnd, "counters_match_build": True,
+                                  "note": "counters collected in the same gpurun call as this bench line, on the same build"})
+        open(os.path.join(dst, "bench_%s.json" % name), "w").write(json.dumps(bl) + "\n")
+        print("bench %s: %.1f %s, bound %s, frac %.3f" % (name, bl["value"], bl["unit"], r["bound"], r["frac"]))
     d["roofline"]["traffic"] = traffic["ns_sw"]["hbm_bytes_per_launch"]
     # the bench line of this same gpurun call was printed BEFORE these counters existed: restate its VALU roofline with them
     r = d["roofline"]
