@@ -22,8 +22,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------
 // workgroup context for poa_graph_dev.h
+// (the scratch words are held as an LDS-address-space pointer built from the LDS offset: a generic pointer to them became a
+// constant "addrspacecast(smem) + 512" argument of the out-of-line graph phases after inter-procedural constant propagation,
+// whose null check -- 0 against the shared aperture -- the AMDGPU back end emits as an illegal VOPC encoding for some kernels)
+typedef __attribute__((address_space(3))) int sxg_lds_int;
 struct WgCtx {
-    int* lds;  // >= 2*16+2 ints of LDS scratch
+    sxg_lds_int* lds;  // >= 2*16+2 ints of LDS scratch
     __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -167,6 +171,7 @@ struct DpBuffers {
     void* row0;        // [Lpad] packed virtual source row
     void* park;        // [Lpad] parked previous row when it cannot live in LDS
     int band_strips;   // packed sweep: strips per row kept in the traceback plane (see poa_dp16.hip.h)
+    int lds_rows;      // packed sweep: on-chip copies of stored rows the workgroup's LDS holds (RowCaps::lds_rows)
     int band_w;        // banded sweep (poa_band16.hip.h): half-width of the band in columns, wb + (int)(wf * L)
     int prio_rank;     // launch rank of this workgroup among its CU's co-residents (see sxg_rotate_prio)
     uint32_t* prio_board;          // this CU's progress board (PRIO_BOARD_SLOTS words) or nullptr
@@ -245,9 +250,15 @@ __host__ __device__ constexpr int dp16_let_words(int W) { return (W + 1) / 2; }
 // One- and two-wave workgroups (sequences up to ~3 kbp, the usual smoothxg block) are LDS-bound in
 // occupancy: they stage 128 row descriptors instead of 256 (and walk a 32-row traceback window),
 // 4 KB instead of 8 KB, which lets 14 instead of 10 of them share a CU.
-__host__ __device__ constexpr int dp16_meta_bytes(int T) { return T <= 128 ? LDS_META_BYTES / 2 : LDS_META_BYTES; }
-__host__ __device__ constexpr int dp16_lds_bytes(int T, int W) {
-    return LDS_CTL_BYTES + dp16_meta_bytes(T) + T * W * 8 + T * dp16_let_words(W) * 4;
+// (round 3: the packed sweep reads its row descriptors through the scalar cache; what is left of the staging area holds the
+// wave-to-wave mailboxes during a sweep and the traceback window after it: 4 KB for every geometry)
+__host__ __device__ constexpr int dp16_meta_bytes(int) { return LDS_META_BYTES / 2; }
+__host__ __device__ constexpr int dp16_row_bytes(int T, int W) { return T * W * 8 + T * 4; }   // a stored row + its left-neighbour words
+// control words | mailboxes / traceback window | lds_rows on-chip copies of stored rows | query letters.  The traceback
+// keeps its precomputed runs (2.3 KB) where the row copies start: never less than that behind the window.
+__host__ __device__ constexpr int dp16_lds_bytes(int T, int W, int lds_rows) {
+    const int body = lds_rows * dp16_row_bytes(T, W) + T * dp16_let_words(W) * 4;
+    return LDS_CTL_BYTES + dp16_meta_bytes(T) + (body > 2560 ? body : 2560);
 }
 __host__ __device__ constexpr int dp_lds_launch_bytes(int Lpad, int word_bytes) {
     return dp_park_in_lds(Lpad, word_bytes) ? dp_lds_bytes(Lpad, word_bytes) : LDS_CTL_BYTES + LDS_META_BYTES;
@@ -705,8 +716,11 @@ __device__ __forceinline__ int winner_ordinal(const RowsView& R, const DpBuffers
     return 0;
 }
 
+// (views by value: a reference to the kernel's private copy makes the out-of-line callee read it through FLAT pointers
+// whose private-aperture null check trips an AMDGPU back-end assertion for some strip widths -- which ones changes with
+// every unrelated edit of the kernel)
 template <bool PAIRS>
-__device__ __noinline__ int traceback(const RowsView& R, const DpBuffers& B, const int T, const int W, const int sw, int i, int j,
+__device__ __noinline__ int traceback(const RowsView R, const DpBuffers B, const int T, const int W, const int sw, int i, int j,
                          int32_t* posnode, int32_t* pair_row, int32_t* pair_pos) {
     const int Lpad = T * W;
     int n = 0, st = SRC_STOP;

@@ -38,6 +38,15 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NEGP = -16384;  // "minus infinity" of the packed sweep
+// LOCAL alignments run the packed sweep on BIASED fields: a register half holds score + P16_BIAS, always inside
+// [P16_FLOOR, 32767].  Every reachable value of a local alignment is >= min(g, q) >= -120 (H >= 0, every gap state is
+// some H plus at most one opening) and the few "minus infinity" inputs (the column left of column 0, a carry that enters
+// strip 0) are replaced by P16_FLOOR - P16_BIAS = -512, which never wins a maximum.  Fields that never leave
+// [0, 65535] make a PLAIN 32-bit add/subtract of a constant -- or of any register whose fields do not underflow --
+// correct on both halves at once (no borrow ever crosses bit 16), and on gfx950 v_add_u32 / v_sub_u32 issue every 2
+// cycles per wave where every VOP3P instruction (v_pk_add_i16, v_pk_max_i16, ...) takes 4
+// (profiles/r03/op_rate.txt): 37 % of the row loop's VALU instructions were packed adds and subtracts.
+constexpr int P16_BIAS = 1024, P16_FLOOR = 512;
 
 __device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b))); }
 __device__ __forceinline__ int pk_sub(int a, int b) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); }
@@ -51,15 +60,19 @@ __device__ __forceinline__ int pk_hi(int v) { return v >> 16; }
 // to the row's OUTGOING gap candidates oF = max(H + g, F + e), oO = max(H + q, O + c) -- what every
 // successor takes as its F / O.  H >= F and g <= e < 0 bound the distances to [-e, -g] and [-c, -q]:
 // one byte each, never clamped (host check: |g|, |q| <= 120).
-template <bool CVX>
+// (BIASED: the fields are biased and h >= of, oo field by field, so the differences are plain 32-bit subtractions)
+template <bool CVX, bool BIASED = false>
 __device__ __forceinline__ u32x2 p16_pack_row(int h, int of, int oo) {
-    const int df = pk_sub(h, of);
-    return u32x2{(unsigned)h, (unsigned)(CVX ? (df | (pk_sub(h, oo) << 8)) : df)};
+    const int df = BIASED ? (int)((unsigned)h - (unsigned)of) : pk_sub(h, of);
+    const int dq = BIASED ? (int)((unsigned)h - (unsigned)oo) : pk_sub(h, oo);
+    return u32x2{(unsigned)h, (unsigned)(CVX ? (df | (dq << 8)) : df)};
 }
+template <bool BIASED = false>
 __device__ __forceinline__ void p16_unpack_row(u32x2 w, int& h, int& of, int& oo) {
     h = (int)w.x;
-    of = pk_sub(h, (int)(w.y & 0x00ff00ffu));
-    oo = pk_sub(h, (int)((w.y >> 8) & 0x00ff00ffu));
+    const int df = (int)(w.y & 0x00ff00ffu), dq = (int)((w.y >> 8) & 0x00ff00ffu);
+    of = BIASED ? (int)((unsigned)h - (unsigned)df) : pk_sub(h, df);
+    oo = BIASED ? (int)((unsigned)h - (unsigned)dq) : pk_sub(h, dq);
 }
 
 // Buffer addressing for the sweep's rows: address = descriptor base (one row of the ring / of the plane,
@@ -99,23 +112,48 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     const int T = (int)blockDim.x;
     const int NW = T >> 6;
     const int TW = T * W;           // columns of one half
-    const int MB = dp16_meta_bytes(T), CH = MB / 32;  // descriptor staging area: bytes, rows per chunk
+    const int MB = dp16_meta_bytes(T);   // (bytes of the LDS area the traceback window uses; the sweep keeps its mailboxes there)
     int* lds = (int*)smem;
-    const i32x4* lmeta = (const i32x4*)(smem + LDS_CTL_BYTES);
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int j0 = t * W;           // first column of my lo strip; hi strip starts at TW + j0
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    // Wave w owns the 128 strips [128 w, 128 w + 128): lane l its strips 128 w + l (low halves) and 128 w + 64 + l (high
+    // halves).  A wave's columns are contiguous, so the ONLY thing that crosses a wave boundary inside a row is what crosses
+    // one column boundary: the gap states entering the wave's first column and the diagonal's source left of it.
+    const int s_lo = wv * 128 + lane, s_hi = s_lo + 64;
+    const int j0 = s_lo * W, j0h = s_hi * W;   // first columns of my two strips
     // scoring values are block-uniform: keep them (and everything derived) in SGPRs
     const int g = __builtin_amdgcn_readfirstlane(S.g), e = __builtin_amdgcn_readfirstlane(S.e);
     const int q = __builtin_amdgcn_readfirstlane(S.q), c = __builtin_amdgcn_readfirstlane(S.c);
     const int G2 = pk2(g, g), E2 = pk2(e, e), Q2 = pk2(q, q), C2 = pk2(c, c);
     const int sm = __builtin_amdgcn_readfirstlane(S.m), sn = __builtin_amdgcn_readfirstlane(S.n);
-    const int NEG2 = pk2(NEGP, NEGP);
+    // local alignment: biased fields (see P16_BIAS); "x + K" for a penalty K <= 0 is then x - |K| * 0x10001 in 32 bits
+    constexpr int BIAS = SW ? P16_BIAS : 0, FLOORV = SW ? P16_FLOOR : NEGP;
+    const int NEG2 = pk2(FLOORV, FLOORV), B2 = pk2(BIAS, BIAS);
+    const unsigned Gm = (unsigned)(-g) * 0x10001u, Em = (unsigned)(-e) * 0x10001u, Qm = (unsigned)(-q) * 0x10001u, Cm = (unsigned)(-c) * 0x10001u;
+#define P16_DEC(x, Km, K2) (SW ? (int)((unsigned)(x) - (Km)) : pk_add((x), (K2)))   /* x + K */
+#define P16_INC(x, Km, K2) (SW ? (int)((unsigned)(x) + (Km)) : pk_sub((x), (K2)))   /* x - K */
     // substitution scores come out of a per-row byte table (see pass 1): all-mismatch rows of it, and match ^ mismatch
     const unsigned SC_N4 = (unsigned)(sn & 0xff) * 0x01010101u, SC_MX = (unsigned)((sm ^ sn) & 0xff);
     const int We = W * e, Wc = W * c;
     const int BS = __builtin_amdgcn_readfirstlane(B.band_strips);
-    int* tot = lds;            // [4][16]: a_lo, a_hi, b_lo, b_hi inclusive totals per wave
-    int* xch = lds + 64;       // [16]: Hc[W-1] (packed) of every wave's last lane
+    // ---- wave pipeline.  The waves of a workgroup do NOT meet inside the row loop.  Wave w sweeps row i as soon as wave
+    // w-1 has handed over, through a ring of P16_MBOX mailboxes in LDS, the three values that cross its left edge in row i:
+    // E and Q entering its first column and H of the column left of it (one 16-byte word {E, Q, H, row}, written and read
+    // by single LDS instructions; the row number is the "full" flag).  Everything else a wave reads it wrote itself: rows
+    // in the ring are lane-private, and a stored row carries the left-neighbour column of every lane as one more word.
+    // Waves drift apart by up to P16_MBOX rows (a writer checks every P16_MBOX / 2 rows that its reader has freed the
+    // slots it is about to reuse), so a wave that waits -- for a stored predecessor row, for its SIMD -- delays its
+    // successors only once that slack is used up: the per-row cost is the AVERAGE over the waves, not the maximum that
+    // two s_barrier per row made it (47 % of the wave time was parked in round 2).
+    typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
+    typedef __attribute__((address_space(3))) int lds_i32;
+    constexpr int P16_MBOX = 16;
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_groupstaticsize();
+    volatile lds_i32x4* const mb_in = (volatile lds_i32x4*)(size_t)(lds0 + (unsigned)(LDS_CTL_BYTES + (max(wv, 1) - 1) * P16_MBOX * 16));
+    volatile lds_i32x4* const mb_out = (volatile lds_i32x4*)(size_t)(lds0 + (unsigned)(LDS_CTL_BYTES + wv * P16_MBOX * 16));
+    volatile lds_i32* const prog = (volatile lds_i32*)(size_t)(lds0 + 64u * 4u);   // [16] rows consumed by wave w
+    if (lane < P16_MBOX) mb_out[lane] = i32x4{0, 0, 0, 0};
+    if (lane == 0) prog[wv] = 0;
+    __syncthreads();
 
     // query letters, one byte per (strip, column), as SELECTORS into the row's score table: A,C,G,T,N = 0..4, "no letter"
     // (padding columns, never a match) = 5.  Register k2 holds the bytes (lo_k+1, lo_k, hi_k+1, hi_k) of columns
@@ -129,7 +167,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int kc = 2 * k2 + ((b & 1) ? 0 : 1);  // strip-local column (W odd: one spare pair)
-            const int j = ((b >> 1) ? TW : 0) + j0 + kc;
+            const int j = ((b >> 1) ? j0h : j0) + kc;
             const bool valid = kc < W && j >= 1 && j <= L;
             const unsigned ch = valid ? (unsigned)seq[j - 1] : 5u;
             v |= (valid && ch > 4u ? 4u : ch) << (8 * b);
@@ -142,7 +180,8 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     // two wide LDS loads per row.
     // (raw LDS byte offset: the dynamic LDS starts right behind the kernel's static LDS)
     typedef __attribute__((address_space(3))) unsigned lds_u32;
-    const unsigned llet_off = (unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)(LDS_CTL_BYTES + MB + TW * 8 + t * NL * 4);
+    const int LDS_ROWS = __builtin_amdgcn_readfirstlane(B.lds_rows);
+    const unsigned llet_off = (unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)(LDS_CTL_BYTES + MB + LDS_ROWS * (TW * 8 + T * 4) + t * NL * 4);
 #pragma unroll
     for (int k2 = 0; k2 < NL; ++k2) ((lds_u32*)(size_t)llet_off)[k2] = let[k2];
 
@@ -164,33 +203,37 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         int h2[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const int j = hf * TW + j0 + k;
-            int h = 0;
+            const int j = (hf ? j0h : j0) + k;
+            int h = BIAS;
             if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = max(a > b ? a : b, NEGP); }
             h2[hf] = h;
         }
         Hp[k] = pk2(h2[0], h2[1]);
-        Fp[k] = pk_add(Hp[k], G2);                  // nothing to extend in row 0: both candidates open
-        Op[k] = CVX ? pk_add(Hp[k], Q2) : NEG2;
+        Fp[k] = P16_DEC(Hp[k], Gm, G2);             // nothing to extend in row 0: both candidates open
+        Op[k] = CVX ? P16_DEC(Hp[k], Qm, Q2) : NEG2;
     }
     {
         int h2[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const int j = hf * TW + j0 - 1;
-            int h = 0;
+            const int j = (hf ? j0h : j0) - 1;
+            int h = BIAS;
             if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = max(a > b ? a : b, NEGP); }
-            h2[hf] = j < 0 ? NEGP : h;
+            h2[hf] = j < 0 ? FLOORV : h;
         }
         Hleft = pk2(h2[0], h2[1]);
     }
+    // a stored row: W columns of 8-byte words [column][lane], then the column LEFT of every lane's strips (4 bytes per lane)
+    const int RB = TW * 8 + T * 4;
     {
+        const __amdgpu_buffer_rsrc_t rs0 = p16_rsrc((const void*)g_row0, RB);
 #pragma unroll
         for (int k = 0; k < W; ++k)
-            __builtin_amdgcn_raw_buffer_store_b64(p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]), p16_rsrc((const void*)g_row0, TW * 8), ut8, k * T * 8, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(p16_pack_row<CVX, SW>(Hp[k], Fp[k], Op[k]), rs0, ut8, k * T * 8, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)Hleft, rs0, (unsigned)t * 4u, TW * 8, 0);
     }
-    int best_lo = SW ? 0 : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;
-    const int kL_lo = L - j0, kL_hi = L - TW - j0;  // strip-local index of the end column L
+    int best_lo = SW ? BIAS : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;
+    const int kL_lo = L - j0, kL_hi = L - j0h;  // strip-local index of the end column L
 
     bool next_sib = false;      // decided at the end of a row for its successor
     // (An L2 warm-up for the next row's stored predecessor -- one load per wave touching its 44 cache lines a row ahead,
@@ -200,17 +243,24 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     // this row's stores, was measured again in round 2 with the spills gone: 2.81 s against 2.68 s.  At this VALU
     // occupancy the co-resident workgroups already hide the round trip; its ~60 extra instructions do not pay.)
     typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
-#define P16_LROW(ptr_)                                                                                      \
-    int tp_ = t;                                                                                            \
-    asm volatile("" : "+v"(tp_));   /* raw LDS offset rebuilt from an opaque t: no loop-invariant address register */ \
-    lds_u32x2* const ptr_ = (lds_u32x2*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() +            \
-                                                 (unsigned)(LDS_CTL_BYTES + MB) + (unsigned)(tp_ * W) * 8u)
+    // on-chip copies of stored rows (finish_rows: a stored row whose last reader comes before LDS_ROWS more rows are stored
+    // lives in LDS only and never travels to HBM): behind the control words and the mailbox / traceback-window area
+    const unsigned lds_rows0 = lds0 + (unsigned)(LDS_CTL_BYTES + MB);
+// my words of on-chip row copy b_: W 8-byte words [wave][column][lane] (a wave's 64 lanes side by side: every LDS access of
+// the sweep is conflict-free, and column k is the immediate offset k * 512), then the left-neighbour word [lane].  The
+// addresses are rebuilt from an opaque copy of the thread index: no loop-invariant address registers.
+#define P16_LDS_ROW(words_, left_, b_)                                                                      \
+    int tq_ = t;                                                                                            \
+    asm volatile("" : "+v"(tq_));                                                                           \
+    const unsigned lb_ = lds_rows0 + (unsigned)(b_) * (unsigned)RB;                                         \
+    lds_u32x2* const words_ = (lds_u32x2*)(size_t)(lb_ + (unsigned)(wv * (512 * W - 512)) + (unsigned)tq_ * 8u); \
+    lds_u32* const left_ = (lds_u32*)(size_t)(lb_ + (unsigned)(TW * 8) + (unsigned)tq_ * 4u)
     // (B lives in the kernel's private memory: testing B.prio_board per row was a scratch load plus an
     // in-order vmcnt(0) -- a wait for every store of the previous row -- at the top of EVERY row)
     const bool has_board = __builtin_amdgcn_readfirstlane((int)(B.prio_board != nullptr)) != 0;
     // slots of my two strips in a plane row (strip s -> slot s mod BS: the address of a cell does not depend
     // on where the row's band starts, so the traceback fetches cells and row descriptors in ONE round trip)
-    const unsigned soff = (unsigned)(t % BS) | ((unsigned)((T + t) % BS) << 16);
+    const unsigned soff = (unsigned)(s_lo % BS) | ((unsigned)(s_hi % BS) << 16);
     const int prio_rank = __builtin_amdgcn_readfirstlane(B.prio_rank);
 #ifdef SXG_ROW_PROF
 // profiling builds: wait for the fetched row right away and book the time as segment 6 ("stored row fetch")
@@ -224,27 +274,21 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
 #else
 #define RP_MARK(seg) do { } while (0)
 #endif
+    // Row descriptors (RowMeta, 32 bytes) come through the SCALAR data path, one s_load_dwordx8 per row issued a row ahead:
+    // every wave is at its own row, so there is no chunk of descriptors the workgroup could stage together.  The scalar
+    // cache is not coherent with the vector stores that wrote the descriptors (prep_rows, the band-miss hint shift): it is
+    // invalidated once per sweep, after the workgroup barrier that follows those stores.
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(4))) const i32x8 const_i32x8;
+    const_i32x8* const cmeta = (const_i32x8*)(unsigned long long)g_meta;
+    __builtin_amdgcn_s_dcache_inv();
+    i32x8 dnext = cmeta[0];
     for (int i = 1; i <= N; ++i) {
         if (has_board) { if ((i & 127) == 1) sxg_balance_prio(B, (unsigned long long)i * (unsigned long long)L); }
         else if ((i & 63) == 1) sxg_rotate_prio(prio_rank);
-        const int r = i - 1;
-        if ((r & (CH - 1)) == 0) {
-            __syncthreads();
-            SXG_GLOBAL const i32x4* gm = (SXG_GLOBAL const i32x4*)(g_meta + 8 * (size_t)r);
-            i32x4* lm = (i32x4*)(smem + LDS_CTL_BYTES);
-            const int nrow = min(CH, N - r);
-            for (int x = t; x < 2 * nrow; x += T) lm[x] = gm[x];
-            __syncthreads();
-        }
-        const i32x4 m0 = lmeta[2 * (r & (CH - 1))], m1 = lmeta[2 * (r & (CH - 1)) + 1];
-        const int pb = __builtin_amdgcn_readfirstlane(m0.x);
-        const int info = __builtin_amdgcn_readfirstlane(m0.y);
-        const int p0 = __builtin_amdgcn_readfirstlane(m0.z);
-        const int s0 = __builtin_amdgcn_readfirstlane(m0.w);
-        const int p1 = __builtin_amdgcn_readfirstlane(m1.x);
-        const int s1 = __builtin_amdgcn_readfirstlane(m1.y);
-        const int myslot = __builtin_amdgcn_readfirstlane(m1.z);
-        const int hint = __builtin_amdgcn_readfirstlane(m1.w);
+        const i32x8 dsc = dnext;
+        dnext = cmeta[min(i, N - 1)];
+        const int pb = dsc[0], info = dsc[1], p0 = dsc[2], s0 = dsc[3], p1 = dsc[4], s1 = dsc[5], myslot = dsc[6], hint = dsc[7];
         const int np = info & 0xffff, code = (info >> 16) & 0xff, flags = (info >> 24) & 0xff;
         // score table of this row: byte c = score(node letter, query letter c); c = 5 (no letter) never matches
         const unsigned SC_T0 = SC_N4 ^ (code < 4 ? SC_MX << (8 * code) : 0u), SC_T1 = SC_N4 ^ (code == 4 ? SC_MX : 0u);
@@ -257,24 +301,25 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         // row announced this one as its sibling (an alternative allele: the same single predecessor),
         // that row's own F/O, which are this row's too.
         const bool sib = next_sib;
-// the column left of my strips in a stored row: lane t-1's last column; lane 0: lo = none,
-// hi = last column of the lo half (lane T-1)
-#define P16_LOAD_LEFT(rs_, hl)                                                                              \
-    do {                                                                                                    \
-        if (t > 0) hl = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_, ut8, (W - 1) * T * 8 - 8, 0);         \
-        else hl = pk2(NEGP, pk_lo((int)__builtin_amdgcn_raw_buffer_load_b32(rs_, 0, (TW - 1) * 8, 0)));      \
-    } while (0)
-// words of the stored row of predecessor p_ (slot sl_) and the column to their left
+// words of the stored row of predecessor p_ (slot sl_) and the column to their left (stored with the row: every word of
+// a stored row was written by the lane that reads it).  sl_ <= -2: the row is one of the LDS_ROWS on-chip copies.
 #define P16_FETCH(p_, sl_, wr_, hl_)                                                                        \
     do {                                                                                                    \
-        const __amdgpu_buffer_rsrc_t rs_ = p16_rsrc(((p_) == 0) ? (const void*)g_row0 : (const void*)(g_pool + (size_t)(sl_) * TW), TW * 8); \
-        _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = __builtin_amdgcn_raw_buffer_load_b64(rs_, ut8, k * T * 8, 0); \
-        P16_PROF_FETCH();                                                                                   \
-        P16_LOAD_LEFT(rs_, hl_);                                                                            \
+        if ((sl_) <= -2) {                                                                                  \
+            P16_LDS_ROW(la_, lf_, -2 - (sl_));                                                              \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = la_[k * 64];                             \
+            hl_ = (int)*lf_;                                                                                \
+        } else {                                                                                            \
+            const __amdgpu_buffer_rsrc_t rs_ = p16_rsrc(((p_) == 0) ? (const void*)g_row0 : (const void*)((SXG_GLOBAL const char*)g_pool + (size_t)(sl_) * (size_t)RB), RB); \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = __builtin_amdgcn_raw_buffer_load_b64(rs_, ut8, k * T * 8, 0); \
+            P16_PROF_FETCH();                                                                               \
+            hl_ = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_, ut8 >> 1, TW * 8, 0);                       \
+            P16_DRAIN();                                                                                    \
+        }                                                                                                   \
     } while (0)
 
-// Every branch that loaded a stored row ends by draining its loads itself.  Otherwise the compiler, which cannot know
-// at the join which branch ran, waits for vmcnt(0) at the top of pass 1 of EVERY row (a loaded register that a branch
+// Every branch that loaded a stored row from HBM ends by draining its loads itself.  Otherwise the compiler, which cannot
+// know at the join which branch ran, waits for vmcnt(0) at the top of pass 1 of EVERY row (a loaded register that a branch
 // did not consume is reused there) -- and on gfx9 vmcnt also counts stores, so rows that read nothing waited for the
 // write acknowledgements of the previous row's ring and band stores.
 #define P16_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0), expcnt / lgkmcnt untouched */
@@ -291,63 +336,52 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             Hleft = hl;
 #pragma unroll
             for (int k = 0; k < W; ++k) Hp[k] = (int)wr[k].x;
-            P16_DRAIN();
         } else {
-            // Several predecessors: D, F and O are plain maxima over them (which predecessor won is
-            // re-derived by the traceback), so the fold order is free: the register row first.
-            const bool reg0 = (p0 == i - 1), reg1 = (np == 2 && p1 == i - 1);
-            const bool park = np >= 3;
-            const int Hleft_reg = Hleft;   // the register row's left column (a parked row is folded later)
-            P16_LROW(lrow_t);   // my slice of the parked row
-            if (park) {
-#pragma unroll
-                for (int k = 0; k < W; ++k) lrow_t[k] = p16_pack_row<CVX>(Hp[k], Fp[k], Op[k]);
-            }
-            if (!reg0 && !(reg1 && !park)) {
+            // Several predecessors: D, F and O are plain maxima over them (which predecessor won is re-derived by the
+            // traceback), so the fold order is free: when the previous row is one of them (ROW_REGPRED) the registers are
+            // the running maxima as they stand, otherwise the first predecessor's stored row is unpacked into them; every
+            // other predecessor is folded in.
+            const bool regbase = (flags & ROW_REGPRED) != 0;
+            if (!regbase) {
                 u32x2 wr[W];
                 int hl;
                 P16_FETCH(p0, s0, wr, hl);
                 Hleft = hl;
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    p16_unpack_row(wr[k], Hp[k], Fp[k], Op[k]);
+                    p16_unpack_row<SW>(wr[k], Hp[k], Fp[k], Op[k]);
                     SXG_PIN("+v"(Hp[k]), "+v"(Fp[k]), "+v"(Op[k]));
                 }
-                P16_DRAIN();
             }
 // fold one more predecessor row (p_, slot sl_) into the running maxima
 #define P16_FOLD(p_, sl_)                                                                                   \
     do {                                                                                                    \
         u32x2 wr[W];                                                                                        \
-        int hl = Hleft_reg;                                                                                 \
-        if ((p_) == i - 1) {                                                                                \
-            _Pragma("unroll") for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];                                \
-        } else P16_FETCH(p_, sl_, wr, hl);                                                                  \
+        int hl;                                                                                             \
+        P16_FETCH(p_, sl_, wr, hl);                                                                         \
         Hleft = pk_max(Hleft, hl);                                                                          \
         _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                     \
             int hs, fs, os;                                                                                 \
-            p16_unpack_row(wr[k], hs, fs, os);                                                              \
+            p16_unpack_row<SW>(wr[k], hs, fs, os);                                                          \
             Fp[k] = pk_max(Fp[k], fs);                                                                      \
             if (CVX) Op[k] = pk_max(Op[k], os);                                                             \
             Hp[k] = pk_max(Hp[k], hs);                                                                      \
             SXG_PIN("+v"(Hp[k]), "+v"(Fp[k]), "+v"(Op[k]));                                                 \
         }                                                                                                   \
-        if ((p_) != i - 1) P16_DRAIN();                                                                     \
     } while (0)
-            // (the second predecessor in straight-line code: two-predecessor rows -- the closing node of every
+            // (the first two predecessors in straight-line code: two-predecessor rows -- the closing node of every
             // bubble -- are a third of all rows; the loop form made the allocator spill around them)
-            if (np >= 2) {
-                const int p = reg1 ? p0 : p1, sl = reg1 ? s0 : s1;
-                P16_FOLD(p, sl);
-            }
+            if (regbase && p0 != i - 1) P16_FOLD(p0, s0);
+            if (np >= 2 && p1 != i - 1) P16_FOLD(p1, s1);
             for (int x = 2; x < np; ++x) {
                 const int p = __builtin_amdgcn_readfirstlane(g_preds[pb + x]);
-                const int sl = (p >= 1 && p != i - 1) ? __builtin_amdgcn_readfirstlane(g_slot[p - 1]) : -1;
+                if (p == i - 1) continue;
+                const int sl = p >= 1 ? __builtin_amdgcn_readfirstlane(g_slot[p - 1]) : -1;
                 P16_FOLD(p, sl);
             }
 #undef P16_FOLD
-#undef P16_DRAIN
         }
+#undef P16_DRAIN
 #undef P16_FETCH
         if (!CVX) {
 #pragma unroll
@@ -378,47 +412,48 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             // a = max_k' (h_k' - (k'-k) e) over the columns k' >= k done so far: "the gap is e longer, or restarts here";
             // shifted by (W-1) e below it is max_k (h_k + (W-1-k) e), the carry the strip hands on.  The opening cost
             // and the local-alignment clamp (whose best term is k = W-1) are applied once per row
-            a = pk_max(pk_sub(a, E2), h);
-            if (CVX) b = pk_max(pk_sub(b, C2), h);
+            a = pk_max(P16_INC(a, Em, E2), h);
+            if (CVX) b = pk_max(P16_INC(b, Cm, C2), h);
             SXG_PIN("+v"(Hc[k]), "+v"(a), "+v"(b));
         }
-        a = pk_add(a, pk2((W - 1) * e, (W - 1) * e));
-        if (CVX) b = pk_add(b, pk2((W - 1) * c, (W - 1) * c));
-        if (SW) { a = pk_max(a, 0); if (CVX) b = pk_max(b, 0); }
-        a = pk_add(a, G2);
-        if (CVX) b = pk_add(b, Q2);
-        // ---- carries (32-bit).  Strip order: lo strips of lanes 0..T-1, then hi strips.
-        // y = a - s*W*e with strip index s (lo: t, hi: T + t); E entering strip s = max_{s'<s} y_{s'} + (s-1)*W*e
-        // (the lane's offsets are rebuilt from an opaque copy of t every row: hoisted out of the loop
+        a = P16_DEC(a, (unsigned)(W - 1) * Em, pk2((W - 1) * e, (W - 1) * e));
+        if (CVX) b = P16_DEC(b, (unsigned)(W - 1) * Cm, pk2((W - 1) * c, (W - 1) * c));
+        if (SW) { a = pk_max(a, B2); if (CVX) b = pk_max(b, B2); }
+        a = P16_DEC(a, Gm, G2);
+        if (CVX) b = P16_DEC(b, Qm, Q2);
+        // ---- carries (32-bit), inside the wave.  Wave-local strip index u: lo strips 0..63, then hi strips 64..127; what
+        // came in through the mailbox is strip u = -1.  y_u = a_u - u*W*e;  E entering strip u = max_{u'<u} y_u' + (u-1)*W*e
+        // (the lane's offsets are rebuilt from an opaque copy of the lane every row: hoisted out of the loop
         // they are six more loop-invariant VGPRs, which the allocator spills and reloads per row --
         // and a scratch reload is an in-order vmcnt wait behind every store still in flight)
-        int tt = t;
+        int tt = lane;
         asm volatile("" : "+v"(tt));
         const int tWe = __mul24(tt, We), tWc = __mul24(tt, Wc);
-        int ya_lo = pk_lo(a) - tWe, ya_hi = pk_hi(a) - tWe - T * We;
-        int yb_lo = CVX ? pk_lo(b) - tWc : NEG, yb_hi = CVX ? pk_hi(b) - tWc - T * Wc : NEG;
+        int ya_lo = pk_lo(a) - tWe, ya_hi = pk_hi(a) - tWe - 64 * We;
+        int yb_lo = CVX ? pk_lo(b) - tWc : NEG, yb_hi = CVX ? pk_hi(b) - tWc - 64 * Wc : NEG;
         ya_lo = sxg_wave_incl_max(ya_lo); ya_hi = sxg_wave_incl_max(ya_hi);
         if (CVX) { yb_lo = sxg_wave_incl_max(yb_lo); yb_hi = sxg_wave_incl_max(yb_hi); }
-        if (lane == 63) { tot[wv] = ya_lo; tot[16 + wv] = ya_hi; tot[32 + wv] = yb_lo; tot[48 + wv] = yb_hi; }
         RP_MARK(1);  // pass 1 + in-wave scan
-        SXG_ROW_BARRIER();  // B1
-        RP_MARK(2);  // waiting at B1
-        {
-            int b0 = NEG * 2, b1 = NEG * 2, b2 = NEG * 2, b3 = NEG * 2, lo_a = NEG * 2, lo_b = NEG * 2;
-            for (int x = 0; x < NW; ++x) {
-                const int v0 = tot[x], v1 = tot[16 + x], v2 = tot[32 + x], v3 = tot[48 + x];
-                lo_a = max(lo_a, v0); lo_b = max(lo_b, v2);
-                if (x < wv) { b0 = max(b0, v0); b1 = max(b1, v1); b2 = max(b2, v2); b3 = max(b3, v3); }
-            }
-            b1 = max(b1, lo_a); b3 = max(b3, lo_b);  // every lo strip precedes every hi strip
-            ya_lo = max(ya_lo, b0); ya_hi = max(ya_hi, b1); yb_lo = max(yb_lo, b2); yb_hi = max(yb_hi, b3);
-            ya_lo = sxg_wave_shr1(ya_lo, b0); ya_hi = sxg_wave_shr1(ya_hi, b1);
-            yb_lo = sxg_wave_shr1(yb_lo, b2); yb_hi = sxg_wave_shr1(yb_hi, b3);
+        // what crosses my left edge in this row: {E, Q entering my first column, H of the column left of it, row}
+        int in_e = NEG * 2, in_q = NEG * 2, in_h = FLOORV;
+        if (wv > 0) {
+            i32x4 m = mb_in[i & (P16_MBOX - 1)];
+            while (__builtin_amdgcn_readfirstlane(m.w) != i) { __builtin_amdgcn_s_sleep(2); m = mb_in[i & (P16_MBOX - 1)]; }
+            in_e = __builtin_amdgcn_readfirstlane(m.x) + We;   // (as y of strip u = -1)
+            in_q = __builtin_amdgcn_readfirstlane(m.y) + Wc;
+            in_h = __builtin_amdgcn_readfirstlane(m.z);
+            if (lane == 0) prog[wv] = i;
         }
-        const int Ein_lo = (tt == 0) ? NEGP : max(ya_lo + tWe - We, NEGP);
-        const int Ein_hi = max(ya_hi + tWe + (T - 1) * We, NEGP);
-        const int Qin_lo = (tt == 0 || !CVX) ? NEGP : max(yb_lo + tWc - Wc, NEGP);
-        const int Qin_hi = !CVX ? NEGP : max(yb_hi + tWc + (T - 1) * Wc, NEGP);
+        RP_MARK(2);  // waiting for the left neighbour
+        {
+            const int ta = max(__builtin_amdgcn_readlane(ya_lo, 63), in_e), tb = max(__builtin_amdgcn_readlane(yb_lo, 63), in_q);
+            ya_lo = max(sxg_wave_shr1(ya_lo, NEG * 2), in_e); ya_hi = max(sxg_wave_shr1(ya_hi, NEG * 2), ta);
+            yb_lo = max(sxg_wave_shr1(yb_lo, NEG * 2), in_q); yb_hi = max(sxg_wave_shr1(yb_hi, NEG * 2), tb);
+        }
+        const int Ein_lo = max(ya_lo + tWe - We, FLOORV);
+        const int Ein_hi = max(ya_hi + tWe + 63 * We, FLOORV);
+        const int Qin_lo = !CVX ? FLOORV : max(yb_lo + tWc - Wc, FLOORV);
+        const int Qin_hi = !CVX ? FLOORV : max(yb_hi + tWc + 63 * Wc, FLOORV);
         int E = pk2(Ein_lo, Ein_hi), Q = pk2(Qin_lo, Qin_hi);
 
         // ---- pass 2: final H
@@ -427,24 +462,29 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         for (int k = 0; k < W; ++k) {
             int h = pk_max(Hc[k], E);
             if (CVX) h = pk_max(h, Q);
-            if (SW) h = pk_max(h, 0);
+            if (SW) h = pk_max(h, B2);
             Hc[k] = h;
             rowmax = pk_max(rowmax, h);
-            E = pk_max(pk_add(h, G2), pk_add(E, E2));
-            if (CVX) Q = pk_max(pk_add(h, Q2), pk_add(Q, C2));
+            E = pk_max(P16_DEC(h, Gm, G2), P16_DEC(E, Em, E2));
+            if (CVX) Q = pk_max(P16_DEC(h, Qm, Q2), P16_DEC(Q, Cm, C2));
             SXG_PIN("+v"(Hc[k]), "+v"(E), "+v"(Q), "+v"(rowmax));
         }
-        // hand my last column to the right neighbour; the lo half's last lane feeds lane 0's hi strip
+        // hand my last column to the right neighbour: inside the wave by a lane shift (lane 0's hi strip begins where lane
+        // 63's lo strip ends; the column left of its lo strip came in through the mailbox); lane 63's hi strip is the wave's
+        // right edge -- E, Q after its last column and its H go into the next wave's mailbox of this row
         const int xh = Hc[W - 1];
         int lh = sxg_wave_shr1(xh, 0);
-        if (lane == 63) xch[wv] = xh;
-        RP_MARK(3);  // carry combine + pass 2
-        SXG_ROW_BARRIER();  // B2
-        RP_MARK(4);  // waiting at B2
-        if (lane == 0) {
-            if (wv > 0) lh = xch[wv - 1];
-            else lh = pk2(NEGP, pk_lo(xch[NW - 1]));  // lane T-1's lo strip ends where my hi strip begins
+        {
+            const int x63 = __builtin_amdgcn_readlane(xh, 63);
+            if (lane == 0) lh = pk2(in_h, pk_lo(x63));
         }
+        RP_MARK(3);  // carry combine + pass 2
+        if (wv + 1 < NW) {
+            if ((i & (P16_MBOX / 2 - 1)) == 0)   // the slots of the next P16_MBOX / 2 rows: has my reader freed them?
+                while (__builtin_amdgcn_readfirstlane(prog[wv + 1]) < i - P16_MBOX / 2) __builtin_amdgcn_s_sleep(2);
+            if (lane == 63) mb_out[i & (P16_MBOX - 1)] = i32x4{pk_hi(E), pk_hi(Q), pk_hi(xh), i};
+        }
+        RP_MARK(4);  // waiting for the right neighbour's progress
 
         // ---- end cell bookkeeping
         if (SW) {
@@ -470,33 +510,39 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         // ---- outgoing candidates (see p16_pack_row), ring store, band store.  A sibling successor --
         // single predecessor, the same as mine, not me -- wants my own F/O left in place instead.
         next_sib = false;
-        if (np <= 1 && i < N && (i & (CH - 1)) != 0) {
-            const i32x4 n0 = lmeta[2 * (i & (CH - 1))];
-            const int nnp = __builtin_amdgcn_readfirstlane(n0.y) & 0xffff, np0 = __builtin_amdgcn_readfirstlane(n0.z);
+        if (np <= 1 && i < N) {
+            const int nnp = dnext[1] & 0xffff, np0 = dnext[2];
             next_sib = nnp <= 1 && np0 == p0 && np0 != i;
         }
-        // band of this row: strips [bs0, bs0 + BS); my wave covers lo strips [64 wv, 64 wv + 64) and the
-        // hi strips T further on.  (wave-uniform tests; the lane test is ONE exec mask around all W stores)
+        // band of this row: strips [bs0, bs0 + BS); my wave covers lo strips [128 wv, 128 wv + 64) and the
+        // hi strips 64 further on.  (wave-uniform tests; the lane test is ONE exec mask around all W stores)
         const int bs0 = band_first_strip(hint, W, BS, T);
-        const int w0 = wv << 6;
+        const int w0 = wv << 7;
         const bool band_lo = (w0 + 63 >= bs0) && (w0 < bs0 + BS);
-        const bool band_hi = (T + w0 + 63 >= bs0) && (T + w0 < bs0 + BS);
+        const bool band_hi = (w0 + 127 >= bs0) && (w0 + 64 < bs0 + BS);
         const bool ring = (flags & ROW_STORE) != 0;
-        const __amdgpu_buffer_rsrc_t rs_ring = p16_rsrc((const void*)(g_pool + (size_t)(ring ? myslot : 0) * TW), TW * 8);
+        const __amdgpu_buffer_rsrc_t rs_ring = p16_rsrc((const void*)((SXG_GLOBAL const char*)g_pool + (size_t)(ring && myslot >= 0 ? myslot : 0) * (size_t)RB), RB);
         const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
-        const bool in_lo = (unsigned)(tt - bs0) < (unsigned)BS, in_hi = (unsigned)(T + tt - bs0) < (unsigned)BS;
+        const bool in_lo = (unsigned)(w0 + tt - bs0) < (unsigned)BS, in_hi = (unsigned)(w0 + 64 + tt - bs0) < (unsigned)BS;
         const unsigned so_lo = (soff & 0xffffu) << 2, so_hi = (soff >> 16) << 2;   // strip s lives in slot s mod BS of its row (byte offsets)
 // ring row + band cells of this row; CF(k) / CO(k) = the row's outgoing candidates of column k
 #define P16_STORES(CF, CO)                                                                                  \
     do {                                                                                                    \
         if (ring) {                                                                                         \
-            _Pragma("unroll") for (int k = 0; k < W; ++k)                                                   \
-                __builtin_amdgcn_raw_buffer_store_b64(p16_pack_row<CVX>(Hc[k], CF, CO), rs_ring, ut8, k * T * 8, 0); \
+            if (myslot <= -2) {                                                                             \
+                P16_LDS_ROW(la_, lf_, -2 - myslot);                                                         \
+                _Pragma("unroll") for (int k = 0; k < W; ++k) la_[k * 64] = p16_pack_row<CVX, SW>(Hc[k], CF, CO); \
+                *lf_ = (unsigned)lh;                                                                        \
+            } else {                                                                                        \
+                _Pragma("unroll") for (int k = 0; k < W; ++k)                                               \
+                    __builtin_amdgcn_raw_buffer_store_b64(p16_pack_row<CVX, SW>(Hc[k], CF, CO), rs_ring, ut8, k * T * 8, 0); \
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)lh, rs_ring, ut8 >> 1, TW * 8, 0);          \
+            }                                                                                               \
         }                                                                                                   \
         if (band_lo) {                                                                                      \
             if (in_lo) {                                                                                    \
                 _Pragma("unroll") for (int k = 0; k < W; ++k) {                                             \
-                    const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                       \
+                    const u32x2 w = p16_pack_row<CVX, SW>(Hc[k], CF, CO);                                   \
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), rs_plane, so_lo, k * BS * 4, 0); \
                 }                                                                                           \
             }                                                                                               \
@@ -504,7 +550,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         if (band_hi) {                                                                                      \
             if (in_hi) {                                                                                    \
                 _Pragma("unroll") for (int k = 0; k < W; ++k) {                                             \
-                    const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                       \
+                    const u32x2 w = p16_pack_row<CVX, SW>(Hc[k], CF, CO);                                   \
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), rs_plane, so_hi, k * BS * 4, 0); \
                 }                                                                                           \
             }                                                                                               \
@@ -513,18 +559,17 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         if (!next_sib) {
 #pragma unroll
             for (int k = 0; k < W; ++k) {
-                Fp[k] = pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2));
-                if (CVX) Op[k] = pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2));
+                Fp[k] = pk_max(P16_DEC(Hc[k], Gm, G2), P16_DEC(Fp[k], Em, E2));
+                if (CVX) Op[k] = pk_max(P16_DEC(Hc[k], Qm, Q2), P16_DEC(Op[k], Cm, C2));
                 SXG_PIN("+v"(Fp[k]), "+v"(Op[k]));
             }
             P16_STORES(Fp[k], Op[k]);
         } else if (ring || band_lo || band_hi) {
             // (a sibling follows: Fp/Op stay this row's own F/O, the outgoing candidates are temporaries)
-            P16_STORES(pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2)), (CVX ? pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2)) : NEG2));
+            P16_STORES(pk_max(P16_DEC(Hc[k], Gm, G2), P16_DEC(Fp[k], Em, E2)), (CVX ? pk_max(P16_DEC(Hc[k], Qm, Q2), P16_DEC(Op[k], Cm, C2)) : NEG2));
         }
 #undef P16_STORES
-#undef P16_LOAD_LEFT
-#undef P16_LROW
+#undef P16_LDS_ROW
 #pragma unroll
         for (int k = 0; k < W; ++k) Hp[k] = Hc[k];
         Hleft = lh;
@@ -535,6 +580,8 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         for (int k = 0; k < 8; ++k) B.row_prof[k] += racc[k];
 #endif
 #undef RP_MARK
+#undef P16_DEC
+#undef P16_INC
 
     // ---- end cell: greatest score, then smallest row, then smallest column (two candidates per lane)
     unsigned long long key = 0;
@@ -544,7 +591,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     if (bi_hi >= 0) {
         const unsigned long long k2 = ((unsigned long long)(unsigned)(best_hi + (1 << 27)) << 35) |
                                       ((unsigned long long)(0xFFFFFu - (unsigned)bi_hi) << 15) |
-                                      (unsigned long long)(0x7FFFu - (unsigned)(TW + j0 + bk_hi));
+                                      (unsigned long long)(0x7FFFu - (unsigned)(j0h + bk_hi));
         key = k2 > key ? k2 : key;
     }
 #pragma unroll
@@ -561,7 +608,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     __syncthreads();
     if (key == 0) { res.best = 0; res.bi = -1; res.bj = -1; }
     else {
-        res.best = (int)(unsigned)(key >> 35) - (1 << 27);
+        res.best = (int)(unsigned)(key >> 35) - (1 << 27) - BIAS;
         res.bi = (int)(0xFFFFFu - (unsigned)((key >> 15) & 0xFFFFFu));
         res.bj = (int)(0x7FFFu - (unsigned)(key & 0x7FFFu));
     }
@@ -608,6 +655,8 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     const int g = __builtin_amdgcn_readfirstlane(S_.g), e = __builtin_amdgcn_readfirstlane(S_.e);
     const int q = __builtin_amdgcn_readfirstlane(S_.q), c = __builtin_amdgcn_readfirstlane(S_.c);
     const int sw = __builtin_amdgcn_readfirstlane(S_.sw);
+    // the full-matrix sweep of a local alignment stores biased H (P16_BIAS): "zero" is the bias
+    const int bias = (!BANDED && sw) ? P16_BIAS : 0;
     const int BS = __builtin_amdgcn_readfirstlane(B.band_strips);
     const int bw = __builtin_amdgcn_readfirstlane(B.band_w), last_strip = L / W;
     // is strip s of a row with band hint `hint` kept in the plane?
@@ -646,7 +695,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
 #define TBU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
     // H of the virtual row 0
     auto h_row0 = [&](int col) -> int {
-        if (sw || col <= 0) return 0;
+        if (sw || col <= 0) return bias;
         const int a = g + (col - 1) * e, b = q + (col - 1) * c;
         return max(a > b ? a : b, NEGP);
     };
@@ -677,7 +726,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     auto sext = [](uint32_t w) -> int { return (int)(short)(w & 0xffffu); };
     int n = 0;
     int st = SRC_STOP;           // SRC_STOP = "in H", SRC_F / SRC_O = walking up a gap in the sequence
-    int hv = best, gv = 0;       // H of the current cell / value of the gap state being walked
+    int hv = best + bias, gv = 0;       // H of the current cell / value of the gap state being walked
 #ifdef SXG_ROW_PROF
     unsigned long long tb_steps = 0, tb_loads = 0, tb_t0 = __builtin_readcyclecounter(), tb_ld = 0;
 #endif
@@ -691,7 +740,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             ++n; --j;
             continue;
         }
-        if (sw && st == SRC_STOP && hv == 0) break;
+        if (sw && st == SRC_STOP && hv == bias) break;
         {   // (re)fill the window when row i or column j leave it
             const int l = wtop - i;
             const int x = j - wcol0(l);
@@ -760,7 +809,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                                         (unsigned)lo >= (unsigned)TBW_LET) continue;
                                     if (!((nva >> (24 + xa)) & 1u) || !((nvb >> (24 + xb)) & 1u)) continue;
                                     const int hcell = sext(me[x2]);
-                                    if (sw && hcell == 0) continue;
+                                    if (sw && hcell == bias) continue;
                                     const int ha = sext(win[la * TBW_STRIDE + xa]), hb = np2 == 2 ? sext(win[lb * TBW_STRIDE + xb]) : ha;
                                     const bool second = np2 == 2 && hb > ha;    // (first predecessor in list order on ties)
                                     const int best2 = second ? hb : ha;

@@ -276,6 +276,7 @@ struct RowCaps {
     int rows_cap;   // rows of the traceback plane
     int pool_slots; // row-pool slots
     int step_cap;   // fold steps of the step-mask plane (sum over multi-pred rows of np-1)
+    int lds_rows;   // packed sweep: stored rows the workgroup can keep in LDS at a time (0: every stored row goes to the ring)
 };
 
 // Second half of row preparation, shared by the block kernel (graph -> rows) and the
@@ -312,7 +313,12 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
             if (!(fl[u] & ROW_STORE)) { R.slot[r] = -1; continue; }
             const int cnt = sl[u] - sr[u];  // stored rows in [r, lu): must fit the ring
             if (cnt > worst) worst = cnt;
-            R.slot[r] = sr[u] % caps.pool_slots;
+            // A row whose last reader comes before lds_rows more rows are stored never leaves the chip: stored rows take the
+            // on-chip copies in turn (copy = stored-row number mod lds_rows), so the copy this row is written to at the end of
+            // its sweep is next written by the stored row lds_rows later -- which is >= lu, and a row reads its predecessors
+            // before it writes itself.  Slot -2 - copy; every word of a copy is written and read by the same lane.
+            if (hinted == 1 && caps.lds_rows > 0 && cnt <= caps.lds_rows) R.slot[r] = -2 - sr[u] % caps.lds_rows;
+            else R.slot[r] = sr[u] % caps.pool_slots;
         }
     }
     worst = c.reduce_max(worst);
@@ -427,9 +433,9 @@ SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const 
         for (int u = 0; u < GB; ++u) {
             const int r = r0 + u * T;
             if (r >= N) continue;
-            int oo = o[u];
-            if (ei[u] >= 0) R.preds[oo++] = ri[u] + 1;
-            for (int e = ni[u]; e >= 0; e = G.e_next_in[e]) R.preds[oo++] = G.rank[G.e_tail[e]] + 1;
+            int oo = o[u], regpred = 0;
+            if (ei[u] >= 0) { R.preds[oo++] = ri[u] + 1; regpred |= (int)(ri[u] + 1 == r); }
+            for (int e = ni[u]; e >= 0; e = G.e_next_in[e]) { const int pr = G.rank[G.e_tail[e]] + 1; R.preds[oo++] = pr; regpred |= (int)(pr == r); }
             int store = 0, lu = r;
             if (eo[u] >= 0) { if (ro[u] != r + 1) store = 1; if (ro[u] > lu) lu = ro[u]; }
             for (int e = no[u]; e >= 0; e = G.e_next_out[e]) {
@@ -437,7 +443,7 @@ SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const 
                 if (hr != r + 1) store = 1;
                 if (hr > lu) lu = hr;
             }
-            R.flags[r] = (uint8_t)((store ? ROW_STORE : 0) | (od[u] == 0 ? ROW_SINK : 0));
+            R.flags[r] = (uint8_t)((store ? ROW_STORE : 0) | (od[u] == 0 ? ROW_SINK : 0) | (regpred ? ROW_REGPRED : 0));
             R.slot[r] = lu;
         }
     }

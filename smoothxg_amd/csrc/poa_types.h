@@ -26,6 +26,7 @@ constexpr int TB_FEXT = 0x08, TB_OEXT = 0x10, TB_EEXT = 0x20, TB_QEXT = 0x40;
 // per-row flags prepared for the DP
 constexpr int ROW_STORE = 1;  // some successor is not rank+1 -> row goes to the row pool
 constexpr int ROW_SINK = 2;   // no out-edge (NW end candidates)
+constexpr int ROW_REGPRED = 4;  // the previous rank is one of the row's predecessors (its values are still in registers)
 
 // status codes (per block); mirrored in include/sxg_poa.h
 enum : int {

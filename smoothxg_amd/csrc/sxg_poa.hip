@@ -37,6 +37,7 @@ struct SlotLayout {  // byte offsets inside one slot arena (all 16-byte aligned)
         row0, park, cons_sc, cons_pr, pair_row, pair_pos, total;
     int nodes_cap, rows_cap, pool_slots, step_cap, scratch_len, Lpad, word_bytes, threads;
     int band_strips;  // packed sweep: strips per row in the traceback plane (0 = not the packed sweep)
+    int lds_rows;     // packed sweep: stored rows the workgroup's LDS holds on chip (set by prepare_plan)
 };
 
 static size_t lay(size_t& cur, size_t bytes) {
@@ -74,8 +75,9 @@ static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int s
     // traceback plane: one byte per cell, or (packed sweep) one dword per cell of the row's band of strips
     L.tb = lay(cur, ((size_t)rows_cap + 1) * (packed ? (size_t)band_strips * (size_t)(Lpad / (2 * threads)) * 4 : (size_t)Lpad));
     L.steps = lay(cur, packed ? 256 : (size_t)std::max(step_cap, 1) * 3 * threads * 4);
-    L.pool = lay(cur, (size_t)pool_slots * Lpad * word_bytes);
-    L.row0 = lay(cur, (size_t)Lpad * word_bytes);
+    // (a stored row of the packed sweep ends with one more word per lane: the column left of the lane's strips)
+    L.pool = lay(cur, (size_t)pool_slots * ((size_t)Lpad * word_bytes + (size_t)threads * 4));
+    L.row0 = lay(cur, (size_t)Lpad * word_bytes + (size_t)threads * 4);
     L.park = lay(cur, (size_t)Lpad * word_bytes);
     L.cons_sc = lay(cur, 8 * C); L.cons_pr = lay(cur, 4 * C);
     if (pairs) { L.pair_row = lay(cur, 4 * (Rr + Lpad)); L.pair_pos = lay(cur, 4 * (Rr + Lpad)); }
@@ -111,7 +113,7 @@ __device__ static SlotViews slot_views(uint8_t* base, const SlotLayout& L) {
     V.R.row_node = P32(r_row_node); V.R.meta = P32(r_meta);
     V.B.tb = base + L.tb; V.B.steps = (uint32_t*)(base + L.steps);
     V.B.pool = base + L.pool; V.B.row0 = base + L.row0; V.B.park = base + L.park;
-    V.B.band_strips = L.band_strips;
+    V.B.band_strips = L.band_strips; V.B.lds_rows = L.lds_rows;
     V.cons_sc = (int64_t*)(base + L.cons_sc); V.cons_pr = (int32_t*)(base + L.cons_pr);
     V.pair_row = (int32_t*)(base + L.pair_row); V.pair_pos = (int32_t*)(base + L.pair_pos);
 #undef P32
@@ -173,12 +175,12 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lds = (int*)smem;
     int& s_work = lds[200];
-    WgCtx ctx{lds + 128};
+    WgCtx ctx{(sxg_lds_int*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() + 128u * 4u)};
     const int t = threadIdx.x;
     SlotViews V = slot_views(A.arena + (size_t)blockIdx.x * A.lay.total, A.lay);
     V.B.prio_rank = (int)(blockIdx.x / (unsigned)A.num_cu) & (PRIO_BOARD_SLOTS - 1);
     V.B.prio_board = A.prio_board ? A.prio_board + (size_t)(__smid() & (PRIO_BOARD_CUS - 1)) * PRIO_BOARD_SLOTS : nullptr;
-    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap};
+    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap, A.lay.lds_rows};
     // the first item of a slot is fixed (work[blockIdx]: the host orders the list by where the slot will
     // run, see launch_plan), the rest comes from the queue
     bool first = true;
@@ -333,12 +335,12 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lds = (int*)smem;
     int& s_work = lds[200];
-    WgCtx ctx{lds + 128};
+    WgCtx ctx{(sxg_lds_int*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() + 128u * 4u)};
     const int t = threadIdx.x;
     SlotViews V = slot_views(A.arena + (size_t)blockIdx.x * A.lay.total, A.lay);
     V.B.prio_rank = (int)(blockIdx.x / (unsigned)A.num_cu) & (PRIO_BOARD_SLOTS - 1);
     V.B.prio_board = nullptr; V.B.prio_rem0 = 0; V.B.row_prof = nullptr;
-    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap};
+    const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap, A.lay.lds_rows};
     for (;;) {
         __syncthreads();
         if (t == 0) s_work = atomicAdd(A.queue, 1);
@@ -362,7 +364,10 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
                 V.R.row_node[r] = r;
                 V.R.slot[r] = r;
                 V.R.tbx[r] = 0;  // (packed sweep: the align-only arenas keep every strip, hints are not used)
-                V.R.flags[r] = A.row_sink[r0 + r] ? ROW_SINK : 0;
+                int fl = A.row_sink[r0 + r] ? ROW_SINK : 0;
+                for (int64_t k = A.pred_off[r0 + r]; k < A.pred_off[r0 + r + 1]; ++k)   // the previous rank is a predecessor:
+                    if (A.preds[k] == r) fl |= ROW_REGPRED;                               // its values are still in registers
+                V.R.flags[r] = (uint8_t)fl;
             }
             if (t == 0) V.R.pred_off[N] = (int)(A.pred_off[r0 + N] - e0);
             __syncthreads();
@@ -471,6 +476,16 @@ static bool variant_for_len(int maxlen, int rm, Variant* v, bool sw = false) {
 }
 
 template <class Args> using KernelFn = void (*)(const Args);
+
+// On-chip copies of stored rows a packed-sweep workgroup gets (SlotLayout::lds_rows): what is left of its share of the CU's
+// 160 KB of LDS when as many workgroups share the CU as its registers allow (128 VGPRs: 16 waves per CU).
+static int p16_lds_rows(const int T, const int W) {
+    if (const char* e = getenv("SXG_POA_LDS_ROWS")) return std::max(0, std::min(8, atoi(e)));
+    const int wg_per_cu = std::max(1, 16 / std::max(T / 64, 1));
+    const int share = (160 * 1024) / wg_per_cu - 512;   // (allocation granularity)
+    const int rows = (share - dp16_lds_bytes(T, W, 0)) / dp16_row_bytes(T, W);
+    return std::max(0, std::min(8, rows));
+}
 
 template <int TMAX, int W, int RM> static KernelFn<BlockArgs> pick_block(bool cvx, bool sw) {
     if (cvx) return sw ? poa_block_kernel<TMAX, W, true, RM, true> : poa_block_kernel<TMAX, W, true, RM, false>;
@@ -862,7 +877,7 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
-    if (V.RM == 2) { P.smem = dp16_lds_bytes(V.T(), V.W); P.park_lds = true; }  // packed sweep parks in LDS only
+    if (V.RM == 2) { P.lay.lds_rows = p16_lds_rows(V.T(), V.W); P.smem = dp16_lds_bytes(V.T(), V.W, P.lay.lds_rows); P.park_lds = true; }
     if (V.RM == 3) { P.smem = band_lds_bytes(V.W); P.park_lds = true; }
     P.pf_off = (V.RM < 2 && getenv("SXG_POA_PREFETCH")) ? dp_pf_offset(Lpad, wb, V.T()) : -1;
     if (P.pf_off >= 0) P.smem += dp_pf_bytes(Lpad, wb, V.T());
@@ -985,7 +1000,7 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
         }
         double rt = 1e-9;
         for (int k = 0; k < 8; ++k) rt += (double)ra[k];
-        static const char* seg[8] = {"setup", "pass1+scan", "wait B1", "combine+pass2", "wait B2", "hand-over+end cell", "stored row fetch", "outgoing+row store"};
+        static const char* seg[8] = {"setup", "pass1+scan", "wait left wave", "combine+pass2", "wait right wave", "hand-over+end cell", "stored row fetch", "outgoing+row store"};
         fprintf(stderr, "[sxg]   row profile:");
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", seg[k], 100.0 * (double)ra[k] / rt);
         fprintf(stderr, "\n");
@@ -1881,11 +1896,12 @@ extern "C" int sxg_poa_align_batch(sxg_poa_handle* h, const sxg_poa_align_in* in
         for (int p : pl.work) maxe = std::max<int64_t>(maxe, in->pred_off[in->row_off[p + 1]] - in->pred_off[in->row_off[p]]);
         // r_preds is sized by nodes_cap in make_layout: give it the edge count
         const int wb = V.RM == 1 ? 8 : 4;
-        const SlotLayout lay2 = make_layout((int)std::max<int64_t>(maxe + 8, rows_cap + 8), rows_cap, rows_cap + 1,
-                                            (int)maxe + 8, V.T(), V.Lpad(), wb, true, V.RM == 2 ? 2 * V.T() : 0);  // every strip kept
+        SlotLayout lay2 = make_layout((int)std::max<int64_t>(maxe + 8, rows_cap + 8), rows_cap, rows_cap + 1,
+                                      (int)maxe + 8, V.T(), V.Lpad(), wb, true, V.RM == 2 ? 2 * V.T() : 0);  // every strip kept
+        if (V.RM == 2) lay2.lds_rows = p16_lds_rows(V.T(), V.W);
         auto kern = align_kernel(pl.variant, pl.cvx, pl.sw);
         int per_cu = 1;
-        int smem = V.RM == 2 ? dp16_lds_bytes(V.T(), V.W) : dp_lds_launch_bytes(V.Lpad(), wb);
+        int smem = V.RM == 2 ? dp16_lds_bytes(V.T(), V.W, lay2.lds_rows) : dp_lds_launch_bytes(V.Lpad(), wb);
         const int pf_off = (V.RM != 2 && getenv("SXG_POA_PREFETCH")) ? dp_pf_offset(V.Lpad(), wb, V.T()) : -1;
         if (pf_off >= 0) smem += dp_pf_bytes(V.Lpad(), wb, V.T());
         if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -385,3 +385,18 @@ print("views ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "views ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n_seqs,length", [(4, 300), (4, 700), (4, 1500), (4, 3000), (3, 5000)])
+def test_packed_sweep_handles_the_block_itself(engine, oracle, n_seqs, length):
+    """One, two, three and four-wave workgroups of the packed sweep: the block is done in ONE launch, with no retry --
+    a wrong sweep that the widening ladder silently repairs on the 32-bit kernels (band miss -> re-run) would still
+    produce the oracle's results, only slower, and every other parity test would stay green."""
+    bases, seq_off, blk_off = synth.make_batch(2, n_seqs, length)
+    res = engine.run_flat(bases, seq_off, blk_off, None, gparams("convex_default", 0), want_consensus=False)
+    st = engine.stats()
+    assert st["retries"] == 0 and st["dp_launches"] == 1 and st["dom_row_mode"] == 2, st
+    for b in range(2):
+        seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[b], blk_off[b + 1])]
+        g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
+        assert_block_equal(res[b], g, sc, cells, f"block {b}")
