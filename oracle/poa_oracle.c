@@ -62,6 +62,18 @@
  *     along the diagonal.)  The virtual source row is not banded.
  *  B3 a cell outside its row's band does not exist: H and both outgoing gap candidates are -inf for every
  *     reader, in-row gaps start at the band's first column.  Local mode only; cells = sum of band widths.
+ *  B4 ADAPTIVE band (banded = 2; abPOA's published rule -- Gao et al. 2021, "adaptive banding": the band of a node
+ *     follows the best-scoring cells of its predecessors and the node's position in the graph).  For the row of node v:
+ *       remain(v) = number of edges of the walk that leaves v by its heaviest out-edge (the first of greatest weight in
+ *                   out-list order), and so on from node to node, until a node without out-edges;
+ *       c   = L - remain(v)                                   (where v would sit if the rest of the query ran along it)
+ *       P_l = min over the predecessor rows p of ml(p) + 1,   P_r = max over them of mr(p) + 1
+ *             ml(p) / mr(p) = leftmost / rightmost column of row p's band holding the row's greatest H; virtual row: 0, 0
+ *       the band covers the columns  max(0, min(P_l, c) - w) .. min(L, max(P_r, c) + w),  w as B1,
+ *     in whole strips as B2.  While the greatest H of the first rows of a local alignment is still ambiguous (a 1-mer,
+ *     2-mer ... match somewhere) P_l and P_r lie far apart; a band of more than 128 strips keeps the 128 strips
+ *     from max(first, min(strip(c) - 64, last - 127)) on (one wavefront's window; strip(c) = clamp(c, 0, L) / s).
+ *     B3 applies unchanged.  Stand-alone alignments over a caller's CSR have no edge weights: B4 is a whole-block mode.
  */
 #include "poa_oracle.h"
 #include <stdlib.h>
@@ -233,7 +245,13 @@ static int32_t *ws_new_row(poa_ws_t *w) {
     return r;
 }
 
-/* hint != NULL: banded mode (B1-B3), *band_cells receives the number of cells inside the bands */
+/* banded = params.banded: 0 = off, 1 = backbone band (B2), 2 = adaptive band (B4), strip width from L;
+ * 6 / 8 / 11 = backbone band with that strip width, 0x80 | strip = adaptive band with that strip width */
+static int band_is_adaptive(unsigned banded) { return banded == 2 || (banded & 0x80) != 0; }
+static int band_strip_of(unsigned banded, int L) { const int s = (int)(banded & 0x7f); return s > 2 ? s : poa_band_strip_width(L); }
+
+/* hint != NULL: banded mode (B1-B3: hint = backbone coordinate of every row; B4: hint = remain() of every row),
+ * *band_cells receives the number of cells inside the bands */
 static int align_rows(poa_ws_t *ws, int N, const uint8_t *codes, const int32_t *off, const int32_t *pred,
                       const uint8_t *sink, const int32_t *row_node, const uint8_t *seq, int L,
                       const poa_params_t *pp, int32_t *out_node, int32_t *out_pos,
@@ -292,6 +310,9 @@ static int align_rows(poa_ws_t *ws, int N, const uint8_t *codes, const int32_t *
     }
     int best_i = -1, best_j = -1, best = 0;
     static const int32_t zero_pred = 0;
+    const int adaptive = hint && band_is_adaptive(pp->banded);
+    int32_t *mlr = NULL;   /* B4: ml, mr of every row */
+    if (adaptive) { mlr = (int32_t *)malloc(sizeof(int32_t) * 2 * ((size_t)N + 1)); mlr[0] = 0; mlr[1] = 0; }
     for (int i = 1; i <= N; ++i) {
         int np = off[i] - off[i - 1];
         const int32_t *pl = pred + off[i - 1];
@@ -303,11 +324,34 @@ static int align_rows(poa_ws_t *ws, int N, const uint8_t *codes, const int32_t *
         const int code = codes[i - 1];
         int E = NEG, Q = NEG;
         int beg = 0, end = L;
-        if (hint) {   /* B1, B2 */
-            const int strip = pp->banded > 1 ? (int)pp->banded : poa_band_strip_width(L);
+        if (hint) {   /* B1, B2 / B4 */
+            const int strip = band_strip_of(pp->banded, L);
             const int w0 = POA_BAND_WB + (int)(POA_BAND_WF * L), w = w0 < POA_BAND_WMAX ? w0 : POA_BAND_WMAX, x = hint[i - 1];
-            beg = ((x - w > 0 ? x - w : 0) / strip) * strip;
-            end = ((x + w) / strip) * strip + strip - 1;
+            if (!adaptive) {
+                beg = ((x - w > 0 ? x - w : 0) / strip) * strip;
+                end = ((x + w) / strip) * strip + strip - 1;
+            } else {
+                const int c = L - x;
+                int p_l = 0x7fffffff, p_r = -1;
+                for (int k = 0; k < np; ++k) {
+                    const int l = mlr[2 * pl[k]] + 1, r = mlr[2 * pl[k] + 1] + 1;
+                    if (l < p_l) p_l = l;
+                    if (r > p_r) p_r = r;
+                }
+                int b0 = (p_l < c ? p_l : c) - w, e0 = (p_r > c ? p_r : c) + w;
+                if (b0 < 0) b0 = 0;
+                if (e0 > L) e0 = L;
+                int sb = b0 / strip, se = e0 / strip;
+                if (se - sb + 1 > 128) {
+                    const int sc = (c < 0 ? 0 : (c > L ? L : c)) / strip;
+                    int first = sc - 64;
+                    if (first > se - 127) first = se - 127;
+                    if (first < sb) first = sb;
+                    sb = first; se = first + 127;
+                }
+                beg = sb * strip;
+                end = se * strip + strip - 1;
+            }
             if (end > L) end = L;
             if (band_cells && beg <= end) *band_cells += (uint64_t)(end - beg + 1);
         }

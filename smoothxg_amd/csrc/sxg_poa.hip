@@ -15,6 +15,7 @@
 #include <new>
 #include <string>
 #include <sys/mman.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/sxg_poa.h"
@@ -601,6 +602,7 @@ struct DevBuf {
 struct BlockMeta {
     int maxlen = 0, nseq = 0, rm = 0; bool fits = false; Variant variant{16, 1, 256, 0};
     int tier = 0;      // arena capacity tier the block runs at next (raised by ROWS/POOL/TBX overflow only)
+    bool wide_band = false;   // packed sweep re-run with a traceback plane that keeps EVERY strip (after ST_BAND_MISS)
     int64_t sumlen = 0;
     double cost = 0;
     bool cvx = false, sw = true;
@@ -826,7 +828,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
 }
 
 struct LaunchPlan {
-    Variant variant; bool cvx, sw; int tier = 0;
+    Variant variant; bool cvx, sw; int tier = 0; bool wide_band = false;
     std::vector<int32_t> work;  // block ids, largest cost first
     std::vector<unsigned long long> est;  // cost-model cells per work item (priority balancing)
     // filled by prepare_plan
@@ -834,6 +836,16 @@ struct LaunchPlan {
     int clock_mhz = 0;   // shader clock this launch ran at, sampled from its slots (see sample_clock)
     int smem = 0, pf_off = -1; bool park_lds = true; uint64_t cells = 0, bytes = 0; float ms = 0;
 };
+
+// strips per plane row of the packed sweep: ~1100 columns around the backbone hint (SXG_POA_BAND_COLS narrows it -- a test
+// knob that makes tracebacks miss their band, so that the in-kernel hint shift and the wide-plane re-run are exercised)
+static int plane_strips_p16(int T, int W) {
+    if (const char* e = getenv("SXG_POA_BAND_COLS")) {
+        const int cols = std::max(atoi(e), W);
+        return std::min((cols + W - 1) / W, 2 * T);
+    }
+    return p16_band_strips(T, W);
+}
 
 static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     const Variant V = P.variant;
@@ -873,7 +885,7 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     const int wb = V.RM == 1 ? 8 : 4;
     if (V.RM == 3) pool_slots = 1;   // (the banded sweep has no row ring: predecessors come from the plane)
     P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false,
-                        V.RM == 3 ? band_plane_strips(maxlen, V.W) : (V.RM == 2 ? p16_band_strips(V.T(), V.W) : 0));
+                        V.RM == 3 ? band_plane_strips(maxlen, V.W) : (V.RM == 2 ? (P.wide_band ? 2 * V.T() : plane_strips_p16(V.T(), V.W)) : 0));
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
@@ -1056,16 +1068,17 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
     // Rounds.  A block comes back for two independent reasons, each with its own ladder: its arena was too
     // small (ROWS / POOL / TBX overflow: capacity tier 0..3, the last one is the worst case) or its sweep was
     // too narrow (RANGE overflow / BAND miss: packed -> int16 row words -> int32 row words, at the SAME
-    // capacity tier).  3 + 2 steps at most, so 6 rounds always suffice; neither internal status is ever final.
-    for (int attempt = 0; attempt < 6 && !pending.empty(); ++attempt) {
+    // capacity tier; a band miss first repeats the packed sweep with a plane that keeps every strip).  3 + 3 steps at most, so 7
+    // rounds always suffice; neither internal status is ever final.
+    for (int attempt = 0; attempt < 7 && !pending.empty(); ++attempt) {
         // group by (variant, convex, local, capacity tier): one launch per group, all groups concurrently
         std::vector<LaunchPlan> plans;
         for (int b : pending) {
             const BlockMeta& m = h->meta[b];
             LaunchPlan* pl = nullptr;
             for (auto& q : plans)
-                if (q.variant.W == m.variant.W && q.variant.NW == m.variant.NW && q.variant.RM == m.variant.RM && q.cvx == m.cvx && q.sw == m.sw && q.tier == m.tier) { pl = &q; break; }
-            if (!pl) { plans.emplace_back(); pl = &plans.back(); pl->variant = m.variant; pl->cvx = m.cvx; pl->sw = m.sw; pl->tier = m.tier; }
+                if (q.variant.W == m.variant.W && q.variant.NW == m.variant.NW && q.variant.RM == m.variant.RM && q.cvx == m.cvx && q.sw == m.sw && q.tier == m.tier && q.wide_band == m.wide_band) { pl = &q; break; }
+            if (!pl) { plans.emplace_back(); pl = &plans.back(); pl->variant = m.variant; pl->cvx = m.cvx; pl->sw = m.sw; pl->tier = m.tier; pl->wide_band = m.wide_band; }
             pl->work.push_back(b);
         }
         std::sort(plans.begin(), plans.end(), [](const LaunchPlan& a, const LaunchPlan& b) { return a.variant.Lpad() > b.variant.Lpad(); });
@@ -1076,7 +1089,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         for (size_t i = 0; i < plans.size(); ++i)
             for (size_t j = i + 1; j < plans.size();) {
                 const LaunchPlan &a = plans[i], &b = plans[j];
-                if (a.variant.RM == b.variant.RM && a.variant.RM != 3 && a.cvx == b.cvx && a.sw == b.sw && a.tier == b.tier &&
+                if (a.variant.RM == b.variant.RM && a.variant.RM != 3 && a.cvx == b.cvx && a.sw == b.sw && a.tier == b.tier && a.wide_band == b.wide_band &&
                     (double)b.variant.Lpad() >= merge_ratio * (double)a.variant.Lpad()) {
                     plans[i].work.insert(plans[i].work.end(), b.work.begin(), b.work.end());
                     plans.erase(plans.begin() + (long)j);
@@ -1197,13 +1210,21 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             if (std::find(nomem_blocks.begin(), nomem_blocks.end(), b) != nomem_blocks.end()) continue;
             if (status[b] == ST_ROWS_OVERFLOW || status[b] == ST_POOL_OVERFLOW || status[b] == ST_TBX_OVERFLOW || status[b] == ST_NODES_OVERFLOW) {
                 if (m.tier < 3) { m.tier += 1; again.push_back(b); }
+            } else if (status[b] == ST_BAND_MISS && m.rm == 2 && !m.wide_band) {
+                // The traceback kept leaving the ~1100 columns the plane holds around the backbone hints (a structural variant
+                // that carries the alignment further off).  The same packed sweep is repeated with a plane that keeps EVERY
+                // strip of every row -- rows x columns dwords, up to ~6 GB for a 26 kbp block, but it cannot miss, it covers
+                // every length the packed sweep covers (the 32-bit sweeps end at SXG_POA_MAX_SEQ_LEN_WIDE) and it runs at the
+                // packed sweep's speed.
+                m.wide_band = true;
+                again.push_back(b);
             } else if (status[b] == ST_RANGE_OVERFLOW || status[b] == ST_BAND_MISS) {
                 // one step wider at the same capacity tier: packed -> int16 row words -> int32 row words
                 if (m.rm != 1) {
                     m.rm = row_mode(m.S, m.maxlen, m.maxlen, m.rm >= 2 ? 0 : 1);
                     m.fits = variant_for_len(m.maxlen, m.rm, &m.variant, m.S.sw);
-                    if (m.fits) again.push_back(b);  // (the wider sweeps cover every length the packed one does)
-                    else status[b] = ST_TOO_LONG;
+                    if (m.fits) again.push_back(b);
+                    else status[b] = ST_TOO_LONG;    // (a score range beyond int16 on a sequence beyond SXG_POA_MAX_SEQ_LEN_WIDE)
                 } else status[b] = ST_TOO_LONG;      // (unreachable: the int32 sweep reports neither)
             }
         }
@@ -1454,6 +1475,7 @@ extern "C" int sxg_poa_batch_run(sxg_poa_handle* h, const sxg_poa_batch_in* in, 
         if (_r != ncclSuccess) return fail(SXG_E_NODEVICE, std::string(#x) + ": " + ncclGetErrorString(_r)); \
     } while (0)
 
+constexpr int BC_N_WORDS = 8;   // words per rank in the count exchange (BC_N below)
 extern "C" int sxg_poa_comm_unique_id(uint8_t* id) {
     if (!id) return fail(SXG_E_INVALID, "NULL argument");
     static_assert(sizeof(ncclUniqueId) == SXG_POA_COMM_ID_BYTES, "ncclUniqueId size");
@@ -1475,13 +1497,15 @@ extern "C" int sxg_poa_comm_init(sxg_poa_handle* h, const uint8_t* id, int nrank
     memcpy(&u, id, sizeof(u));
     NCCLCHK(ncclCommInitRank(&h->comm, nranks, u, rank));
     h->own_comm = true; h->nranks = nranks; h->rank = rank;
-    return SXG_OK;
+    // (the exchange buffer of the sharded run's counts: allocated here so that the run itself cannot fail before its collectives)
+    return h->d_counts.ensure(8 * (size_t)BC_N_WORDS * (size_t)(nranks + 1));
 }
 extern "C" int sxg_poa_comm_attach(sxg_poa_handle* h, void* nccl_comm, int nranks, int rank) {
     if (!h || !nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(SXG_E_INVALID, "bad argument");
     sxg_poa_comm_destroy(h);
     h->comm = (ncclComm_t)nccl_comm; h->own_comm = false; h->nranks = nranks; h->rank = rank;
-    return SXG_OK;
+    HIPCHK(hipSetDevice(h->device));
+    return h->d_counts.ensure(8 * (size_t)BC_N_WORDS * (size_t)(nranks + 1));
 }
 
 namespace {
@@ -1538,7 +1562,8 @@ void build_local(const sxg_poa_batch_in* in, const std::vector<int32_t>& part, L
     L.in.per_block_params = in->per_block_params; L.in.want_consensus = in->want_consensus; L.in.want_msa = 0;
 }
 // blob of one rank: eight counts, then the arrays, every section 16-byte aligned
-enum { BC_NB = 0, BC_NS, BC_NBASES, BC_NODES, BC_EDGES, BC_CONS, BC_BYTES, BC_PAD, BC_N };
+enum { BC_NB = 0, BC_NS, BC_NBASES, BC_NODES, BC_EDGES, BC_CONS, BC_BYTES, BC_PAD /* error code of the rank (0 = fine) */, BC_N };
+static_assert(BC_N == BC_N_WORDS, "count words");
 struct BlobLayout { size_t status, nn, ne, nc, score, cells, code, rank, group, et, eh, ew, paths, cons, total; };
 BlobLayout blob_layout(const int64_t* c) {
     BlobLayout B;
@@ -1717,6 +1742,33 @@ int run_shard(sxg_poa_handle* h, const sxg_poa_batch_in* in, const std::vector<i
 }
 }  // namespace
 
+// Waiting for a collective with a deadline: a peer that died (or never called) would otherwise park this rank in
+// hipStreamSynchronize for ever.  The stream is polled; after SXG_POA_COMM_TIMEOUT_S seconds (default 600) or on an
+// asynchronous RCCL error the communicator is aborted and the call returns SXG_E_NODEVICE.
+static void comm_abort(sxg_poa_handle* h) {
+    if (h->comm && h->own_comm) (void)ncclCommAbort(h->comm);   // (an attached communicator stays the caller's to abort)
+    h->comm = nullptr; h->own_comm = false; h->nranks = 1; h->rank = 0;
+}
+static int comm_wait(sxg_poa_handle* h, const char* what) {
+    static const double limit = [] { const char* e = getenv("SXG_POA_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 600.0; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) return SXG_OK;
+        if (q != hipErrorNotReady) { comm_abort(h); return fail(SXG_E_NODEVICE, std::string(what) + ": " + hipGetErrorString(q)); }
+        ncclResult_t ar = ncclSuccess;
+        if (h->comm && (spin & 255) == 255 && (ncclCommGetAsyncError(h->comm, &ar) != ncclSuccess || (ar != ncclSuccess && ar != ncclInProgress))) {
+            comm_abort(h);
+            return fail(SXG_E_NODEVICE, std::string(what) + ": RCCL reported " + ncclGetErrorString(ar));
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            comm_abort(h);
+            return fail(SXG_E_NODEVICE, std::string(what) + ": no completion after " + std::to_string((int)limit) + " s (a peer rank failed or never called); communicator aborted");
+        }
+        if (spin > 1000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
 static int check_batch(const sxg_poa_batch_in* in) {
     if (in->n_blocks < 0 || (in->n_blocks > 0 && (!in->blk_off || !in->seq_off || !in->params || !in->bases))) return fail(SXG_E_INVALID, "batch_in has NULL arrays");
     return SXG_OK;
@@ -1732,28 +1784,60 @@ extern "C" int sxg_poa_batch_run_sharded(sxg_poa_handle* h, const sxg_poa_batch_
     std::vector<std::vector<int32_t>> parts;
     lpt_partition(in, nranks, parts);
     std::vector<int64_t> counts((size_t)nranks * BC_N, 0);
-    if ((rc = run_shard(h, in, parts[rank], counts.data() + (size_t)rank * BC_N))) return rc;
+    int64_t* mine = counts.data() + (size_t)rank * BC_N;
+    rc = run_shard(h, in, parts[rank], mine);
+    if (nranks == 1 && rc) return rc;
     if (nranks > 1) {
-        // sizes first (RCCL has no all-gather-v) ...
-        if ((rc = h->d_counts.ensure(8 * (size_t)BC_N * (size_t)(nranks + 1)))) return rc;
+        // A rank-local failure (allocation, HIP error) must not leave the peers blocked in a collective: the failing rank
+        // still takes part in the size exchange, with its error code in BC_PAD and nothing to send, and EVERY rank then
+        // returns that failure -- the ranks fail together.  (d_counts is allocated by sxg_poa_comm_init / _attach.)
+        std::string local_err = rc ? std::string(sxg_poa_last_error()) : std::string();
+        if (rc) { memset(mine, 0, sizeof(int64_t) * BC_N); mine[BC_PAD] = rc; }
         int64_t* dc = h->d_counts.as<int64_t>();
-        HIPCHK(hipMemcpyAsync(dc + (size_t)nranks * BC_N, counts.data() + (size_t)rank * BC_N, 8 * BC_N, hipMemcpyHostToDevice, h->stream));
+        if (!dc) return fail(SXG_E_INVALID, "sharded run without sxg_poa_comm_init / sxg_poa_comm_attach");
+        auto gathered_failure = [&](const char* what) -> int {
+            for (int r = 0; r < nranks; ++r)
+                if (counts[(size_t)r * BC_N + BC_PAD]) {
+                    const int code = (int)counts[(size_t)r * BC_N + BC_PAD];
+                    return fail(code, std::string("sharded run: rank ") + std::to_string(r) + " failed " + what + " (code " + std::to_string(code) + ")" +
+                                      (r == rank && !local_err.empty() ? ": " + local_err : std::string()));
+                }
+            return SXG_OK;
+        };
+        // sizes first (RCCL has no all-gather-v) ...
+        HIPCHK(hipMemcpyAsync(dc + (size_t)nranks * BC_N, mine, 8 * BC_N, hipMemcpyHostToDevice, h->stream));
         NCCLCHK(ncclAllGather(dc + (size_t)nranks * BC_N, dc, BC_N, ncclInt64, h->comm, h->stream));
         HIPCHK(hipMemcpyAsync(counts.data(), dc, 8 * (size_t)BC_N * nranks, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        // ... then every blob straight to the root, exact sizes, one group: the seven peers use their own xGMI links
+        if ((rc = comm_wait(h, "size all-gather"))) return rc;
+        if ((rc = gathered_failure("while aligning its share"))) return rc;
+        // ... the root makes room (the one step after the size exchange that can fail on one rank only: its outcome is
+        // all-gathered too, one word per rank, before anybody posts a send) ...
         std::vector<size_t> at(nranks + 1, 0);
         for (int r = 1; r < nranks; ++r) at[r + 1] = at[r] + (((size_t)counts[(size_t)r * BC_N + BC_BYTES] + 255) & ~(size_t)255);
-        if (rank == 0 && (rc = h->d_recv.ensure(at[nranks] + 256))) return rc;
-        NCCLCHK(ncclGroupStart());
-        if (rank == 0) {
-            for (int r = 1; r < nranks; ++r)
-                if (counts[(size_t)r * BC_N + BC_BYTES] > 0)
-                    NCCLCHK(ncclRecv(h->d_recv.as<uint8_t>() + at[r], (size_t)counts[(size_t)r * BC_N + BC_BYTES], ncclUint8, r, h->comm, h->stream));
-        } else if (counts[(size_t)rank * BC_N + BC_BYTES] > 0)
-            NCCLCHK(ncclSend(h->d_blob.p, (size_t)counts[(size_t)rank * BC_N + BC_BYTES], ncclUint8, 0, h->comm, h->stream));
-        NCCLCHK(ncclGroupEnd());
-        HIPCHK(hipStreamSynchronize(h->stream));
+        int64_t ready = 0;
+        if (rank == 0 && (rc = h->d_recv.ensure(at[nranks] + 256))) { ready = rc; local_err = sxg_poa_last_error(); }
+        std::vector<int64_t> readies((size_t)nranks, 0);
+        HIPCHK(hipMemcpyAsync(dc + (size_t)nranks * BC_N, &ready, 8, hipMemcpyHostToDevice, h->stream));
+        NCCLCHK(ncclAllGather(dc + (size_t)nranks * BC_N, dc, 1, ncclInt64, h->comm, h->stream));
+        HIPCHK(hipMemcpyAsync(readies.data(), dc, 8 * (size_t)nranks, hipMemcpyDeviceToHost, h->stream));
+        if ((rc = comm_wait(h, "receive-buffer all-gather"))) return rc;
+        for (int r = 0; r < nranks; ++r) counts[(size_t)r * BC_N + BC_PAD] = readies[r];
+        if ((rc = gathered_failure("to allocate the receive buffer"))) return rc;
+        // ... then every blob straight to the root, exact sizes, one group: the seven peers use their own xGMI links.
+        // ncclGroupStart is ALWAYS paired with ncclGroupEnd: an error inside the group is reported after the group is closed.
+        ncclResult_t gr = ncclGroupStart(), g2;
+        if (gr == ncclSuccess) {
+            if (rank == 0) {
+                for (int r = 1; r < nranks && gr == ncclSuccess; ++r)
+                    if (counts[(size_t)r * BC_N + BC_BYTES] > 0)
+                        gr = ncclRecv(h->d_recv.as<uint8_t>() + at[r], (size_t)counts[(size_t)r * BC_N + BC_BYTES], ncclUint8, r, h->comm, h->stream);
+            } else if (mine[BC_BYTES] > 0)
+                gr = ncclSend(h->d_blob.p, (size_t)mine[BC_BYTES], ncclUint8, 0, h->comm, h->stream);
+            g2 = ncclGroupEnd();
+            if (gr == ncclSuccess) gr = g2;
+        }
+        if (gr != ncclSuccess) { comm_abort(h); return fail(SXG_E_NODEVICE, std::string("blob exchange: ") + ncclGetErrorString(gr)); }
+        if ((rc = comm_wait(h, "blob exchange"))) return rc;
         if (rank != 0) return SXG_NOT_ROOT;
         std::vector<std::vector<uint8_t>> blobs(nranks);
         for (int r = 0; r < nranks; ++r) {

@@ -121,6 +121,30 @@ def test_local_alignments_beyond_12_kbp_run_the_16_wave_packed_classes(engine, o
     assert far[0].status == 5
 
 
+def test_band_miss_on_a_long_block_is_rerun_with_a_full_plane(engine, oracle, monkeypatch):
+    """A local block of 14 kbp whose traceback cannot stay inside the plane's band (here: a 700 bp insertion and a plane
+    narrowed to 96 columns by the test knob, so the in-kernel hint shifts cannot repair it) used to end on the 32-bit
+    sweep -- which stops at 12 287 columns, i.e. ST_TOO_LONG for the block and SXG_E_BLOCK for the batch.  The engine now
+    repeats the packed sweep with a plane that keeps every strip: same results as the oracle, one retry, still packed."""
+    rng = np.random.default_rng(4711)
+    base = random_block(rng, 1, 14000, div=0.0)[0]
+    ins = rng.integers(0, 4, 700).astype(np.uint8)
+    with_sv = np.concatenate([base[:6000], ins, base[6000:13300]])
+    third = base.copy()
+    third[rng.integers(0, len(third), 150)] = rng.integers(0, 4, 150).astype(np.uint8)
+    seqs = [base, with_sv, third]
+    g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
+    monkeypatch.setenv("SXG_POA_BAND_COLS", "96")
+    res = engine.run_blocks([seqs], gparams("convex_default", 0))
+    st = engine.stats()
+    assert st["retries"] >= 1 and st["dom_row_mode"] == 2, st
+    assert_block_equal(res[0], g, sc, cells, label="band-miss-long")
+    # with the default plane (1100 columns) the same block needs no retry: the hints follow the insertion
+    monkeypatch.delenv("SXG_POA_BAND_COLS")
+    res = engine.run_blocks([seqs], gparams("convex_default", 0))
+    assert_block_equal(res[0], g, sc, cells, label="band-default-long")
+
+
 def test_invalid_arguments(engine):
     import smoothxg_amd as S
     with pytest.raises(S.PoaError):
