@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
 CMD="python $R/bench.py --workload ${WL:-ns} --steps ${STEPS:-1} --warmup ${WARMUP:-1} --no-cpu-baseline --no-e2e ${EXTRA:-}"
 i=0
-for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU" \
          "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc16_$i -o pmc -- $CMD > $OUT/pmc16_$i.log 2>&1

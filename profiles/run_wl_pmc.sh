@@ -9,6 +9,8 @@ for ITEM in ${WLS:-c2 c3b c4}; do
   WL=${ITEM%%:*}; MODE=sw; case $ITEM in *:*) MODE=${ITEM##*:}; WL=$WL+$MODE;; esac
   CMD="python $R/bench.py --workload ${ITEM%%:*} --mode $MODE --steps 1 --warmup 0 --no-cpu-baseline --no-e2e"
   for C in SQ_INSTS_VALU FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/wl_${WL}_$C -o pmc -- $CMD > $OUT/wl_${WL}_$C.log 2>&1
+    # (the instruction pass also counts the dual-rate issues: bench.py prices full-rate opcodes issued back to back at 2 cycles)
+    PMC=$C; [ $C = SQ_INSTS_VALU ] && PMC="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU2"
+    rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/wl_${WL}_$C -o pmc -- $CMD > $OUT/wl_${WL}_$C.log 2>&1
   done
 done
