@@ -35,6 +35,8 @@ WORKLOADS = {
     "c3": (5000, 64, 5000, (1, -4, -8, -2, -8, -2), "config 3: 5000 blocks x 64 seqs x 5 kbp, affine (abPOA o+k*e => g=-(o+e)), full matrix"),
     # config 3 as the reference's -A (abPOA) path runs it: banded, wb=311 wf=0.03 (src/smooth.cpp:266-271); cells = band cells
     "c3b": (5000, 64, 5000, (1, -4, -8, -2, -8, -2), "config 3 banded: 5000 blocks x 64 seqs x 5 kbp, affine, band w = 311 + 0.03 L (abPOA path)"),
+    # ... and with abPOA's ADAPTIVE band (params.banded = 2, decree B4): what smooth_abpoa really asks for (src/smooth.cpp:2090)
+    "c3a": (5000, 64, 5000, (1, -4, -8, -2, -8, -2), "config 3 adaptive band: 5000 blocks x 64 seqs x 5 kbp, affine, abPOA's adaptive band w = 311 + 0.03 L"),
     # config 4 is 50 000 mixed blocks over 8 GPUs: 6 250 per GPU; seqs/length are drawn per block (synth mixed=True)
     "c4": (6250, 0, 0, (1, -4, -6, -2, -26, -1), "config 4: mixed blocks, 8-128 seqs x 0.5-10 kbp, 6250 per GPU, convex 1,4,6,2,26,1"),
     "tiny": (64, 8, 400, (1, -4, -6, -2, -26, -1), "smoke: 64 blocks x 8 seqs x 400 bp"),
@@ -279,6 +281,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sxg_smooth_gfa measurement")
     ap.add_argument("--check", action="store_true", help="also verify 2 blocks against the oracle")
+    ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
+                    help="N > 1: the hand-off of every step's results to rank 0 -- cabi: sxg_poa_batch_execute_sharded (the C ABI's own RCCL "
+                         "communicator: counts all-gathered, one grouped ncclSend/ncclRecv per peer); torch: shard.RootGather "
+                         "(torch.distributed batch_isend_irecv on zero-copy views of the results)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -300,26 +306,54 @@ def main():
     if a.blocks:
         nb = a.blocks
     mode = 0 if a.mode == "sw" else 1
-    params = S.Params(*prm, mode, 1 if a.workload == "c3b" else 0)
+    params = S.Params(*prm, mode, {"c3b": 1, "c3a": 2}.get(a.workload, 0))
     strong = a.scaling == "strong" and world > 1
-    if strong:
-        # every rank builds the same batch and keeps its LPT share: block costs span four orders of magnitude
-        # on config 4, so the deal -- not the count -- balances the GPUs
-        bases, seq_off, blk_off = synth.make_batch(nb, ns, ln, first_block=0, mixed=(a.workload == "c4"))
-        _, bases, seq_off, blk_off = shard.shard_batch(bases, seq_off, blk_off, rank, world)
-    else:
-        bases, seq_off, blk_off = synth.make_batch(nb, ns, ln, first_block=rank * nb, mixed=(a.workload == "c4"))
-    n_local = len(blk_off) - 1
     eng = S.PoaEngine(local_rank)
-    eng.upload(bases, seq_off, blk_off, None, params)  # inputs resident in HBM from here on
+    # N > 1: the engine's own RCCL communicator (sxg_poa_comm_init): rank 0 draws the id, torch.distributed carries it
+    exchange = "none"
+    if world > 1:
+        exchange = a.exchange
+        if exchange == "cabi":
+            os.environ.setdefault("SXG_POA_COMM_TIMEOUT_S", "180")
+            ok = 1
+            try:
+                ids = [eng.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                eng.comm_init(ids[0], world, rank)
+            except Exception as e:   # (every rank must learn of it: the ranks switch together)
+                print("[bench] rank %d: C-ABI communicator failed: %s" % (rank, e), file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                exchange = "torch (C-ABI communicator could not be created)"
+    if strong and exchange == "cabi":
+        # every rank hands the SAME batch to the C ABI, which deals it by cost (LPT) and uploads this rank's share
+        bases, seq_off, blk_off = synth.make_batch(nb, ns, ln, first_block=0, mixed=(a.workload == "c4"))
+        eng.upload_sharded(bases, seq_off, blk_off, None, params)
+    else:
+        if strong:
+            # every rank builds the same batch and keeps its LPT share: block costs span four orders of magnitude
+            # on config 4, so the deal -- not the count -- balances the GPUs
+            bases, seq_off, blk_off = synth.make_batch(nb, ns, ln, first_block=0, mixed=(a.workload == "c4"))
+            _, bases, seq_off, blk_off = shard.shard_batch(bases, seq_off, blk_off, rank, world)
+        else:
+            bases, seq_off, blk_off = synth.make_batch(nb, ns, ln, first_block=rank * nb, mixed=(a.workload == "c4"))
+        eng.upload(bases, seq_off, blk_off, None, params)  # inputs resident in HBM from here on
+    n_local = len(blk_off) - 1
 
-    to_root = shard.RootGather() if world > 1 else None
+    to_root = shard.RootGather() if world > 1 and exchange != "cabi" else None
 
     def step():
+        if exchange == "cabi":
+            # align the resident share, pack it into one device blob, sizes all-gathered, every blob straight to rank 0:
+            # the one real exchange of the path (results meet on the rank that laces), through the C ABI's own communicator
+            eng.execute_sharded()
+            return
         eng.execute()
         if world > 1:
-            # the one real exchange of the path: results meet on the rank that laces (rank 0), device to device,
-            # one exact-size message per peer over its own xGMI link; nothing is all-gathered
+            # the same hand-off through torch.distributed: device to device, one exact-size message per peer over its
+            # own xGMI link; nothing is all-gathered
             to_root(shard.engine_result_tensors(eng))
 
     def fence():
@@ -355,8 +389,8 @@ def main():
 
     if a.check and rank == 0:
         from oracle import oracle_py as O
-        res = eng.download()
-        for b in (0, n_local - 1):
+        res = eng.download_sharded() if (strong and exchange == "cabi") else eng.download()
+        for b in (0, len(res) - 1):
             seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[b], blk_off[b + 1])]
             g, sc, _ = O.block_run(seqs, None, O.mkparams(*prm, mode=mode))
             assert (res[b].scores == sc).all() and len(res[b].node_code) == g.n_nodes, "bench check failed"
@@ -436,6 +470,8 @@ def main():
                          "bytes_per_cell": algo_bytes / max(cells, 1),
                          "valu": valu, "hbm": hbm},
             "engine": {"slots": st["n_slots"], "retries": st["retries"], "arena_bytes": st["device_bytes"]},
+            "exchange": ({"path": "C ABI: sxg_poa_batch_execute_sharded (RCCL all-gather of sizes + grouped ncclSend/ncclRecv to rank 0)"
+                          if exchange == "cabi" else exchange, **(eng.sharded_info() if exchange == "cabi" else {})} if world > 1 else None),
         }
         if world == 1 and not a.no_e2e and a.workload in ("ns", "c2", "tiny"):
             e_s, e_bytes = end_to_end(eng, bases, seq_off, blk_off, prm, mode)
@@ -444,7 +480,7 @@ def main():
                                  "seconds": e_s, "blocks_per_sec": nb / e_s, "gfa_bytes": e_bytes,
                                  "kernel_only_blocks_per_sec": nb * a.steps / (kernel_ms / 1e3),
                                  "ratio_to_kernel_only": (nb / e_s) / (nb * a.steps / (kernel_ms / 1e3))}
-        if world == 1 and not a.no_cpu_baseline and a.workload not in ("c4", "c3b"):  # (no fixed shape to sample for c4)
+        if world == 1 and not a.no_cpu_baseline and a.workload not in ("c4", "c3b", "c3a"):  # (no fixed shape to sample for c4)
             cb = cpu_baseline(a.workload, mode)
             cells_per_block = cells / a.steps / nb
             out["cpu_baseline"] = {"value": cb["cells_per_s"] / cells_per_block, "unit": "blocks/s",

@@ -38,7 +38,11 @@
 extern "C" {
 #endif
 
-#define SXG_POA_ABI_VERSION 1
+/* 3: params.banded = 2 (adaptive band); sxg_poa_batch_run_sharded fails on all ranks together and needs the exchange buffer
+ *    that sxg_poa_comm_init / _attach allocate; a band miss is repaired inside the engine at any length.
+ * 2 (round 2, never numbered): params.reserved became params.banded -- callers must zero it --, stats.reserved became
+ *    dom_clock_mhz, status 7 (SXG_ST_BAND_MISS), SXG_POA_MAX_SEQ_LEN 12287 -> 26623 with SXG_POA_MAX_SEQ_LEN_WIDE. */
+#define SXG_POA_ABI_VERSION 3
 
 #define SXG_MODE_LOCAL 0  /* spoa::AlignmentType::kSW */
 #define SXG_MODE_GLOBAL 1 /* spoa::AlignmentType::kNW */
@@ -72,11 +76,17 @@ extern "C" {
 typedef struct sxg_poa_params {
     int8_t m, n, g, e, q, c;
     uint8_t mode;
-    uint8_t banded; /* 0 = full matrix (the spoa path, smooth_spoa); 1 = banded as the abPOA path (smooth_abpoa,
-                       src/smooth.cpp:133-627: wb = 311, wf = 0.03 at :266-271).  The band is this engine's own:
-                       w = 311 + (int)(0.03 L) columns either side of the node's backbone coordinate, in whole
-                       11-column strips (oracle/poa_oracle.c, decrees B1-B3; abPOA is absent from the reference
-                       snapshot).  Local mode only; out->cells then counts band cells.                     */
+    uint8_t banded; /* 0 = full matrix (the spoa path, smooth_spoa).
+                       2 = ADAPTIVE band as the abPOA path runs it (smooth_abpoa, src/smooth.cpp:133-627: wb = 311,
+                           wf = 0.03 at :266-271, `true` at :2090): the band of a graph row spans, w = 311 + (int)(0.03 L)
+                           columns either side, from the leftmost to the rightmost best-scoring column of its predecessor
+                           rows (+1) and the node's position counted back from the end of the graph -- abPOA's published
+                           rule, restated as decree B4 of oracle/poa_oracle.c (abPOA itself is absent from the reference
+                           snapshot); whole 6-, 8- or 11-column strips, at most 128 strips.
+                       1 = STATIC band: w columns either side of the node's backbone coordinate (decrees B1-B3), known
+                           before the sweep starts; same kernel, no per-row search of the best cell.
+                       Local mode only (a global alignment asked to be banded runs the full matrix); out->cells
+                       then counts band cells.  sxg_poa_align_batch ignores it.                                   */
 } sxg_poa_params;
 
 typedef struct sxg_poa_handle sxg_poa_handle;
@@ -217,6 +227,21 @@ int sxg_poa_comm_init(sxg_poa_handle *h, const uint8_t *id, int nranks, int rank
 int sxg_poa_comm_attach(sxg_poa_handle *h, void *nccl_comm, int nranks, int rank); /* caller-owned ncclComm_t */
 void sxg_poa_comm_destroy(sxg_poa_handle *h);
 int sxg_poa_batch_run_sharded(sxg_poa_handle *h, const sxg_poa_batch_in *in, sxg_poa_batch_out *out);
+/* The same in three stages (sxg_poa_batch_run_sharded = upload + execute + download), for callers that keep the inputs
+ * resident or cut the shares themselves:
+ *   _upload_sharded    every rank, SAME batch: deals the blocks by cost and uploads this rank's share;
+ *   _execute_sharded   every rank (collective): aligns the uploaded share -- dealt above, or uploaded by the caller with
+ *                      sxg_poa_batch_upload --, packs the results into one device blob, all-gathers the blob sizes and sends
+ *                      every blob to rank 0 (grouped ncclSend/ncclRecv).  A failure on one rank is returned by ALL ranks;
+ *                      a collective that does not complete within SXG_POA_COMM_TIMEOUT_S seconds (default 600) aborts the
+ *                      communicator and returns SXG_E_NODEVICE instead of hanging;
+ *   _download_sharded  rank 0: the results of all ranks in the batch's block order (needs the deal of _upload_sharded);
+ *                      other ranks: SXG_NOT_ROOT.
+ * sxg_poa_sharded_info: ranks whose counts arrived in the last exchange and bytes rank 0 received from its peers. */
+int sxg_poa_batch_upload_sharded(sxg_poa_handle *h, const sxg_poa_batch_in *in);
+int sxg_poa_batch_execute_sharded(sxg_poa_handle *h);
+int sxg_poa_batch_download_sharded(sxg_poa_handle *h, const sxg_poa_batch_in *in, sxg_poa_batch_out *out);
+int sxg_poa_sharded_info(sxg_poa_handle *h, int32_t *ranks_seen, uint64_t *bytes_received);
 /* Test entry: the same partition / packing / assembly with `nranks` simulated ranks on this one GPU. */
 int sxg_poa_batch_run_sharded_local(sxg_poa_handle *h, const sxg_poa_batch_in *in, int nranks, sxg_poa_batch_out *out);
 

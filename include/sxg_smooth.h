@@ -46,6 +46,13 @@ typedef struct sxg_smooth_params {
     const char *consensus_base_name;                  /* default "Consensus_" */
     int32_t adaptive_poa_params;                      /* -a: per-block scores from the estimated identity, default 0 */
     int32_t kmer_size;                                /* -k: k-mer size of the identity estimate, default 17 */
+    int32_t use_abpoa;                                /* -A (src/main.cpp:130-132): the smooth_abpoa path, src/smooth.cpp:133-627.  The
+                                                         scores are then in abPOA's convention -- a gap of k costs min(g + k e, q + k c);
+                                                         g = 0: linear, q = 0: affine (the 4-parameter form sets q = c = 0,
+                                                         src/main.cpp:355-358) --, alignments run with the ADAPTIVE band
+                                                         (params.banded = 2: wb = 311, wf = 0.03, src/smooth.cpp:266-271,2090) and the
+                                                         consensus path keeps only nodes some sequence visits (build_odgi_abPOA,
+                                                         src/smooth.cpp:2542-2548).  Default 0. */
 } sxg_smooth_params;
 
 void sxg_smooth_default_params(sxg_smooth_params *p);

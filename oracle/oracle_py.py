@@ -49,6 +49,7 @@ def lib():
         L.poa_graph_edges.argtypes = [vp, i32p, i32p, u32p]
         L.poa_graph_rows.argtypes = [vp, u8p, i32p, i32p, u8p, i32p]
         L.poa_graph_row_hints.argtypes = [vp, i32p]
+        L.poa_graph_row_remain.argtypes = [vp, i32p]
         L.poa_graph_seq_len.argtypes = [vp, C.c_int]
         L.poa_graph_seq_path.argtypes = [vp, C.c_int, i32p]
         L.poa_consensus.argtypes = [vp, i32p]
@@ -159,6 +160,11 @@ class Graph:
     def row_hints(self):
         out = np.empty(max(self.n_nodes, 1), np.int32)
         lib().poa_graph_row_hints(self.h, _p(out, C.c_int32))
+        return out[:self.n_nodes].copy()
+
+    def row_remain(self):
+        out = np.empty(max(self.n_nodes, 1), np.int32)
+        lib().poa_graph_row_remain(self.h, _p(out, C.c_int32))
         return out[:self.n_nodes].copy()
 
     def seq_path(self, s):

@@ -393,11 +393,20 @@ static int align_rows(poa_ws_t *ws, int N, const uint8_t *codes, const int32_t *
             if (P.sw && h > best) { best = h; best_i = i; best_j = j; }
         }
         if (!P.sw && sink[i - 1] && (best_i < 0 || H[L] > best)) { best = H[L]; best_i = i; best_j = L; }
+        if (adaptive) {   /* B4: leftmost / rightmost column of the band holding the row's greatest H */
+            int mx = H[beg], l = beg, r = beg;
+            for (int j = beg + 1; j <= end; ++j) {
+                if (H[j] > mx) { mx = H[j]; l = j; r = j; }
+                else if (H[j] == mx) r = j;
+            }
+            mlr[2 * i] = l; mlr[2 * i + 1] = r;
+        }
         /* release rows nobody will read again */
         for (int r = free_head[i]; r >= 0; r = free_next[r]) { ROW_FREE(Hm[r]); Hm[r] = NULL; }
     }
 #undef ROW_ALLOC
 #undef ROW_FREE
+    free(mlr);
 
     int n = 0;
     if (best_i >= 0) {
@@ -490,7 +499,7 @@ int poa_align_ws(poa_ws_t *ws, const poa_graph_t *g, const uint8_t *seq, int len
         uint64_t bc = 0;
         if (banded) {
             hint = (int32_t *)ws_get(ws, WS_HINT, sizeof(int32_t) * (size_t)N);
-            poa_graph_row_hints(g, hint);
+            if (band_is_adaptive(p->banded)) poa_graph_row_remain(g, hint); else poa_graph_row_hints(g, hint);
         }
         n = align_rows(ws, N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score, hint, &bc);
         if (banded && cells) *cells = bc;
@@ -620,6 +629,18 @@ void poa_graph_edges(const poa_graph_t *g, int32_t *tail, int32_t *head, uint32_
 void poa_graph_row_hints(const poa_graph_t *g, int32_t *hints) {
     for (int r = 0; r < g->n_nodes; ++r) hints[r] = g->xpos[g->order[r]];
 }
+/* B4: remain() of the node of every rank -- edges of the walk along heaviest out-edges (first of greatest weight in
+ * out-list order) down to a node without out-edges.  Reverse rank order: every out-neighbour has a greater rank. */
+void poa_graph_row_remain(const poa_graph_t *g, int32_t *remain) {
+    for (int r = g->n_nodes - 1; r >= 0; --r) {
+        const int v = g->order[r];
+        int best = -1;
+        uint32_t bw = 0;
+        for (int e = g->out_head[v]; e >= 0; e = g->e_next_out[e])
+            if (best < 0 || g->e_w[e] > bw) { best = g->e_head[e]; bw = g->e_w[e]; }
+        remain[r] = best < 0 ? 0 : remain[g->rank[best]] + 1;
+    }
+}
 int poa_graph_seq_len(const poa_graph_t *g, int s) { return (int)(g->seq_off[s + 1] - g->seq_off[s]); }
 void poa_graph_seq_path(const poa_graph_t *g, int s, int32_t *nodes) {
     memcpy(nodes, g->path + g->seq_off[s], sizeof(int32_t) * (size_t)poa_graph_seq_len(g, s));
@@ -731,7 +752,8 @@ poa_graph_t *poa_block_run_ws(poa_ws_t *ws, const uint8_t *bases, const int32_t 
     int32_t *an = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
     int32_t *ap = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
     poa_params_t pb = *p;   /* B2: one strip width for all alignments of the block, from its longest sequence */
-    if (pb.banded && pb.mode == POA_MODE_SW) pb.banded = (uint8_t)poa_band_strip_width((long)maxlen);
+    if (pb.banded && pb.mode == POA_MODE_SW)
+        pb.banded = (uint8_t)((band_is_adaptive(pb.banded) ? 0x80 : 0) | poa_band_strip_width((long)maxlen));
     for (int s = 0; s < n_seqs; ++s) {
         const uint8_t *seq = bases + seq_off[s];
         const int len = seq_off[s + 1] - seq_off[s];

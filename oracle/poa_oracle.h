@@ -38,10 +38,11 @@ typedef struct {
     int8_t m, n, g, e, q, c; /* spoa sign convention: m>0 match, n<=0 mismatch, gaps <=0
                                 (src/smooth.cpp:2098-2106 negates the CLI values)       */
     uint8_t mode;            /* POA_MODE_SW | POA_MODE_NW                               */
-    uint8_t banded;          /* != 0: abPOA-style band wb=311, wf=0.03 (src/smooth.cpp:266-271), decrees B1-B3 in
-                                poa_oracle.c; local mode only (ignored for POA_MODE_NW).  1 = the strip width (B2)
-                                follows from the length of the sequence being aligned; 6, 8 or 11 = that strip width
-                                (what poa_block_run sets for every alignment of a block: from the block's longest)  */
+    uint8_t banded;          /* != 0: abPOA-style band wb=311, wf=0.03 (src/smooth.cpp:266-271), decrees B1-B4 in
+                                poa_oracle.c; local mode only (ignored for POA_MODE_NW).  1 = band around the backbone
+                                coordinate (B2), 2 = ADAPTIVE band (B4: abPOA's rule), strip width from the length of the
+                                sequence being aligned; 6, 8 or 11 = B2 with that strip width, 0x80 | 6, 8, 11 = B4 with that
+                                strip width (what poa_block_run sets for every alignment of a block: from the block's longest) */
 } poa_params_t;
 
 #define POA_BAND_WB 311
@@ -116,6 +117,7 @@ void poa_graph_rows(const poa_graph_t *g, uint8_t *codes, int32_t *off, int32_t 
                     uint8_t *sink, int32_t *row_node);
 /* backbone coordinate of the node at every rank (decree B2 / the HIP sweep's band hints) */
 void poa_graph_row_hints(const poa_graph_t *g, int32_t *hints);
+void poa_graph_row_remain(const poa_graph_t *g, int32_t *remain);
 int poa_graph_seq_len(const poa_graph_t *g, int s);
 void poa_graph_seq_path(const poa_graph_t *g, int s, int32_t *nodes);
 

@@ -347,10 +347,24 @@ def collect_text(c):
 CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
 
 
-def poa(c, m=1, n=4, g=6, e=2, q=26, cc=1, local=True):
+def engine_params(m, n, g, e, q, cc, local, abpoa):
+    """CLI scores -> the POA engine's (spoa's) convention.  smooth_spoa negates them (src/smooth.cpp:2098-2106); smooth_abpoa
+    hands them to abPOA as they are (:2079-2090): a gap of k costs min(g + k e, q + k cc), g = 0 linear, q = 0 affine, and the
+    alignment runs with abPOA's adaptive band (banded = 2)."""
+    mode = 0 if local else 1
+    if not abpoa:
+        return O.mkparams(m, -n, -g, -e, -q, -cc, mode)
+    if g == 0:
+        return O.mkparams(m, -n, -e, -e, -e, -e, mode, banded=2)
+    if q == 0:
+        return O.mkparams(m, -n, -(g + e), -e, -(g + e), -e, mode, banded=2)
+    return O.mkparams(m, -n, -(g + e), -e, -(q + cc), -cc, mode, banded=2)
+
+
+def poa(c, m=1, n=4, g=6, e=2, q=26, cc=1, local=True, abpoa=False):
     """The POA of one block through the C oracle -> (node letters, per-seq paths, consensus)."""
     seqs = [np.array([CODE.get(ch, 4) for ch in s], np.uint8) for s in c.seqs]
-    G, _, _ = O.block_run(seqs, c.weights, O.mkparams(m, -n, -g, -e, -q, -cc, 0 if local else 1))
+    G, _, _ = O.block_run(seqs, c.weights, engine_params(m, n, g, e, q, cc, local, abpoa))
     code = G.nodes()[0]
     return code, [G.seq_path(k) for k in range(len(seqs))], G.consensus()
 
@@ -492,8 +506,9 @@ def to_gfa(G):
     return "\n".join(o) + "\n"
 
 
-def build_block_graph(c, node_code, seq_paths, cons, consensus_name):
-    """A9 (src/smooth.cpp:2576-2654) + A10 (:935-1010)."""
+def build_block_graph(c, node_code, seq_paths, cons, consensus_name, abpoa=False):
+    """A9 (src/smooth.cpp:2576-2654; abpoa: build_odgi_abPOA :2442-2574, whose consensus path keeps only nodes that a
+    sequence path visits, :2542-2548) + A10 (:935-1010)."""
     by_name = []
     for i, s in enumerate(c.seqs):
         for j, nm in enumerate(c.dup_seq_names[i]):
@@ -502,7 +517,8 @@ def build_block_graph(c, node_code, seq_paths, cons, consensus_name):
                 st = [h ^ 1 for h in reversed(st)]
             by_name.append((nm, st))
     if consensus_name:
-        by_name.append((consensus_name, [int(v) << 1 for v in cons]))
+        visited = {h >> 1 for _, st in by_name for h in st}
+        by_name.append((consensus_name, [int(v) << 1 for v in cons if not abpoa or int(v) in visited]))
     used = sorted({h >> 1 for _, st in by_name for h in st})
     keep = {v: k for k, v in enumerate(used)}
     G = OGraph()
@@ -521,9 +537,9 @@ def build_block_graph(c, node_code, seq_paths, cons, consensus_name):
 
 
 # ---- MSA -> MAF rows (src/smooth.cpp:782-905) and the MAF block text (src/maf.hpp:35-66)
-def poa_msa(c, add_consensus, m=1, n=4, g=6, e=2, q=26, cc=1, local=True):
+def poa_msa(c, add_consensus, m=1, n=4, g=6, e=2, q=26, cc=1, local=True, abpoa=False):
     seqs = [np.array([CODE.get(ch, 4) for ch in s], np.uint8) for s in c.seqs]
-    G, _, _ = O.block_run(seqs, c.weights, O.mkparams(m, -n, -g, -e, -q, -cc, 0 if local else 1))
+    G, _, _ = O.block_run(seqs, c.weights, engine_params(m, n, g, e, q, cc, local, abpoa))
     return G.msa(add_consensus), len(G.consensus())
 
 
@@ -646,11 +662,12 @@ def block_scores(g, ranges, adaptive, k, max_depth, m=1, n=4, g_=6, e=2, q=26, c
     return sc
 
 
-def smooth(g, blocks, add_consensus=False, consensus_base="Consensus_", fraction=0.001, max_depth=1000, adaptive=False,
-           kmer_size=17, merge=None, **scores):
+def smooth(graph, blocks, add_consensus=False, consensus_base="Consensus_", fraction=0.001, max_depth=1000, adaptive=False,
+           kmer_size=17, merge=None, abpoa=False, **scores):
     """One smoothing iteration (src/main.cpp:599-1061 around the per-block POA) -> GFA text.
     merge: dict(merge_blocks, jaccard, preserve_unmerged, max_groups, header) -> runs the in-order MAF consumer as
-    well (block merging, flips) and returns (GFA text, MAF text, flipped blocks)."""
+    well (block merging, flips) and returns (GFA text, MAF text, flipped blocks).  scores: m, n, g, e, q, cc (CLI values), local."""
+    g = graph
     cols = [collect(g, b, fraction, max_depth) for b in blocks]
     graphs, mapping = [], []
     block_mafs, groom = [], []
@@ -661,19 +678,20 @@ def smooth(g, blocks, add_consensus=False, consensus_base="Consensus_", fraction
         if adaptive:
             local = scores.get("local", True)
             base = {kk: vv for kk, vv in scores.items() if kk != "local"}
+            # (the tier table is applied to the CLI values, then converted: src/smooth.cpp:2028-2090)
             m_, n_, g__, e_, q_, c_ = block_scores(g, blocks[k], True, kmer_size, max_depth, base.get("m", 1), base.get("n", 4),
                                                    base.get("g", 6), base.get("e", 2), base.get("q", 26), base.get("cc", 1))
-            code, paths, cons = poa(c, m_, n_, g__, e_, q_, c_, local)
+            code, paths, cons = poa(c, m_, n_, g__, e_, q_, c_, local, abpoa)
         else:
-            code, paths, cons = poa(c, **scores)
+            code, paths, cons = poa(c, abpoa=abpoa, **scores)
         cname = (consensus_base + str(k)) if add_consensus else ""
-        G = build_block_graph(c, code, paths, cons, cname)
+        G = build_block_graph(c, code, paths, cons, cname, abpoa)
         graphs.append(G)
         if merge is not None:
             if adaptive:
-                msa, _ = poa_msa(c, add_consensus, m_, n_, g__, e_, q_, c_, local)
+                msa, _ = poa_msa(c, add_consensus, m_, n_, g__, e_, q_, c_, local, abpoa)
             else:
-                msa, _ = poa_msa(c, add_consensus, **scores)
+                msa, _ = poa_msa(c, add_consensus, abpoa=abpoa, **scores)
             while len(block_mafs) < k:
                 block_mafs.append(None)
                 groom.append(False)

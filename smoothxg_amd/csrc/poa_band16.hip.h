@@ -21,6 +21,13 @@
 //     to change (their strips may enter the next row's band) and kept out of the gap scan, the hand-over, the
 //     end-cell search and the stores.
 // Local alignment only (decree B3); a global alignment asked to be banded runs the full sweep.
+//
+// ADAPTIVE band (params.banded = 2, decree B4 -- abPOA's rule): the band of a row follows the columns of the greatest H of
+// its predecessor rows and the node's distance to the end of the graph.  Everything it depends on belongs to EARLIER rows,
+// so it is still known before the row starts and the one-wave window applies unchanged: a finished row leaves its band
+// (strips) and its leftmost / rightmost best column in words 6 and 7 of its descriptor (16 bits each), the previous row's
+// stay in scalar registers, a stored predecessor's come back with one 8-byte load issued before its cells are fetched.
+// Per row this adds a wave-wide maximum, two ballots and a scalar search of one lane's columns.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "poa_dp16.hip.h"
@@ -75,6 +82,29 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
     const int prio_rank = __builtin_amdgcn_readfirstlane(B.prio_rank);
     constexpr int NL = (W + 1) / 2;
     typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+    // adaptive band (B4): per-row records {band word = first | last strip << 16, best-cell word = leftmost | rightmost column << 16}
+    // in words 6, 7 of the row descriptors, written and read with vector instructions only (this wave wrote them)
+    const bool ada = __builtin_amdgcn_readfirstlane(B.band_mode) == 2;
+    // (device-scope accesses, sc1: the descriptor lines were read into the CU's vector L1 when their chunk was staged, and a
+    // later store does not refresh that copy -- a plain load of the record would still see the staged words)
+    constexpr int REC_AUX = 0x10;
+    const __amdgpu_buffer_rsrc_t rs_meta = p16_rsrc((const void*)g_meta, N * 32);
+    int prev_bw = 0, prev_lr = 0;   // record of row i-1
+    auto load_rec = [&](const int p) -> u32x2 {   // record of a stored row p >= 1 (uniform address: one request for the wave)
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_meta, 0u, (p - 1) * 32 + 24, REC_AUX);
+        return u32x2{(unsigned)__builtin_amdgcn_readfirstlane((int)v.x), (unsigned)__builtin_amdgcn_readfirstlane((int)v.y)};
+    };
+    auto ada_band = [&](const int p_l, const int p_r, const int rem, int& bl_, int& bh_) {
+        const int c_ = L - rem;
+        const int b0 = max(min(p_l, c_) - bw, 0), e0 = min(max(p_r, c_) + bw, L);
+        int sb = b0 / W, se = e0 / W;
+        if (se - sb + 1 > BAND_WIN) {   // (the ambiguous first rows of a local alignment: keep the window's worth around c)
+            const int sc = min(max(c_, 0), L) / W;
+            sb = max(sb, min(sc - BAND_WIN / 2, se - (BAND_WIN - 1)));
+            se = sb + BAND_WIN - 1;
+        }
+        bl_ = sb; bh_ = se;
+    };
 
     int s0 = -1000000;          // window origin (strip); far away: the first row re-centres
     unsigned let[NL];           // letters of my two strips, one byte per (strip, column): (lo_k+1, lo_k, hi_k+1, hi_k)
@@ -115,7 +145,32 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         const unsigned SC_T0 = SC_N4 ^ (code < 4 ? SC_MX << (8 * code) : 0u), SC_T1 = SC_N4 ^ (code == 4 ? SC_MX : 0u);
 
         int bl, bh;
-        band_strips_of(hint, bw, W, last_strip, bl, bh);
+        int hp0 = h0, hp1 = h1;     // what BAND_FETCH needs of predecessors #0, #1: their hint (B2) or their band word (B4)
+        int my_pl = 0, my_pr = 0;   // B4: P_l, P_r of this row (a sibling successor has the same)
+        if (!ada) band_strips_of(hint, bw, W, last_strip, bl, bh);
+        else {
+            const bool st0 = p0 >= 1 && p0 != i - 1, st1 = np >= 2 && p1 >= 1 && p1 != i - 1;
+            u32x2 r0 = u32x2{0u, 0u}, r1 = u32x2{0u, 0u};
+            if (st0 && st1) {   // (both loads in flight together)
+                const u32x2 v0 = __builtin_amdgcn_raw_buffer_load_b64(rs_meta, 0u, (p0 - 1) * 32 + 24, REC_AUX);
+                const u32x2 v1 = __builtin_amdgcn_raw_buffer_load_b64(rs_meta, 0u, (p1 - 1) * 32 + 24, REC_AUX);
+                r0 = u32x2{(unsigned)__builtin_amdgcn_readfirstlane((int)v0.x), (unsigned)__builtin_amdgcn_readfirstlane((int)v0.y)};
+                r1 = u32x2{(unsigned)__builtin_amdgcn_readfirstlane((int)v1.x), (unsigned)__builtin_amdgcn_readfirstlane((int)v1.y)};
+            } else if (st0) r0 = load_rec(p0);
+            else if (st1) r1 = load_rec(p1);
+            if (p0 == i - 1 && p0 >= 1) r0 = u32x2{(unsigned)prev_bw, (unsigned)prev_lr};
+            if (np >= 2 && p1 == i - 1) r1 = u32x2{(unsigned)prev_bw, (unsigned)prev_lr};
+            int p_l = (int)(r0.y & 0xffffu) + 1, p_r = (int)(r0.y >> 16) + 1;   // (np = 0: the virtual row, ml = mr = 0)
+            if (np >= 2) { p_l = min(p_l, (int)(r1.y & 0xffffu) + 1); p_r = max(p_r, (int)(r1.y >> 16) + 1); }
+            for (int x = 2; x < np; ++x) {
+                const int p = __builtin_amdgcn_readfirstlane(g_preds[pb + x]);
+                const u32x2 rx = p == i - 1 ? u32x2{(unsigned)prev_bw, (unsigned)prev_lr} : (p >= 1 ? load_rec(p) : u32x2{0u, 0u});
+                p_l = min(p_l, (int)(rx.y & 0xffffu) + 1); p_r = max(p_r, (int)(rx.y >> 16) + 1);
+            }
+            ada_band(p_l, p_r, hint, bl, bh);
+            hp0 = (int)r0.x; hp1 = (int)r1.x;
+            my_pl = p_l; my_pr = p_r;
+        }
         if (bh >= bl) cells += (unsigned long long)(min(L, bh * W + W - 1) - bl * W + 1);
         if (bh >= bl && (bl < s0 || bh >= s0 + BAND_WIN)) {
             // re-centre the window on this band; registers of the previous row no longer line up with it
@@ -151,7 +206,8 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             hl_ = pk2(st_lo == 0 ? NEGP : 0, 0);                                                            \
         } else {                                                                                            \
             int fl_, fh_;                                                                                   \
-            band_strips_of(hp_, bw, W, last_strip, fl_, fh_);                                                  \
+            if (ada) { fl_ = (hp_) & 0xffff; fh_ = (int)((unsigned)(hp_) >> 16); }                          \
+            else band_strips_of(hp_, bw, W, last_strip, fl_, fh_);                                          \
             const __amdgpu_buffer_rsrc_t rs_ = p16_rsrc((const void*)(g_tb + (size_t)(p_) * (size_t)(W * BS)), W * BS * 4); \
             const bool a_ = st_lo >= fl_ && st_lo <= fh_, b_ = st_hi >= fl_ && st_hi <= fh_;                 \
             const bool la_ = st_lo - 1 >= fl_ && st_lo - 1 <= fh_, lb_ = st_hi - 1 >= fl_ && st_hi - 1 <= fh_; \
@@ -184,7 +240,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         } else if (sib) {
             u32x2 wr[W];
             int hl;
-            BAND_FETCH(p0, h0, wr, hl);
+            BAND_FETCH(p0, hp0, wr, hl);
             Hc[0] = hl;
 #pragma unroll
             for (int k = 1; k < W; ++k) Hc[k] = (int)wr[k - 1].x;
@@ -199,11 +255,12 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             const int hleft_reg = Hleft;
             for (int x = 0; x < max(np, 1); ++x) {
                 int p, hp;
-                if (x == 0) { p = p0; hp = h0; }
-                else if (x == 1) { p = p1; hp = h1; }
+                if (x == 0) { p = p0; hp = hp0; }
+                else if (x == 1) { p = p1; hp = hp1; }
                 else {
                     p = __builtin_amdgcn_readfirstlane(g_preds[pb + x]);
-                    hp = p >= 1 ? __builtin_amdgcn_readfirstlane(g_hint[p - 1]) : 0;
+                    if (ada) hp = p == i - 1 ? prev_bw : (p >= 1 ? (int)load_rec(p).x : 0);
+                    else hp = p >= 1 ? __builtin_amdgcn_readfirstlane(g_hint[p - 1]) : 0;
                 }
                 u32x2 wr[W];
                 int hl;
@@ -306,6 +363,49 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
                 if (ih) bj_hi = st_hi * W + bk_hi;
             }
         }
+        // ---- B4: leftmost / rightmost column of the band that holds the row's greatest H; the row's record
+        int ml_ = 0, mr_ = 0;
+        if (ada) {
+            int rmx = rowmax;
+            if (bh == last_strip) {   // the strip of column L also has columns beyond L: not cells, and they may hold more than any cell
+                const int kL = L - last_strip * W;
+                int rv = 0;
+#pragma unroll
+                for (int k = 0; k < W; ++k) if (k <= kL) rv = pk_max(rv, Hc[k]);
+                rv &= m2;
+                if (st_lo == last_strip) rmx = (int)(((unsigned)rmx & 0xffff0000u) | ((unsigned)rv & 0x0000ffffu));
+                if (st_hi == last_strip) rmx = (int)(((unsigned)rmx & 0x0000ffffu) | ((unsigned)rv & 0xffff0000u));
+            }
+            const int M = __builtin_amdgcn_readlane(sxg_wave_incl_max(max(pk_lo(rmx), pk_hi(rmx))), 63);
+            const unsigned long long mk_lo = __ballot(in_lo && pk_lo(rmx) == M), mk_hi = __ballot(in_hi && pk_hi(rmx) == M);
+            // lo strips (origin + lane) come before hi strips (origin + 64 + lane)
+            const bool l_hi = mk_lo == 0ull, r_hi = mk_hi != 0ull;
+            const int l_ln = (int)__builtin_ctzll(l_hi ? mk_hi : mk_lo), r_ln = 63 - (int)__builtin_clzll(r_hi ? mk_hi : mk_lo);
+            const int l_strip = s0 + l_ln + (l_hi ? 64 : 0), r_strip = s0 + r_ln + (r_hi ? 64 : 0);
+            const int l_kmax = L - l_strip * W, r_kmax = L - r_strip * W;
+            int kf = 0, kl = 0;
+#pragma unroll
+            for (int k = W - 1; k >= 0; --k) {
+                const int v = __builtin_amdgcn_readlane(Hc[k], l_ln);
+                if ((l_hi ? pk_hi(v) : pk_lo(v)) == M && k <= l_kmax) kf = k;
+            }
+            if (l_ln == r_ln && l_hi == r_hi) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const int v = __builtin_amdgcn_readlane(Hc[k], l_ln);
+                    if ((l_hi ? pk_hi(v) : pk_lo(v)) == M && k <= l_kmax) kl = k;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const int v = __builtin_amdgcn_readlane(Hc[k], r_ln);
+                    if ((r_hi ? pk_hi(v) : pk_lo(v)) == M && k <= r_kmax) kl = k;
+                }
+            }
+            ml_ = l_strip * W + kf; mr_ = r_strip * W + kl;
+            prev_bw = bl | (bh << 16); prev_lr = ml_ | (mr_ << 16);
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)prev_bw, (unsigned)prev_lr}, rs_meta, 0u, (i - 1) * 32 + 24, REC_AUX);
+        }
         // ---- outgoing candidates, band store.  A sibling successor keeps my own F/O instead.
         next_sib = false;
         int nbl = -1, nbh = -2;    // the next row's band (unknown at a descriptor-chunk edge)
@@ -313,7 +413,10 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             const i32x4 n0 = lmeta[2 * (i & (CH - 1))], n1 = lmeta[2 * (i & (CH - 1)) + 1];
             const int nnp = __builtin_amdgcn_readfirstlane(n0.y) & 0xffff, np0 = __builtin_amdgcn_readfirstlane(n0.z);
             next_sib = np <= 1 && nnp <= 1 && np0 == p0 && np0 != i;
-            band_strips_of(__builtin_amdgcn_readfirstlane(n1.w), bw, W, last_strip, nbl, nbh);
+            const int nhint = __builtin_amdgcn_readfirstlane(n1.w);
+            if (!ada) band_strips_of(nhint, bw, W, last_strip, nbl, nbh);
+            else if (nnp <= 1 && np0 == i) ada_band(ml_ + 1, mr_ + 1, nhint, nbl, nbh);   // (my register successor)
+            else if (next_sib) ada_band(my_pl, my_pr, nhint, nbl, nbh);                   // (same single predecessor as mine)
         }
         const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
 #define BAND_STORE(CF, CO)                                                                                  \

@@ -173,6 +173,7 @@ struct DpBuffers {
     int band_strips;   // packed sweep: strips per row kept in the traceback plane (see poa_dp16.hip.h)
     int lds_rows;      // packed sweep: on-chip copies of stored rows the workgroup's LDS holds (RowCaps::lds_rows)
     int band_w;        // banded sweep (poa_band16.hip.h): half-width of the band in columns, wb + (int)(wf * L)
+    int band_mode;     // banded sweep: params.banded -- 1 = band around the backbone coordinate (B2), 2 = adaptive band (B4)
     int prio_rank;     // launch rank of this workgroup among its CU's co-residents (see sxg_rotate_prio)
     uint32_t* prio_board;          // this CU's progress board (PRIO_BOARD_SLOTS words) or nullptr
     unsigned long long prio_rem0;  // estimated cells this workgroup still has to do, at row 0 of this sweep

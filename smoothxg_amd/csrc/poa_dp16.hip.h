@@ -659,9 +659,15 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     const int bias = (!BANDED && sw) ? P16_BIAS : 0;
     const int BS = __builtin_amdgcn_readfirstlane(B.band_strips);
     const int bw = __builtin_amdgcn_readfirstlane(B.band_w), last_strip = L / W;
+    // adaptive band (B4): the sweep left every row's band -- first | last strip << 16 -- in word 6 of its descriptor
+    const bool ada = BANDED && __builtin_amdgcn_readfirstlane(B.band_mode) == 2;
+    const int HW = ada ? 6 : 7;   // descriptor word that says which strips the row kept
     // is strip s of a row with band hint `hint` kept in the plane?
     auto kept = [&](int hint, int s) -> bool {
-        if (BANDED) return s >= max(hint - bw, 0) / W && s <= min((hint + bw) / W, last_strip);
+        if (BANDED) {
+            if (ada) return s >= (hint & 0xffff) && s <= (int)((unsigned)hint >> 16);
+            return s >= max(hint - bw, 0) / W && s <= min((hint + bw) / W, last_strip);
+        }
         return (unsigned)(s - band_first_strip(hint, W, BS, T)) < (unsigned)BS;
     };
     // outputs and letters through global pointers: a FLAT store also counts on lgkmcnt, and the walk
@@ -704,7 +710,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     int miss_row = 0, miss_delta = 0;
     // plane cell (row p >= 1, column col) straight from HBM; a cell outside the row's band is a miss
     auto gcell = [&](int p, int col) -> uint32_t {
-        const int hint = (int)TBU(g_meta[8 * (size_t)(p - 1) + 7]);
+        const int hint = (int)TBU(g_meta[8 * (size_t)(p - 1) + HW]);
         const int s = col / W, k = col - s * W;
         if (!kept(hint, s)) {
             if (BANDED) return 0x0000C000u;   // (NEGCELL: H = -inf)
@@ -768,7 +774,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                     for (int x2 = 0; x2 < TBW_COLS; ++x2) {
                         const int col = c0 + x2;
                         if (col >= 0 && col <= L) {
-                            if (kept(d1.w, col / W)) valid |= 1u << x2;
+                            if (kept(ada ? d1.z : d1.w, col / W)) valid |= 1u << x2;
                             else if (BANDED) { v[x2] = 0x0000C000u; valid |= 1u << x2; }
                         }
                     }
@@ -909,7 +915,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             if (!done && !miss) {
                 // a gap in the graph.  E: smallest k with H[i][j-k] + g + (k-1) e == hv (k <= kmax_e), else Q
                 // likewise with q, c; 64 columns per round trip, straight from the plane.
-                const int hint = (int)TBU(g_meta[8 * (size_t)(i - 1) + 7]);
+                const int hint = (int)TBU(g_meta[8 * (size_t)(i - 1) + HW]);
                 int kk = 0, hnew = 0;
                 for (int piece = 0; piece < (CVX ? 2 : 1) && !kk && !miss; ++piece) {
                     const int go = piece ? q : g, ge = piece ? c : e;

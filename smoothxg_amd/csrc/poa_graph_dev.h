@@ -285,7 +285,9 @@ struct RowCaps {
 // the step-mask plane offset of multi-pred rows.  Returns a status (same on every thread).
 // `hinted`: 1 = packed sweep -- R.tbx already holds the band hint of every row and there is no step-mask plane;
 // 2 = banded sweep -- additionally there is no row ring (every row keeps its band in the plane) and the descriptor
-// carries the hints of the first two predecessors where the ring slots would be.
+// carries the hints of the first two predecessors where the ring slots would be;
+// 3 = banded sweep with the ADAPTIVE band (decree B4) -- R.tbx holds remain() of every row; the bands follow from the
+// sweep itself, which leaves every finished row's band and best-cell columns in words 6 and 7 of its descriptor.
 template <class Ctx>
 SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps, const int hinted = 0) {
     const int T = c.nthreads(), t = c.tid();
@@ -322,7 +324,7 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
         }
     }
     worst = c.reduce_max(worst);
-    if (worst > caps.pool_slots && hinted != 2) return ST_POOL_OVERFLOW;
+    if (worst > caps.pool_slots && hinted < 2) return ST_POOL_OVERFLOW;
     if (!hinted) {
         // multi-pred rows: np-1 fold steps each in the step-mask plane
         const int n_steps = array_excl_sum(c, N, [&](int r) {
@@ -353,7 +355,8 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             const int r = r0 + u * T;
-            if (hinted == 2) {
+            if (hinted == 3) { q0[u] = 0; q1[u] = 0; }
+            else if (hinted == 2) {
                 q0[u] = p0[u] >= 1 ? R.tbx[p0[u] - 1] : 0;
                 q1[u] = p1[u] >= 1 ? R.tbx[p1[u] - 1] : 0;
             } else {
@@ -371,6 +374,64 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
     }
     c.sync();
     return ST_OK;
+}
+
+// Decree B4: remain() of the node of every rank -- the number of edges of the walk that follows, from node to node, the
+// heaviest out-edge (the first of greatest weight in out-list order) down to a node without out-edges.  A chain over
+// ranks when done serially; here: every rank points to the rank of its heaviest successor, and pointer jumping doubles
+// the distance covered per round (ceil(log2 N) rounds of N / T steps each; two pairs of scratch arrays -- free between
+// two add_alignment calls -- are read and written alternately, so a round never reads what it writes).
+template <class Ctx>
+SXG_HD_PHASE void rows_remain(Ctx& c, const GraphView& G, int N, SXG_GP int32_t* out) {
+    const int T = c.nthreads(), t = c.tid();
+    SXG_GP int32_t* nx[2] = {G.preva, G.newidx};
+    SXG_GP int32_t* ds[2] = {G.nexta, G.target};
+    c.sync();
+    constexpr int GB = 4;
+    for (int r0 = t; r0 < N; r0 += GB * T) {
+        int e[GB], best[GB];
+        uint32_t bw[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) { e[u] = r0 + u * T < N ? G.out_head[G.order[r0 + u * T]] : -1; best[u] = -1; bw[u] = 0; }
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+            for (int x = e[u]; x >= 0; x = G.e_next_out[x]) {
+                const uint32_t w = G.e_w[x];
+                if (best[u] < 0 || w > bw[u]) { best[u] = G.e_head[x]; bw[u] = w; }
+            }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int r = r0 + u * T;
+            if (r >= N) continue;
+            nx[0][r] = best[u] >= 0 ? G.rank[best[u]] : -1;
+            ds[0][r] = best[u] >= 0 ? 1 : 0;
+        }
+    }
+    c.sync();
+    int cur = 0;
+    for (int round = 0; round < 32; ++round) {
+        int open = 0;
+        for (int r0 = t; r0 < N; r0 += GB * T) {
+            int n1[GB], d1[GB], n2[GB], d2[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) { const int r = r0 + u * T; n1[u] = r < N ? nx[cur][r] : -1; d1[u] = r < N ? ds[cur][r] : 0; }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) { n2[u] = n1[u] >= 0 ? nx[cur][n1[u]] : -1; d2[u] = n1[u] >= 0 ? ds[cur][n1[u]] : 0; }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int r = r0 + u * T;
+                if (r >= N) continue;
+                nx[cur ^ 1][r] = n2[u];
+                ds[cur ^ 1][r] = d1[u] + d2[u];
+                open |= (int)(n2[u] >= 0);
+            }
+        }
+        cur ^= 1;
+        open = c.reduce_max(open);   // (also the barrier between the rounds)
+        if (!open) break;
+    }
+    for (int r = t; r < N; r += T) out[r] = ds[cur][r];
+    c.sync();
 }
 
 // Rank-space CSR + per-row DP metadata of the current graph.  Returns a status code
@@ -396,9 +457,10 @@ SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const 
             if (r >= N) continue;
             R.row_node[r] = v[u];
             R.code[r] = (uint8_t)cd[u];
-            if (hinted) R.tbx[r] = xp[u];
+            if (hinted && hinted != 3) R.tbx[r] = xp[u];
         }
     }
+    if (hinted == 3) rows_remain(c, G, N, R.tbx);
     const int E = array_excl_sum(c, N, [&](int r) { return G.in_deg[G.order[r]]; }, R.pred_off);
     if (t == 0) R.pred_off[N] = E;
     c.sync();

@@ -226,7 +226,8 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             }
             if (N > 0 && len > 0) {
                 PROF(0);
-                status = prep_rows(ctx, V.G, V.R, caps, RM == 3 ? 2 : (RM == 2 ? 1 : 0));
+                const int band_mode = RM == 3 ? (int)A.params[A.per_block_params ? b : 0].banded : 0;   // 1 = B2, 2 = adaptive (B4)
+                status = prep_rows(ctx, V.G, V.R, caps, RM == 3 ? (band_mode == 2 ? 3 : 2) : (RM == 2 ? 1 : 0));
                 if (status != ST_OK) break;
                 PROF(1);
                 DpResult res;
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     // banded sweep (decrees B1-B3): one wave, the band slides with the rows; out-of-band cells do not
                     // exist, so the traceback cannot leave the kept cells
                     V.B.band_w = band_half_width(len);
+                    V.B.band_mode = band_mode;
                     res = dp_fill_band16<CVX, W>(S, V.R, N, seq, len, V.B, smem, A.cells + s);
                     __syncthreads();
                     PROF(2);
@@ -643,6 +645,14 @@ struct sxg_poa_handle {
     bool own_comm = false;
     int nranks = 1, rank = 0;
     DevBuf d_blob, d_recv, d_counts;
+    // staged sharded run: the deal of the last sxg_poa_batch_upload_sharded, the counts every rank announced in the last
+    // sxg_poa_batch_execute_sharded and where the root put their blobs
+    std::vector<std::vector<int32_t>> sh_parts;
+    std::vector<int64_t> sh_counts;
+    std::vector<size_t> sh_at;
+    bool sh_dealt = false, sh_exchanged = false;
+    uint64_t sh_bytes_received = 0;
+    int sh_ranks_seen = 0;
 };
 
 extern "C" int sxg_poa_abi_version(void) { return SXG_POA_ABI_VERSION; }
@@ -747,7 +757,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     const int np = in->per_block_params ? nb : 1;
     for (int k = 0; k < np && nb > 0; ++k) {
         const sxg_poa_params& p = in->params[k];
-        if (p.m < 0 || p.n > 0 || p.g > 0 || p.e > 0 || p.q > 0 || p.c > 0 || p.mode > 1 || p.banded > 1)
+        if (p.m < 0 || p.n > 0 || p.g > 0 || p.e > 0 || p.q > 0 || p.c > 0 || p.mode > 1 || p.banded > 2)
             return fail(SXG_E_INVALID, "scores must follow spoa's sign convention (m>=0, others <=0), mode 0|1");
     }
     h->n_blocks = nb; h->n_seqs = ns; h->n_bases = nbases;
@@ -824,6 +834,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     if (h->want_consensus && (rc = h->d_cons.ensure(4 * NB))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_batch = true;
+    h->sh_dealt = false; h->sh_exchanged = false;   // (a plain upload: no deal the root could reassemble by)
     return SXG_OK;
 }
 
@@ -851,10 +862,12 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     const Variant V = P.variant;
     const int Lpad = V.Lpad();
     int nodes_cap = 0, maxlen = 0;
+    bool any_adaptive = false;   // banded blocks with the adaptive band (B4): a row's band may span the whole 128-strip window
     double rows_est = 0;  // graph rows a block is expected to reach: every further sequence adds ~1.5 % of its
                           // length in new nodes on pangenome-like input (measured on the synthetic blocks: 1.43 %)
     for (int b : P.work) {
         const BlockMeta& m = h->meta[b];
+        any_adaptive = any_adaptive || h->h_params[h->per_block_params ? b : 0].banded == 2;
         nodes_cap = (int)std::max<int64_t>(nodes_cap, m.sumlen);
         maxlen = std::max(maxlen, m.maxlen);
         rows_est = std::max(rows_est, (double)m.maxlen * std::max(2.0, 1.0 + 0.0165 * m.nseq));
@@ -885,7 +898,7 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     const int wb = V.RM == 1 ? 8 : 4;
     if (V.RM == 3) pool_slots = 1;   // (the banded sweep has no row ring: predecessors come from the plane)
     P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false,
-                        V.RM == 3 ? band_plane_strips(maxlen, V.W) : (V.RM == 2 ? (P.wide_band ? 2 * V.T() : plane_strips_p16(V.T(), V.W)) : 0));
+                        V.RM == 3 ? (any_adaptive ? BAND_WIN : band_plane_strips(maxlen, V.W)) : (V.RM == 2 ? (P.wide_band ? 2 * V.T() : plane_strips_p16(V.T(), V.W)) : 0));
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
@@ -1774,20 +1787,43 @@ static int check_batch(const sxg_poa_batch_in* in) {
     return SXG_OK;
 }
 
-extern "C" int sxg_poa_batch_run_sharded(sxg_poa_handle* h, const sxg_poa_batch_in* in, sxg_poa_batch_out* out) {
-    if (!h || !in || !out) return fail(SXG_E_INVALID, "NULL argument");
-    memset(out, 0, sizeof(*out));
+// The sharded run in three stages, like upload / execute / download of the single-GPU call:
+//   sxg_poa_batch_upload_sharded   deals the blocks of the SAME batch on every rank (LPT) and uploads this rank's share;
+//   sxg_poa_batch_execute_sharded  aligns the uploaded share (whatever uploaded it: the deal above, or a plain
+//                                  sxg_poa_batch_upload of a share the caller cut himself), packs the results into one
+//                                  device blob and brings every blob to rank 0 -- the collective part;
+//   sxg_poa_batch_download_sharded rank 0: results of all ranks in the batch's block order; others: SXG_NOT_ROOT.
+extern "C" int sxg_poa_batch_upload_sharded(sxg_poa_handle* h, const sxg_poa_batch_in* in) {
+    if (!h || !in) return fail(SXG_E_INVALID, "NULL argument");
     int rc = check_batch(in);
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
     const int nranks = h->comm ? h->nranks : 1, rank = h->comm ? h->rank : 0;
-    std::vector<std::vector<int32_t>> parts;
-    lpt_partition(in, nranks, parts);
-    std::vector<int64_t> counts((size_t)nranks * BC_N, 0);
+    lpt_partition(in, nranks, h->sh_parts);
+    h->sh_dealt = false; h->sh_exchanged = false;
+    LocalBatch L;
+    build_local(in, h->sh_parts[rank], L);
+    if ((rc = sxg_poa_batch_upload(h, &L.in))) return rc;
+    h->sh_dealt = true;
+    return SXG_OK;
+}
+
+extern "C" int sxg_poa_batch_execute_sharded(sxg_poa_handle* h) {
+    if (!h) return fail(SXG_E_INVALID, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    const int nranks = h->comm ? h->nranks : 1, rank = h->comm ? h->rank : 0;
+    h->sh_exchanged = false; h->sh_bytes_received = 0; h->sh_ranks_seen = 0;
+    std::vector<int64_t>& counts = h->sh_counts;
+    counts.assign((size_t)nranks * BC_N, 0);
     int64_t* mine = counts.data() + (size_t)rank * BC_N;
-    rc = run_shard(h, in, parts[rank], mine);
-    if (nranks == 1 && rc) return rc;
-    if (nranks > 1) {
+    int rc = h->have_batch ? sxg_poa_batch_execute(h) : fail(SXG_E_INVALID, "no batch uploaded");
+    if (!rc || rc == SXG_E_BLOCK) rc = pack_blob(h, mine);   // (per-block failures travel in the status array)
+    if (!h->comm) {
+        if (rc) return rc;
+        h->sh_at.assign(2, 0); h->sh_exchanged = true; h->sh_ranks_seen = 1;
+        return SXG_OK;
+    }
+    {   // (a communicator of ONE rank takes the same way: the collectives run, nothing is sent)
         // A rank-local failure (allocation, HIP error) must not leave the peers blocked in a collective: the failing rank
         // still takes part in the size exchange, with its error code in BC_PAD and nothing to send, and EVERY rank then
         // returns that failure -- the ranks fail together.  (d_counts is allocated by sxg_poa_comm_init / _attach.)
@@ -1805,14 +1841,16 @@ extern "C" int sxg_poa_batch_run_sharded(sxg_poa_handle* h, const sxg_poa_batch_
             return SXG_OK;
         };
         // sizes first (RCCL has no all-gather-v) ...
-        HIPCHK(hipMemcpyAsync(dc + (size_t)nranks * BC_N, mine, 8 * BC_N, hipMemcpyHostToDevice, h->stream));
+        std::vector<int64_t> my_counts(mine, mine + BC_N);
+        HIPCHK(hipMemcpyAsync(dc + (size_t)nranks * BC_N, my_counts.data(), 8 * BC_N, hipMemcpyHostToDevice, h->stream));
         NCCLCHK(ncclAllGather(dc + (size_t)nranks * BC_N, dc, BC_N, ncclInt64, h->comm, h->stream));
         HIPCHK(hipMemcpyAsync(counts.data(), dc, 8 * (size_t)BC_N * nranks, hipMemcpyDeviceToHost, h->stream));
         if ((rc = comm_wait(h, "size all-gather"))) return rc;
         if ((rc = gathered_failure("while aligning its share"))) return rc;
         // ... the root makes room (the one step after the size exchange that can fail on one rank only: its outcome is
         // all-gathered too, one word per rank, before anybody posts a send) ...
-        std::vector<size_t> at(nranks + 1, 0);
+        std::vector<size_t>& at = h->sh_at;
+        at.assign(nranks + 1, 0);
         for (int r = 1; r < nranks; ++r) at[r + 1] = at[r] + (((size_t)counts[(size_t)r * BC_N + BC_BYTES] + 255) & ~(size_t)255);
         int64_t ready = 0;
         if (rank == 0 && (rc = h->d_recv.ensure(at[nranks] + 256))) { ready = rc; local_err = sxg_poa_last_error(); }
@@ -1838,23 +1876,54 @@ extern "C" int sxg_poa_batch_run_sharded(sxg_poa_handle* h, const sxg_poa_batch_
         }
         if (gr != ncclSuccess) { comm_abort(h); return fail(SXG_E_NODEVICE, std::string("blob exchange: ") + ncclGetErrorString(gr)); }
         if ((rc = comm_wait(h, "blob exchange"))) return rc;
-        if (rank != 0) return SXG_NOT_ROOT;
-        std::vector<std::vector<uint8_t>> blobs(nranks);
         for (int r = 0; r < nranks; ++r) {
-            const size_t bytes = (size_t)counts[(size_t)r * BC_N + BC_BYTES];
-            blobs[r].resize(std::max<size_t>(bytes, 16));
-            if (bytes) HIPCHK(hipMemcpy(blobs[r].data(), r == 0 ? h->d_blob.p : (void*)(h->d_recv.as<uint8_t>() + at[r]), bytes, hipMemcpyDeviceToHost));
+            h->sh_ranks_seen += 1;   // (every rank's counts arrived; a rank with an empty share sends nothing)
+            if (r != 0 && rank == 0) h->sh_bytes_received += (uint64_t)counts[(size_t)r * BC_N + BC_BYTES];
         }
-        rc = assemble(in, parts, blobs, counts, out);
-    } else {
-        std::vector<std::vector<uint8_t>> blobs(1);
-        const size_t bytes = (size_t)counts[BC_BYTES];
-        blobs[0].resize(std::max<size_t>(bytes, 16));
-        if (bytes) HIPCHK(hipMemcpy(blobs[0].data(), h->d_blob.p, bytes, hipMemcpyDeviceToHost));
-        rc = assemble(in, parts, blobs, counts, out);
     }
+    h->sh_exchanged = true;
+    return SXG_OK;
+}
+
+extern "C" int sxg_poa_batch_download_sharded(sxg_poa_handle* h, const sxg_poa_batch_in* in, sxg_poa_batch_out* out) {
+    if (!h || !in || !out) return fail(SXG_E_INVALID, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    if (!h->sh_exchanged) return fail(SXG_E_INVALID, "no sharded batch executed");
+    if (!h->sh_dealt) return fail(SXG_E_INVALID, "the batch was not dealt by sxg_poa_batch_upload_sharded: the root cannot know its block order");
+    HIPCHK(hipSetDevice(h->device));
+    const int nranks = h->comm ? h->nranks : 1, rank = h->comm ? h->rank : 0;
+    if (rank != 0) return SXG_NOT_ROOT;
+    if ((int)h->sh_parts.size() != nranks) return fail(SXG_E_INVALID, "communicator changed since the upload");
+    std::vector<std::vector<uint8_t>> blobs(nranks);
+    for (int r = 0; r < nranks; ++r) {
+        const size_t bytes = (size_t)h->sh_counts[(size_t)r * BC_N + BC_BYTES];
+        blobs[r].resize(std::max<size_t>(bytes, 16));
+        if (bytes) HIPCHK(hipMemcpy(blobs[r].data(), r == 0 ? h->d_blob.p : (void*)(h->d_recv.as<uint8_t>() + h->sh_at[r]), bytes, hipMemcpyDeviceToHost));
+    }
+    int rc = assemble(in, h->sh_parts, blobs, h->sh_counts, out);
     if (rc && rc != SXG_E_BLOCK) sxg_poa_batch_free(out);
     return rc;
+}
+
+extern "C" int sxg_poa_sharded_info(sxg_poa_handle* h, int32_t* ranks_seen, uint64_t* bytes_received) {
+    if (!h) return fail(SXG_E_INVALID, "handle is NULL");
+    if (ranks_seen) *ranks_seen = h->sh_ranks_seen;
+    if (bytes_received) *bytes_received = h->sh_bytes_received;
+    return SXG_OK;
+}
+
+extern "C" int sxg_poa_batch_run_sharded(sxg_poa_handle* h, const sxg_poa_batch_in* in, sxg_poa_batch_out* out) {
+    if (!h || !in || !out) return fail(SXG_E_INVALID, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    // (an upload that fails on one rank only -- a host or device allocation -- must still reach the collective: the
+    //  execute stage then reports "no batch" as this rank's error and all ranks fail together)
+    const int urc = sxg_poa_batch_upload_sharded(h, in);
+    const std::string uerr = urc ? std::string(sxg_poa_last_error()) : std::string();
+    if (urc && !(h->comm && h->nranks > 1)) return urc;
+    if (urc) h->have_batch = false;
+    int rc = sxg_poa_batch_execute_sharded(h);
+    if (rc) return urc ? fail(urc, uerr) : rc;
+    return sxg_poa_batch_download_sharded(h, in, out);
 }
 
 // TEST ENTRY: the sharded run with `nranks` SIMULATED ranks on this one GPU -- every shard is aligned here, one after

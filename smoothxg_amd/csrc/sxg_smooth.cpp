@@ -585,9 +585,11 @@ std::string to_gfa(const ograph_t& G) {
 }
 
 // A9 + A10 for one block.  poa_* describe the block's POA graph (include/sxg_poa.h, block-local).
+// abpoa: the consensus path keeps only nodes that some sequence path visits (build_odgi_abPOA, src/smooth.cpp:2542-2548;
+// build_odgi_SPOA appends every consensus node, :2624-2627)
 ograph_t build_block_graph(const collected_t& c, const uint8_t* node_code, int64_t n_nodes,
                            const std::vector<const int32_t*>& seq_paths, const int32_t* cons, int64_t n_cons,
-                           const std::string& consensus_name) {
+                           const std::string& consensus_name, const bool abpoa = false) {
     static const char dec[5] = {'A', 'C', 'G', 'T', 'N'};
     ograph_t G;
     // A9 (src/smooth.cpp:2583-2637): one node per POA node; a path per duplicate name, padding steps
@@ -606,7 +608,13 @@ ograph_t build_block_graph(const collected_t& c, const uint8_t* node_code, int64
     if (!consensus_name.empty()) {
         steps_t st;
         st.reserve((size_t)std::max<int64_t>(0, n_cons));
-        for (int64_t k = 0; k < n_cons; ++k) st.push_back(mk((uint64_t)cons[k], false));
+        std::vector<char> visited;
+        if (abpoa) {
+            visited.assign((size_t)n_nodes, 0);
+            for (auto& pth : by_name) for (handle_t h : pth.second) visited[nid(h)] = 1;
+        }
+        for (int64_t k = 0; k < n_cons; ++k)
+            if (!abpoa || visited[(size_t)cons[k]]) st.push_back(mk((uint64_t)cons[k], false));
         by_name.emplace_back(consensus_name, std::move(st));
     }
     // :2639-2653 drop nodes no path visits; A10 :980-994 keeps only path-supported edges, so the
@@ -653,8 +661,23 @@ void add_to_batch(batch_t& B, const collected_t& c) {
 }
 sxg_poa_params poa_params(const sxg_smooth_params& p) {  // src/smooth.cpp:2098-2106
     sxg_poa_params q;
-    q.m = (int8_t)p.poa_m; q.n = (int8_t)-p.poa_n; q.g = (int8_t)-p.poa_g; q.e = (int8_t)-p.poa_e; q.q = (int8_t)-p.poa_q; q.c = (int8_t)-p.poa_c;
     q.mode = p.local_alignment ? SXG_MODE_LOCAL : SXG_MODE_GLOBAL; q.banded = 0;
+    if (!p.use_abpoa) {
+        q.m = (int8_t)p.poa_m; q.n = (int8_t)-p.poa_n; q.g = (int8_t)-p.poa_g; q.e = (int8_t)-p.poa_e; q.q = (int8_t)-p.poa_q; q.c = (int8_t)-p.poa_c;
+        return q;
+    }
+    // smooth_abpoa (src/smooth.cpp:2079-2090, 256-297): abPOA takes the CLI values as they are, a gap of k letters costs
+    // min(o1 + k e1, o2 + k e2); gap_open1 = 0 selects its linear and gap_open2 = 0 its affine model.  The engine's
+    // convention is spoa's -- the first letter of a gap costs g, every further one e -- so g = -(o + e), e = -e.
+    // Banded alignment is always on (:2090), with abPOA's adaptive band.
+    const int o1 = p.poa_g, e1 = p.poa_e, o2 = p.poa_q, e2 = p.poa_c;
+    q.m = (int8_t)p.poa_m; q.n = (int8_t)-p.poa_n;
+    if (o1 == 0) { q.g = q.e = q.q = q.c = (int8_t)-e1; }
+    else {
+        q.g = (int8_t)-(o1 + e1); q.e = (int8_t)-e1;
+        if (o2 == 0) { q.q = q.g; q.c = q.e; } else { q.q = (int8_t)-(o2 + e2); q.c = (int8_t)-e2; }
+    }
+    q.banded = 2;
     return q;
 }
 // ---------------------------------------------------------------------------------------------
@@ -1077,13 +1100,14 @@ std::string cons_name(const sxg_smooth_params& p, int64_t block_id) {
     if (!p.add_consensus) return "";
     return std::string(p.consensus_base_name ? p.consensus_base_name : "Consensus_") + std::to_string(block_id);
 }
-ograph_t block_graph_from_out(const collected_t& c, const batch_t& B, const sxg_poa_batch_out& out, int64_t slot, const std::string& cname) {
+ograph_t block_graph_from_out(const collected_t& c, const batch_t& B, const sxg_poa_batch_out& out, int64_t slot, const std::string& cname,
+                              const bool abpoa = false) {
     std::vector<const int32_t*> sp;
     for (int32_t s = B.blk_off[slot]; s < B.blk_off[slot + 1]; ++s) sp.push_back(out.seq_path_nodes + B.seq_off[s]);
     const int64_t n0 = out.node_off[slot], nn = out.node_off[slot + 1] - n0;
     const int32_t* cons = out.cons_nodes && out.cons_off ? out.cons_nodes + out.cons_off[slot] : nullptr;
     const int64_t nc = out.cons_nodes && out.cons_off ? out.cons_off[slot + 1] - out.cons_off[slot] : 0;
-    return build_block_graph(c, out.node_code + n0, nn, sp, cons, nc, cname);
+    return build_block_graph(c, out.node_code + n0, nn, sp, cons, nc, cname, abpoa);
 }
 char* dup_out(const std::string& s) {
     char* r = (char*)malloc(s.size() + 1);
@@ -1103,6 +1127,7 @@ void sxg_smooth_default_params(sxg_smooth_params* p) {
     p->poa_padding_fraction = 0.001f; p->max_block_depth_for_padding_more = 1000;         // src/main.cpp:293-295
     p->add_consensus = 0; p->consensus_base_name = "Consensus_";
     p->adaptive_poa_params = 0; p->kmer_size = 17;                                        // src/main.cpp:111,304
+    p->use_abpoa = 0;                                                                    // src/main.cpp:130-132
 }
 
 void sxg_adaptive_poa_scores(float thr, const int32_t set_scores[6], int32_t out_scores[6]) { adaptive_scores(thr, set_scores, out_scores); }
@@ -1241,7 +1266,7 @@ int sxg_block_graph_gfa(const sxg_graph* g, const sxg_blockset* b, int64_t block
     memset(&out, 0, sizeof(out));
     const int rc = run(ctx, &in, &out);
     if (rc != SXG_OK) { if (fre) fre(&out); return fail(rc, "POA provider failed"); }
-    const ograph_t G = block_graph_from_out(c, B, out, 0, cons_name(*p, block_id));
+    const ograph_t G = block_graph_from_out(c, B, out, 0, cons_name(*p, block_id), p->use_abpoa != 0);
     if (fre) fre(&out);
     *out_gfa = dup_out(to_gfa(G));
     return SXG_OK;
@@ -1397,7 +1422,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t k = 0; k < nb; ++k) {
         if (col[(size_t)k].seqs.empty()) continue;
-        graphs[(size_t)k] = block_graph_from_out(col[(size_t)k], B, out, k, cons_name(*p, k));
+        graphs[(size_t)k] = block_graph_from_out(col[(size_t)k], B, out, k, cons_name(*p, k), p->use_abpoa != 0);
         if (mp) {   // MSA -> MAF rows of the block (src/smooth.cpp:782-905), and its grooming orientation (:1826-1842)
             const collected_t& c = col[(size_t)k];
             const size_t nrow = c.seqs.size() + (p->add_consensus ? 1 : 0), cols = (size_t)out.msa_cols[k];

@@ -77,7 +77,8 @@ EXPORTS = ["sxg_poa_batch_device_view", "sxg_poa_abi_version", "sxg_poa_device_c
            "sxg_poa_destroy", "sxg_poa_batch_run", "sxg_poa_batch_upload", "sxg_poa_batch_execute",
            "sxg_poa_batch_download", "sxg_poa_batch_free", "sxg_poa_align_batch", "sxg_poa_align_free",
            "sxg_poa_get_stats", "sxg_poa_set_memory_budget", "sxg_xxh64", "sxg_poa_comm_unique_id", "sxg_poa_comm_init",
-           "sxg_poa_comm_attach", "sxg_poa_comm_destroy", "sxg_poa_batch_run_sharded", "sxg_poa_batch_run_sharded_local"]
+           "sxg_poa_comm_attach", "sxg_poa_comm_destroy", "sxg_poa_batch_run_sharded", "sxg_poa_batch_run_sharded_local",
+           "sxg_poa_batch_upload_sharded", "sxg_poa_batch_execute_sharded", "sxg_poa_batch_download_sharded", "sxg_poa_sharded_info"]
 COMM_ID_BYTES = 128
 NOT_ROOT = 1
 
@@ -116,6 +117,10 @@ def load_library(build_if_missing=True):
     L.sxg_poa_comm_destroy.restype = None
     L.sxg_poa_batch_run_sharded.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(BatchOut)]
     L.sxg_poa_batch_run_sharded_local.argtypes = [vp, C.POINTER(BatchIn), C.c_int, C.POINTER(BatchOut)]
+    L.sxg_poa_batch_upload_sharded.argtypes = [vp, C.POINTER(BatchIn)]
+    L.sxg_poa_batch_execute_sharded.argtypes = [vp]
+    L.sxg_poa_batch_download_sharded.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(BatchOut)]
+    L.sxg_poa_sharded_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     L.sxg_xxh64.restype = C.c_uint64
     L.sxg_xxh64.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
     _lib = L
@@ -310,6 +315,37 @@ class PoaEngine:
             return self._unpack(out)
         finally:
             self.lib.sxg_poa_batch_free(C.byref(out))
+
+    # -- the sharded run in stages (inputs stay resident between executes) ------------------
+    def upload_sharded(self, bases, seq_off, blk_off, weights, params, want_consensus=False, want_msa=False):
+        """Every rank, SAME batch: deal the blocks by cost over the communicator's ranks, upload this rank's share."""
+        self._sh_in = self._mk_in(bases, seq_off, blk_off, weights, params, want_consensus, want_msa)
+        self._shape = (np.asarray(blk_off).copy(), np.asarray(seq_off).copy())
+        if self.lib.sxg_poa_batch_upload_sharded(self.h, C.byref(self._sh_in)):
+            raise self._err("sxg_poa_batch_upload_sharded")
+
+    def execute_sharded(self):
+        """Collective: align the uploaded share, pack it, bring every rank's blob to rank 0 (RCCL)."""
+        if self.lib.sxg_poa_batch_execute_sharded(self.h):
+            raise self._err("sxg_poa_batch_execute_sharded")
+
+    def download_sharded(self, check=True):
+        """Rank 0: all results in the batch's block order; other ranks: None."""
+        out = BatchOut()
+        rc = self.lib.sxg_poa_batch_download_sharded(self.h, C.byref(self._sh_in), C.byref(out))
+        if rc == NOT_ROOT:
+            return None
+        try:
+            if rc and (check or rc != -4):
+                raise self._err("sxg_poa_batch_download_sharded")
+            return self._unpack(out)
+        finally:
+            self.lib.sxg_poa_batch_free(C.byref(out))
+
+    def sharded_info(self):
+        n, b = C.c_int32(), C.c_uint64()
+        self.lib.sxg_poa_sharded_info(self.h, C.byref(n), C.byref(b))
+        return {"ranks_seen": n.value, "bytes_received": b.value}
 
     def run_blocks(self, blocks, params, weights=None, want_consensus=False, want_msa=False, check=True):
         """blocks: list of lists of uint8 code arrays (one inner list per block, alignment order)."""

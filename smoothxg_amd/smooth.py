@@ -20,7 +20,7 @@ class SmoothParams(C.Structure):
                 ("poa_q", C.c_int32), ("poa_c", C.c_int32), ("local_alignment", C.c_int32),
                 ("poa_padding_fraction", C.c_float), ("max_block_depth_for_padding_more", C.c_uint64),
                 ("add_consensus", C.c_int32), ("consensus_base_name", C.c_char_p),
-                ("adaptive_poa_params", C.c_int32), ("kmer_size", C.c_int32)]
+                ("adaptive_poa_params", C.c_int32), ("kmer_size", C.c_int32), ("use_abpoa", C.c_int32)]
 
 
 EXPORTS = ["sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_free", "sxg_graph_from_gfa",

@@ -24,7 +24,8 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
                               const uint32_t* weights, const poa_params_t* p, int pool_slots,
                               int32_t* out_counts /* n_nodes, n_edges, n_cons */, uint8_t* code,
                               int32_t* rank, int32_t* leader, int32_t* e_tail, int32_t* e_head,
-                              uint32_t* e_w, int32_t* paths, int32_t* scores, int32_t* cons, int32_t* row_hints) {
+                              uint32_t* e_w, int32_t* paths, int32_t* scores, int32_t* cons, int32_t* row_hints,
+                              int32_t* row_remain) {
     int64_t cap = 1, maxlen = 1;
     for (int s = 0; s < n_seqs; ++s) {
         cap += seq_off[s + 1] - seq_off[s];
@@ -75,5 +76,6 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
     memcpy(e_head, eh.data(), 4 * (size_t)hdr[1]);
     memcpy(e_w, ew.data(), 4 * (size_t)hdr[1]);
     if (row_hints) for (int r = 0; r < hdr[0]; ++r) row_hints[r] = xps[ord[r]];   // band hints of the packed sweep (decree B2)
+    if (row_remain && hdr[0] > 0) rows_remain(c, G, hdr[0], row_remain);          // decree B4 (pointer jumping over heaviest out-edges)
     return 0;
 }

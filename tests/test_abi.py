@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "missing export " + n
     from smoothxg_amd import poa
     assert sorted(poa.EXPORTS) == names
-    assert lib.sxg_poa_abi_version() == 1
+    assert lib.sxg_poa_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

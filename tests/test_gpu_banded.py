@@ -109,3 +109,79 @@ def test_long_banded_block_with_an_indel_wider_than_the_window_margin(engine):
     assert engine.stats()["dom_row_mode"] == 3
     g, sc, cells = O.block_run(blocks[0], None, op)
     assert_block_equal(res[0], g, sc, cells, label="banded-long-indel")
+
+
+# ---- ADAPTIVE band (params.banded = 2, decree B4: abPOA's rule) ------------------------------------------------
+
+@pytest.mark.parametrize("pname", ["convex_default", "affine_4param", "linear"])
+def test_adaptive_band_blocks_match_the_oracle(engine, pname):
+    """The same batch of shapes as the static band, in the adaptive mode: the band of every row follows the best cells of
+    its predecessor rows (found on the device while sweeping) and the node's distance to the end of the graph (pointer
+    jumping over heaviest out-edges in the graph phase)."""
+    rng = np.random.default_rng(71)
+    blocks = []
+    for L in (40, 300, 900, 1500, 2600, 4000):
+        blocks.append(random_block(rng, int(rng.integers(3, 9)), L, div=0.04))
+    blocks.append(random_block(rng, 24, 400, div=0.12))
+    anc = rng.integers(0, 4, 3000, dtype=np.uint8)
+    ins = rng.integers(0, 4, 280, dtype=np.uint8)
+    blocks.append([np.concatenate([anc[:1200], ins, anc[1200:]]), anc.copy(), np.concatenate([anc[:700], anc[950:]]),
+                   np.concatenate([anc[:2000], ins[:150], anc[2000:]])])
+    blocks.append([rng.integers(0, 4, 5, dtype=np.uint8), rng.integers(0, 4, 3, dtype=np.uint8)])   # tiny: one strip
+    gp, op = _p(pname, 2)
+    res = engine.run_blocks(blocks, gp, want_consensus=True)
+    st = engine.stats()
+    assert st["dom_row_mode"] == 3 and st["dom_threads"] == 64
+    for b, seqs in enumerate(blocks):
+        g, sc, cells = O.block_run(seqs, None, op)
+        assert_block_equal(res[b], g, sc, cells, label=f"adaptive/{pname}/block{b}")
+        assert (res[b].consensus == g.consensus()).all()
+
+
+def test_adaptive_band_follows_a_structural_variant_the_static_band_loses(engine):
+    """Three sequences carry a 700-base insertion the first one lacks (beyond w = 311 + 0.03 L = 386).  The static band sits
+    on the backbone coordinate and loses the alignment after the insertion; the adaptive band moves with the best cells
+    of the rows above, keeps it, and returns the full matrix's scores -- abPOA's reason for the rule.  Each mode
+    equals its own oracle."""
+    rng = np.random.default_rng(72)
+    anc = rng.integers(0, 4, 2500, dtype=np.uint8)
+    ins = rng.integers(0, 4, 700, dtype=np.uint8)
+    with_ins = np.concatenate([anc[:1000], ins, anc[1000:]])
+    seqs = [with_ins, anc.copy(), with_ins.copy(), anc.copy()]
+    seqs[2][[50, 1500, 3000]] ^= 1
+    out = {}
+    for banded in (0, 1, 2):
+        gp, op = _p("convex_default", banded)
+        r = engine.run_blocks([seqs], gp)[0]
+        g, sc, cells = O.block_run(seqs, None, op)
+        assert_block_equal(r, g, sc, cells, label=f"sv/banded={banded}")
+        out[banded] = r
+    assert (out[2].scores == out[0].scores).all()
+    assert not (out[1].scores == out[0].scores).all()
+    assert int(out[2].cells.sum()) < 0.6 * int(out[0].cells.sum())
+
+
+def test_config3_shape_adaptive_band_full_block(engine):
+    """BASELINE config 3 as the reference's -A path runs it, adaptive band: 64 x 5 kbp, affine, whole block."""
+    seqs = synth.make_block(1, 64, 5000)
+    gp, op = Params(1, -4, -8, -2, -8, -2, 0, 2), O.mkparams(1, -4, -8, -2, -8, -2, mode=0, banded=2)
+    res = engine.run_blocks([seqs], gp, want_consensus=True)[0]
+    g, sc, cells = O.block_run(seqs, None, op)
+    assert_block_equal(res, g, sc, cells, label="c3-adaptive")
+    assert (res.consensus == g.consensus()).all()
+    assert int(cells.sum()) < 0.3 * sum(len(s) for s in seqs[1:]) * g.n_nodes
+
+
+def test_adaptive_band_long_blocks_and_mixed_modes_in_one_batch(engine):
+    """15 kbp (the window slides, strip width 11) next to short blocks; static, adaptive and unbanded blocks share a batch
+    (per-block parameters), the two banded modes even a launch."""
+    rng = np.random.default_rng(73)
+    blocks = [random_block(rng, 3, 15000, div=0.02), random_block(rng, 6, 700, div=0.05), random_block(rng, 5, 1800, div=0.03),
+              random_block(rng, 4, 2400, div=0.03)]
+    m, n, g, e, q, c = PARAM_SETS["convex_default"]
+    modes = [2, 1, 2, 0]
+    gp = [Params(m, n, g, e, q, c, 0, b) for b in modes]
+    res = engine.run_blocks(blocks, gp)
+    for b, seqs in enumerate(blocks):
+        gg, sc, cells = O.block_run(seqs, None, O.mkparams(m, n, g, e, q, c, mode=0, banded=modes[b]))
+        assert_block_equal(res[b], gg, sc, cells, label=f"mixed-modes/block{b}/banded={modes[b]}")

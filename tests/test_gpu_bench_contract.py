@@ -31,3 +31,28 @@ def test_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_headline_line_takes_the_valu_roof_from_the_committed_counters():
+    """The headline workload prices its roofline with the counters under profiles/rNN/counters.json: the `valu` branch
+    of bench.py (the tiny workload above has no counters and only ever exercises the HBM fallback).  frac must be
+    recomputable from the fields of the line itself."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "ns", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    r, v = d["roofline"], d["roofline"]["valu"]
+    assert r["bound"] == "valu" and r["unit"] == "G VALU issue cycles/s"
+    assert 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "counters_match_build" in v and v["counter_file"].startswith("profiles/r")
+    # frac = (4 * (insts - dual) + 2 * dual) / (SIMDs * clock * kernel seconds), per launch
+    need = v["issue_cycles_half_rate"] * (v["wave_insts_per_launch"] - v["dual_rate_insts_per_launch"]) + \
+        v["issue_cycles_full_rate"] * v["dual_rate_insts_per_launch"]
+    had = v["simds"] * v["clock_GHz"] * 1e9 * r["kernel_ms_per_launch"] / 1e3
+    assert abs(need / had - r["frac"]) < 1e-6 * max(1.0, r["frac"])
+    assert 0.0 < v["useful_frac"] <= r["frac"] and v["used_columns"] <= v["swept_columns"]
+    assert 0.0 <= v["dual_rate_share"] < 1.0
+    if v["counters_match_build"]:
+        assert r["traffic"] and r["traffic"] > 0
+    assert r["hbm"]["algo_bytes_per_cell"] == 13.0
+    assert d["dtype"] == "int16" and d["config"]["blocks_per_gpu"] == 1000

@@ -43,7 +43,7 @@ def test_random_blocks_random_scores_per_block(engine, seed):
             seqs.append(np.concatenate([seqs[0][:L // 2], rng.integers(0, 4, L // 10 + 1, dtype=np.uint8), seqs[0][L // 2:]]))
         m, n, g, e, q, c = random_scores(rng)
         mode = int(rng.integers(0, 2))
-        banded = int(rng.integers(0, 2)) if mode == 0 else 0
+        banded = int(rng.integers(0, 3)) if mode == 0 else 0
         blocks.append(seqs)
         weights.append(rng.integers(1, 6, len(seqs)).astype(np.uint32))
         gp.append(Params(m, n, g, e, q, c, mode, banded))

@@ -376,8 +376,21 @@ def test_sharded_run_reassembles_in_block_order(engine, oracle):
     engine.comm_init(engine.comm_unique_id(), 1, 0)         # a real RCCL communicator of one rank
     try:
         same(engine.run_flat_sharded(bases, seq_off, blk_off, w, gp, want_consensus=True, want_msa=True))
+        # the staged form (what bench.py --gpus N times): inputs dealt and uploaded once, the collective stage repeated --
+        # with a communicator the size all-gathers and the (empty) send/recv group really run through RCCL
+        engine.upload_sharded(bases, seq_off, blk_off, w, gp, want_consensus=True, want_msa=True)
+        for _ in range(2):
+            engine.execute_sharded()
+            assert engine.sharded_info() == {"ranks_seen": 1, "bytes_received": 0}
+        same(engine.download_sharded())
     finally:
         engine.lib.sxg_poa_comm_destroy(engine.h)
+    # a share the caller cut himself (plain upload) can be executed and exchanged, but the root cannot reassemble a batch it never saw
+    engine.upload(bases, seq_off, blk_off, w, gp, want_consensus=True)
+    engine.execute_sharded()
+    import smoothxg_amd as S
+    with pytest.raises(S.PoaError):
+        engine.download_sharded()
 
 
 def test_device_view_tensors_are_the_downloaded_results():

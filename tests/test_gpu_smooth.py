@@ -122,3 +122,47 @@ def test_drb1_maf_merging_and_flips_on_gpu(engine):
     out = SO.Graph(got[0])
     for q, nm in enumerate(g.pname):
         assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+@pytest.mark.parametrize("cons", [0, 1])
+def test_drb1_abpoa_path_on_gpu(engine, cons):
+    """-A: the smooth_abpoa path (A11) end to end on the GPU -- abPOA's score convention, its ADAPTIVE band
+    (params.banded = 2: the one-wave kernel finds every row's best cells while sweeping), consensus restricted to visited
+    nodes (build_odgi_abPOA) -- equals the oracle stack byte for byte and preserves the 12 paths."""
+    text = open(DRB1).read()
+    g = SO.Graph(text)
+    blocks = SO.break_blocks(g, SO.smoothable_blocks(g, 900 * 12, 900, 5000, 5000), 1800)
+    sm = S.Smoother(text, discover=dict(target_poa_length=900, n_haps=12, max_path_jump=5000, max_edge_jump=5000))
+    got = sm.smooth_gfa(S.default_params(add_consensus=cons, use_abpoa=1), S.gpu_provider(engine))
+    assert engine.stats()["dom_row_mode"] == 3
+    assert got == SO.smooth(g, blocks, add_consensus=bool(cons), abpoa=True)
+    out = SO.Graph(got)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+def test_drb1_three_chained_iterations_as_the_reference_ctest_runs_them(engine):
+    """The reference's own test configuration (CMakeLists.txt:565: -l 700,900,1100 -j 5k -e 5k -r 12) is THREE smoothing
+    iterations, each on the graph the one before wrote (src/main.cpp:374-1065); consensus paths only in the last
+    (src/main.cpp:404).  Every iteration: real block discovery on the previous GFA, one batched GPU POA call, lacing.
+    After each one the 12 paths still spell their sequences and the path count is kept (src/main.cpp:770-810); the GFA
+    of every iteration is byte-identical to the oracle stack's, pinned by size and SHA-256 in
+    tests/golden/drb1_chain.json (made by tests/golden/make_drb1_chain.py; the oracle chain takes minutes on a CPU)."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(HERE, "golden", "drb1_chain.json")))["iterations"]
+    text = open(DRB1).read()
+    g0 = SO.Graph(text)
+    for it, tl in enumerate((700, 900, 1100)):
+        last = it == 2
+        sm = S.Smoother(text, discover=dict(target_poa_length=tl, n_haps=12, max_path_jump=5000, max_edge_jump=5000))
+        assert sm.n_blocks == gold[it]["blocks"]
+        text = sm.smooth_gfa(S.default_params(add_consensus=1 if last else 0), S.gpu_provider(engine))
+        sm.close()
+        assert len(text) == gold[it]["gfa_bytes"], f"iteration {it} (-l {tl})"
+        assert hashlib.sha256(text.encode()).hexdigest() == gold[it]["sha256"], f"iteration {it} (-l {tl})"
+        out = SO.Graph(text)
+        names = [nm for nm in out.pname if not nm.startswith("Consensus_")]
+        assert sorted(names) == sorted(g0.pname) and len(out.pname) == gold[it]["paths"]
+        for q, nm in enumerate(g0.pname):
+            assert out.path_sequence(out.pname.index(nm)) == g0.path_sequence(q)

@@ -34,13 +34,14 @@ def run_emul(L, seqs, weights, params, pool=4096):
     ew = np.zeros(cap, np.uint32)
     sc = np.zeros(len(seqs), np.int32)
     hints = i32()
+    remain = i32()
     w = np.asarray(weights, np.uint32)
     st = L.emul_block_run(_p(bases, C.c_uint8), _p(off, C.c_int32), len(seqs), _p(w, C.c_uint32), C.byref(params),
                           pool, _p(cnt, C.c_int32), _p(code, C.c_uint8), _p(rank, C.c_int32), _p(ld, C.c_int32),
                           _p(et, C.c_int32), _p(eh, C.c_int32), _p(ew, C.c_uint32), _p(paths, C.c_int32),
-                          _p(sc, C.c_int32), _p(cons, C.c_int32), _p(hints, C.c_int32))
+                          _p(sc, C.c_int32), _p(cons, C.c_int32), _p(hints, C.c_int32), _p(remain, C.c_int32))
     n, e, nc = cnt
-    return st, (code[:n], rank[:n], ld[:n], et[:e], eh[:e], ew[:e], paths[:off[-1]], sc, cons[:nc], hints[:n])
+    return st, (code[:n], rank[:n], ld[:n], et[:e], eh[:e], ew[:e], paths[:off[-1]], sc, cons[:nc], hints[:n], remain[:n])
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -66,6 +67,7 @@ def test_graph_code_matches_oracle(emul, oracle, mode, pname):
         assert (r[7] == sc).all()
         assert (r[8] == g.consensus()).all()
         assert (r[9] == g.row_hints()).all()      # backbone coordinates (band hints, decree B2)
+        assert (r[10] == g.row_remain()).all()    # heaviest-path distance to a sink (adaptive band, decree B4)
 
 
 def test_row_pool_overflow_is_reported(emul, oracle):

@@ -39,7 +39,7 @@ class OracleProvider:
         msa_off, msa_cols, msa_txt = [0], [], b""
         for b in range(nb):
             pr = i.params[b if i.per_block_params else 0]
-            par = O.mkparams(pr.m, pr.n, pr.g, pr.e, pr.q, pr.c, pr.mode)
+            par = O.mkparams(pr.m, pr.n, pr.g, pr.e, pr.q, pr.c, pr.mode, pr.banded)
             seqs = [bases[so[s]:so[s + 1]] for s in range(blk[b], blk[b + 1])]
             if seqs:
                 g, _, _ = O.block_run(seqs, w[blk[b]:blk[b + 1]], par)
@@ -207,6 +207,39 @@ def test_block_graph_and_full_iteration_match_oracle(prov, seed, cons):
             assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
 
 
+@pytest.mark.parametrize("cons", [0, 1])
+@pytest.mark.parametrize("scores", [None, (1, 4, 6, 2, 0, 0), (2, 3, 0, 3, 0, 0)])
+def test_abpoa_path_iteration_matches_restatement(prov, cons, scores):
+    """-A (smooth_abpoa, src/smooth.cpp:133-627): the scores in abPOA's convention (convex default, the 4-parameter form
+    with q = c = 0 -> affine, g = 0 -> linear), the adaptive band (params.banded = 2 reaches the provider), the
+    consensus path restricted to visited nodes (build_odgi_abPOA) -- C++ host rows == Python restatement, byte for byte."""
+    text = synthetic_gfa(11, n_paths=6, n_nodes=90)
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 300)
+    blocks = SO.blockset_by_path_windows(g, 300)
+    kw = {} if scores is None else dict(zip(("poa_m", "poa_n", "poa_g", "poa_e", "poa_q", "poa_c"), scores))
+    okw = {} if scores is None else dict(zip(("m", "n", "g", "e", "q", "cc"), scores))
+    p = S.default_params(add_consensus=cons, use_abpoa=1, **kw)
+    seen = []
+    inner = prov.provider()
+    got = sm.smooth_gfa(p, inner)
+    want = SO.smooth(g, blocks, add_consensus=bool(cons), abpoa=True, **okw)
+    assert got == want
+    assert got != SO.smooth(g, blocks, add_consensus=bool(cons), abpoa=False, **okw) or scores is not None
+    out = SO.Graph(got)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+    # the engine parameters the provider is handed
+    e = SO.engine_params(*(scores or (1, 4, 6, 2, 26, 1)), True, True)
+    assert e.banded == 2 and e.mode == 0
+    if scores is None:
+        assert (e.m, e.n, e.g, e.e, e.q, e.c) == (1, -4, -8, -2, -27, -1)
+    elif scores[2] == 0:
+        assert (e.g, e.e, e.q, e.c) == (-3, -3, -3, -3)
+    else:
+        assert (e.g, e.e, e.q, e.c) == (-8, -2, -8, -2)
+
+
 def test_drb1_fixture_round_trip(prov):
     """The reference's own test input (CMakeLists.txt:562-567 runs the CLI on it and checks the exit
     code): one smoothing iteration must preserve all 12 paths and agree with the oracle."""
@@ -221,6 +254,40 @@ def test_drb1_fixture_round_trip(prov):
     assert sorted(out.pname) == sorted(g.pname)
     for q, nm in enumerate(g.pname):
         assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+
+
+def test_three_chained_iterations_on_a_synthetic_graph(prov):
+    """The reference runs its target lengths as a CHAIN (-l 700,900,1100, CMakeLists.txt:565): every iteration reads the
+    graph the one before wrote (src/main.cpp:374-1065), consensus paths only in the last (:404).  Here on a small
+    synthetic graph (the DRB1 chain is pinned by tests/golden/drb1_chain.json and runs in the GPU tier): real block
+    discovery per iteration, C++ host rows == Python restatement after EVERY iteration, paths and path count kept."""
+    text = synthetic_gfa(21, n_paths=6, n_nodes=120)
+    g0 = SO.Graph(text)
+    want_text = text
+    for it, tl in enumerate((150, 220, 300)):
+        last = it == 2
+        gw = SO.Graph(want_text)
+        blocks = SO.break_blocks(gw, SO.smoothable_blocks(gw, tl * 6, tl, 5000, 5000), 2 * tl)
+        want_text = SO.smooth(gw, blocks, add_consensus=last)
+        sm = S.Smoother(text, discover=dict(target_poa_length=tl, n_haps=6, max_path_jump=5000, max_edge_jump=5000))
+        assert [sm.block_ranges(k) for k in range(sm.n_blocks)] == [[tuple(r) for r in blk] for blk in blocks]
+        text = sm.smooth_gfa(S.default_params(add_consensus=1 if last else 0), prov.provider())
+        sm.close()
+        assert text == want_text, "iteration %d (-l %d)" % (it, tl)
+        out = SO.Graph(text)
+        names = [nm for nm in out.pname if not nm.startswith("Consensus_")]
+        assert sorted(names) == sorted(g0.pname)
+        for q, nm in enumerate(g0.pname):
+            assert out.path_sequence(out.pname.index(nm)) == g0.path_sequence(q)
+    assert sum(nm.startswith("Consensus_") for nm in SO.Graph(text).pname) >= 1
+
+
+def test_drb1_chain_fixture_is_well_formed():
+    import json
+    j = json.load(open(os.path.join(os.path.dirname(DRB1), "drb1_chain.json")))
+    assert [x["target_poa_length"] for x in j["iterations"]] == [700, 900, 1100]
+    assert all(len(x["sha256"]) == 64 and x["gfa_bytes"] > 0 for x in j["iterations"])
+    assert j["iterations"][0]["paths"] == j["iterations"][1]["paths"] == 12 and j["iterations"][2]["paths"] > 12
 
 
 def test_adaptive_score_tiers_are_the_reference_table():
@@ -404,7 +471,7 @@ def test_integration_snippet_compiles_and_links_against_the_c_abi(tmp_path):
                            "-Wl,-rpath," + os.path.join(root, "smoothxg_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 1" in r.stdout
+    assert "abi 3" in r.stdout
 
 
 def test_ready_made_and_multi_gpu_snippets_compile_and_link(tmp_path):
