@@ -63,6 +63,7 @@ extern "C" {
 #define SXG_ST_NODES_OVERFLOW 4
 #define SXG_ST_TOO_LONG 5 /* a sequence exceeds SXG_POA_MAX_SEQ_LEN (local) / SXG_POA_MAX_SEQ_LEN_WIDE (see below) */
 #define SXG_ST_RANGE_OVERFLOW 6 /* internal: scores left the narrow sweep's range; the engine re-runs the block wider */
+#define SXG_ST_INTERNAL 8       /* an internal invariant failed (e.g. the banded traceback left its band): final, please report */
 #define SXG_ST_BAND_MISS 7      /* internal: the packed sweep's traceback left its band of kept cells; re-run wider */
 
 /* Longest sequence.  Local alignment (smoothxg's default) with m * length < 30000 runs the packed int16 sweep, whose

@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO] + \
-          os.environ.get("SXG_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-lrccl"]
+          os.environ.get("SXG_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]   # (RCCL is dlopen-ed on first use)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -118,7 +118,16 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
     int best_lo = 0, best_hi = 0, bi_lo = -1, bi_hi = -1, bj_lo = 0, bj_hi = 0;   // (bj: ABSOLUTE column -- the window moves)
     unsigned long long cells = 0;
 
+#ifdef SXG_ROW_PROF
+    unsigned long long racc[8] = {0};
+#define BP_MARK(seg) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tn_ = __builtin_readcyclecounter(); racc[seg] += tn_ - rt_; rt_ = tn_; } while (0)
+#else
+#define BP_MARK(seg) do { } while (0)
+#endif
     for (int i = 1; i <= N; ++i) {
+#ifdef SXG_ROW_PROF
+        unsigned long long rt_ = __builtin_readcyclecounter();
+#endif
         if (has_board) { if ((i & 127) == 1) sxg_balance_prio(B, (unsigned long long)i * (unsigned long long)(2 * bw)); }
         else if ((i & 63) == 1) sxg_rotate_prio(prio_rank);
         const int r = i - 1;
@@ -171,6 +180,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             hp0 = (int)r0.x; hp1 = (int)r1.x;
             my_pl = p_l; my_pr = p_r;
         }
+        BP_MARK(0);   // descriptor, (B4) predecessor records, band
         if (bh >= bl) cells += (unsigned long long)(min(L, bh * W + W - 1) - bl * W + 1);
         if (bh >= bl && (bl < s0 || bh >= s0 + BAND_WIN)) {
             // re-centre the window on this band; registers of the previous row no longer line up with it
@@ -287,6 +297,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             for (int k = 0; k < W; ++k) Op[k] = NEG2;
         }
 
+        BP_MARK(1);   // predecessor rows fetched and folded (all loads drained)
         // ---- pass 1: H before the in-row gaps, strip-local carries
         int a = NEG2, b = NEG2;
         unsigned sc4 = 0;
@@ -346,6 +357,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             if (lane == 0) lh = pk2(NEGP, pk_lo(l63));
         }
 
+        BP_MARK(2);   // pass 1, scan, pass 2
         // ---- end cell (local): only cells of the band count
         rowmax &= m2;
         {
@@ -406,6 +418,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             prev_bw = bl | (bh << 16); prev_lr = ml_ | (mr_ << 16);
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)prev_bw, (unsigned)prev_lr}, rs_meta, 0u, (i - 1) * 32 + 24, REC_AUX);
         }
+        BP_MARK(3);   // end cell, (B4) best-cell search and record
         // ---- outgoing candidates, band store.  A sibling successor keeps my own F/O instead.
         next_sib = false;
         int nbl = -1, nbh = -2;    // the next row's band (unknown at a descriptor-chunk edge)
@@ -461,7 +474,13 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         Hleft = lh;
         pbl = bl; pbh = bh;
         regs_ok = true;
+        BP_MARK(4);   // outgoing candidates, band stores (drained)
     }
+#ifdef SXG_ROW_PROF
+    if (lane == 0 && B.row_prof)
+        for (int k = 0; k < 8; ++k) B.row_prof[k] += racc[k];
+#endif
+#undef BP_MARK
     (void)pbl; (void)pbh;
     if (lane == 0 && cells_out) *cells_out = cells;
 

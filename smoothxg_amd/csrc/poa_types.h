@@ -37,6 +37,7 @@ enum : int {
     ST_NODES_OVERFLOW = 4,
     ST_TOO_LONG = 5,
     ST_RANGE_OVERFLOW = 6,  // a global alignment outgrew the score range of the narrow sweep (re-run wider)
+    ST_INTERNAL = 8,        // a state the kernels hold impossible (the banded traceback reporting a miss): final, never retried
     ST_BAND_MISS = 7,       // packed sweep: the traceback kept leaving the band of stored cells (re-run with a plane that keeps every strip)
 };
 

@@ -19,7 +19,8 @@
 #include <vector>
 
 #include "../../include/sxg_poa.h"
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // (types and prototypes only: the library is opened on first use, see rccl_api)
+#include <dlfcn.h>
 #include "poa_dp.hip.h"
 #include "poa_dp16.hip.h"
 #include "poa_band16.hip.h"
@@ -247,7 +248,9 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                                                            V.G.posnode, nullptr, nullptr, smem);
                     __syncthreads();
                     PROF(3);
-                    if (lds[TBM_FLAG]) { status = ST_BAND_MISS; break; }
+                    // (a cell outside a row's band does not exist for the banded walk, so it cannot miss: if it ever reports one,
+                    //  that is a defect -- the block fails with its own status instead of being re-run on a sweep with other semantics)
+                    if (lds[TBM_FLAG]) { status = ST_INTERNAL; break; }
                 } else if constexpr (RM == 2) {
                     // The traceback derives the alignment from the band of cells the sweep kept around every
                     // row's hint.  If the walk needs a cell outside (a structural variant moved the alignment
@@ -1025,7 +1028,9 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
         }
         double rt = 1e-9;
         for (int k = 0; k < 8; ++k) rt += (double)ra[k];
-        static const char* seg[8] = {"setup", "pass1+scan", "wait left wave", "combine+pass2", "wait right wave", "hand-over+end cell", "stored row fetch", "outgoing+row store"};
+        static const char* seg16[8] = {"setup", "pass1+scan", "wait left wave", "combine+pass2", "wait right wave", "hand-over+end cell", "stored row fetch", "outgoing+row store"};
+        static const char* segb[8] = {"descriptor+band", "predecessor fetch+fold", "pass1+scan+pass2", "end cell+best-cell search", "outgoing+band stores", "-", "-", "-"};
+        const char* const* seg = V.RM == 3 ? segb : seg16;
         fprintf(stderr, "[sxg]   row profile:");
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", seg[k], 100.0 * (double)ra[k] / rt);
         fprintf(stderr, "\n");
@@ -1213,8 +1218,8 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         }
         std::vector<int32_t> again;
         if (dbg) {
-            int cnt[8] = {0};
-            for (int b : pending) cnt[status[b] & 7]++;
+            int cnt[16] = {0};
+            for (int b : pending) cnt[status[b] & 15]++;
             fprintf(stderr, "[sxg] round %d: ok %d rows %d pool %d steps %d nodes %d long %d range %d band %d\n", attempt, cnt[0], cnt[1], cnt[2], cnt[3],
                     cnt[4], cnt[5], cnt[6], cnt[7]);
         }
@@ -1482,6 +1487,58 @@ extern "C" int sxg_poa_batch_run(sxg_poa_handle* h, const sxg_poa_batch_in* in, 
 // dense results into one device blob, the blob sizes are all-gathered and the blobs travel to the root with ONE
 // grouped ncclSend/ncclRecv per peer of exactly that size -- device to device over xGMI, no padding to the
 // largest rank, buffers kept by the handle.  The root assembles the results in the ORIGINAL block order.
+// RCCL is OPTIONAL at load time: a single-GPU user of libsxgpoa.so needs no librccl.so.  The entry points are resolved
+// with dlopen/dlsym the first time a communicator is asked for (in a process that already loaded RCCL -- PyTorch-ROCm --
+// the SONAME resolves to that very instance).
+namespace {
+struct RcclApi {
+    decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&::ncclCommAbort) CommAbort = nullptr;
+    decltype(&::ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+    decltype(&::ncclAllGather) AllGather = nullptr;
+    decltype(&::ncclGroupStart) GroupStart = nullptr;
+    decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&::ncclSend) Send = nullptr;
+    decltype(&::ncclRecv) Recv = nullptr;
+    decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+    std::string why;
+};
+RcclApi& rccl_api() {
+    static RcclApi A = [] {
+        RcclApi a;
+        void* lib = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) { a.why = std::string("librccl.so not found (") + (dlerror() ? dlerror() : "dlopen failed") + ")"; return a; }
+        bool all = true;
+#define SXG_RCCL_SYM(f) do { a.f = (decltype(a.f))dlsym(lib, "nccl" #f); if (!a.f) { all = false; a.why += " nccl" #f; } } while (0)
+        SXG_RCCL_SYM(GetUniqueId); SXG_RCCL_SYM(CommInitRank); SXG_RCCL_SYM(CommDestroy); SXG_RCCL_SYM(CommAbort);
+        SXG_RCCL_SYM(CommGetAsyncError); SXG_RCCL_SYM(AllGather); SXG_RCCL_SYM(GroupStart); SXG_RCCL_SYM(GroupEnd);
+        SXG_RCCL_SYM(Send); SXG_RCCL_SYM(Recv); SXG_RCCL_SYM(GetErrorString);
+#undef SXG_RCCL_SYM
+        a.ok = all;
+        if (!all) a.why = "librccl.so lacks" + a.why;
+        return a;
+    }();
+    return A;
+}
+}  // namespace
+#define RCCL_NEEDED() do { if (!rccl_api().ok) return fail(SXG_E_NODEVICE, "multi-GPU needs RCCL: " + rccl_api().why); } while (0)
+#define ncclGetUniqueId rccl_api().GetUniqueId
+#define ncclCommInitRank rccl_api().CommInitRank
+#define ncclCommDestroy rccl_api().CommDestroy
+#define ncclCommAbort rccl_api().CommAbort
+#define ncclCommGetAsyncError rccl_api().CommGetAsyncError
+#define ncclAllGather rccl_api().AllGather
+#define ncclGroupStart rccl_api().GroupStart
+#define ncclGroupEnd rccl_api().GroupEnd
+#define ncclSend rccl_api().Send
+#define ncclRecv rccl_api().Recv
+#define ncclGetErrorString rccl_api().GetErrorString
+
 #define NCCLCHK(x)                                                                                      \
     do {                                                                                               \
         ncclResult_t _r = (x);                                                                         \
@@ -1492,6 +1549,7 @@ constexpr int BC_N_WORDS = 8;   // words per rank in the count exchange (BC_N be
 extern "C" int sxg_poa_comm_unique_id(uint8_t* id) {
     if (!id) return fail(SXG_E_INVALID, "NULL argument");
     static_assert(sizeof(ncclUniqueId) == SXG_POA_COMM_ID_BYTES, "ncclUniqueId size");
+    RCCL_NEEDED();
     ncclUniqueId u;
     NCCLCHK(ncclGetUniqueId(&u));
     memcpy(id, &u, sizeof(u));
@@ -1504,6 +1562,7 @@ extern "C" void sxg_poa_comm_destroy(sxg_poa_handle* h) {
 }
 extern "C" int sxg_poa_comm_init(sxg_poa_handle* h, const uint8_t* id, int nranks, int rank) {
     if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(SXG_E_INVALID, "bad argument");
+    RCCL_NEEDED();
     HIPCHK(hipSetDevice(h->device));
     sxg_poa_comm_destroy(h);
     ncclUniqueId u;
@@ -1515,6 +1574,7 @@ extern "C" int sxg_poa_comm_init(sxg_poa_handle* h, const uint8_t* id, int nrank
 }
 extern "C" int sxg_poa_comm_attach(sxg_poa_handle* h, void* nccl_comm, int nranks, int rank) {
     if (!h || !nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(SXG_E_INVALID, "bad argument");
+    RCCL_NEEDED();
     sxg_poa_comm_destroy(h);
     h->comm = (ncclComm_t)nccl_comm; h->own_comm = false; h->nranks = nranks; h->rank = rank;
     HIPCHK(hipSetDevice(h->device));

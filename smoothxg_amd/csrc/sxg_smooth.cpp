@@ -15,6 +15,7 @@
 #include <omp.h>
 #include <sys/mman.h>
 #include <algorithm>
+#include <atomic>
 #include <parallel/algorithm>
 #include <chrono>
 #include <cstdio>
@@ -1323,8 +1324,8 @@ int sxg_block_maf(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, c
 // cpu.max).  Measured on the GPU box: 256 hardware threads, quota 16 CPUs -- the default team of 256 is
 // throttled by CFS and runs the host phases ~2x slower than a team of 16.  OMP_NUM_THREADS overrides.
 static int host_threads() {
-    static int cached = 0;
-    if (cached) return cached;
+    static std::atomic<int> cached{0};
+    if (cached.load(std::memory_order_relaxed)) return cached.load(std::memory_order_relaxed);
     int n = omp_get_num_procs();
     if (!getenv("OMP_NUM_THREADS")) {
         if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -1337,16 +1338,23 @@ static int host_threads() {
             fclose(f);
         }
     } else n = omp_get_max_threads();
-    cached = n > 0 ? n : 1;
-    return cached;
+    cached.store(n > 0 ? n : 1, std::memory_order_relaxed);
+    return cached.load(std::memory_order_relaxed);
 }
+// The library's parallel regions run with that team; the caller's own OpenMP setting (smoothxg has its -t) is put back
+// when the call returns: omp_set_num_threads changes the CALLING thread's nthreads-var, nothing process-wide.
+struct OmpTeamGuard {
+    int saved;
+    explicit OmpTeamGuard(int n) : saved(omp_get_max_threads()) { omp_set_num_threads(n); }
+    ~OmpTeamGuard() { omp_set_num_threads(saved); }
+};
 
 static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, const sxg_merge_params* mp,
                             sxg_poa_run_fn run, sxg_poa_free_fn fre, void* ctx, char** out_gfa, char** out_maf, int64_t* n_flipped) {
     if (!g || !b || !p || !run || !out_gfa) return fail(SXG_E_INVALID, "NULL argument");
     if (out_maf) *out_maf = nullptr;
     if (n_flipped) *n_flipped = 0;
-    omp_set_num_threads(host_threads());
+    const OmpTeamGuard team(host_threads());
     const int64_t nb = (int64_t)b->blocks.size();
     const bool timing = getenv("SXG_SMOOTH_TIMING") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
