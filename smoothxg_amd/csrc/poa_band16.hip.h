@@ -394,26 +394,26 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             const bool l_hi = mk_lo == 0ull, r_hi = mk_hi != 0ull;
             const int l_ln = (int)__builtin_ctzll(l_hi ? mk_hi : mk_lo), r_ln = 63 - (int)__builtin_clzll(r_hi ? mk_hi : mk_lo);
             const int l_strip = s0 + l_ln + (l_hi ? 64 : 0), r_strip = s0 + r_ln + (r_hi ? 64 : 0);
-            const int l_kmax = L - l_strip * W, r_kmax = L - r_strip * W;
-            int kf = 0, kl = 0;
+            // Every lane finds the first and the last column of its two strips that holds M -- packed, six VALU instructions
+            // per column (xor, min with 1, two multiply-adds, min, max), no scalar chain -- and the two lanes that matter are
+            // read out afterwards.  Columns beyond L (only in the strip of column L) never count.
+            const int M2 = pk2(M, M);
+            const int islast2 = (st_lo == last_strip ? 0x0000ffff : 0) | (st_hi == last_strip ? (int)0xffff0000 : 0);
+            const int kL = bh == last_strip ? L - last_strip * W : W;
+            u16x2 first2 = u16x2{0x7fff, 0x7fff}, last2 = u16x2{0, 0};
 #pragma unroll
-            for (int k = W - 1; k >= 0; --k) {
-                const int v = __builtin_amdgcn_readlane(Hc[k], l_ln);
-                if ((l_hi ? pk_hi(v) : pk_lo(v)) == M && k <= l_kmax) kf = k;
+            for (int k = 0; k < W; ++k) {
+                int d = Hc[k] ^ M2;
+                if (k > kL) d |= islast2;
+                const int f = __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, d), u16x2{1, 1}));   // 0: the column holds M
+                const int kf2 = pk_mad(f, pk2(0x7fff - k, 0x7fff - k), pk2(k, k));              // f ? 0x7fff : k
+                const int kl2 = pk_mad(f, pk2(-(k + 1), -(k + 1)), pk2(k + 1, k + 1));           // f ? 0 : k + 1
+                first2 = __builtin_elementwise_min(first2, __builtin_bit_cast(u16x2, kf2));
+                last2 = __builtin_elementwise_max(last2, __builtin_bit_cast(u16x2, kl2));
             }
-            if (l_ln == r_ln && l_hi == r_hi) {
-#pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    const int v = __builtin_amdgcn_readlane(Hc[k], l_ln);
-                    if ((l_hi ? pk_hi(v) : pk_lo(v)) == M && k <= l_kmax) kl = k;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    const int v = __builtin_amdgcn_readlane(Hc[k], r_ln);
-                    if ((r_hi ? pk_hi(v) : pk_lo(v)) == M && k <= r_kmax) kl = k;
-                }
-            }
+            const unsigned fl = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, first2), l_ln);
+            const unsigned lr = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, last2), r_ln);
+            const int kf = (int)(l_hi ? fl >> 16 : fl & 0xffffu), kl = (int)(r_hi ? lr >> 16 : lr & 0xffffu) - 1;
             ml_ = l_strip * W + kf; mr_ = r_strip * W + kl;
             prev_bw = bl | (bh << 16); prev_lr = ml_ | (mr_ << 16);
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned)prev_bw, (unsigned)prev_lr}, rs_meta, 0u, (i - 1) * 32 + 24, REC_AUX);

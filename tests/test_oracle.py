@@ -336,3 +336,31 @@ def test_consensus_against_an_independent_heaviest_bundle(oracle):
         code, rank, _ = g.nodes()
         t, h, ww = g.edges()
         assert (heaviest_bundle_independent(code, rank, t, h, ww) == g.consensus()).all(), trial
+
+
+def test_banded_decrees_static_and_adaptive(oracle):
+    """Decrees B1-B4 of oracle/poa_oracle.c on the CPU.  (a) On a calm block both bands return the full matrix's scores
+    and graph at a fraction of its cells.  (b) A 700-base insertion shared by two of four sequences (beyond
+    w = 311 + 0.03 L) carries the alignment off the backbone: the STATIC band (B2) loses it, the ADAPTIVE band (B4, abPOA's
+    rule: the band follows the best cells of the predecessor rows) keeps the full matrix's scores.  (c) remain() -- the
+    walk along heaviest out-edges -- of a chain graph counts down to 0; global mode ignores the flag."""
+    from helpers import random_block
+    rng = np.random.default_rng(81)
+    calm = random_block(rng, 5, 1500, div=0.02)
+    ref = oracle.block_run(calm, None, oracle.mkparams(mode=0, banded=0))
+    for banded in (1, 2):
+        g, sc, cells = oracle.block_run(calm, None, oracle.mkparams(mode=0, banded=banded))
+        assert (sc == ref[1]).all() and g.n_nodes == ref[0].n_nodes and (g.nodes()[1] == ref[0].nodes()[1]).all()
+        assert int(cells.sum()) < 0.6 * int(ref[2].sum())
+    anc = rng.integers(0, 4, 2500, dtype=np.uint8)
+    with_ins = np.concatenate([anc[:1000], rng.integers(0, 4, 700, dtype=np.uint8), anc[1000:]])
+    wild = [with_ins, anc.copy(), with_ins.copy(), anc.copy()]
+    full = oracle.block_run(wild, None, oracle.mkparams(mode=0, banded=0))[1]
+    static = oracle.block_run(wild, None, oracle.mkparams(mode=0, banded=1))[1]
+    adaptive = oracle.block_run(wild, None, oracle.mkparams(mode=0, banded=2))
+    assert (adaptive[1] == full).all() and not (static == full).all()
+    assert int(adaptive[2].sum()) < 0.5 * sum(len(s) for s in wild[1:]) * adaptive[0].n_nodes
+    chain = oracle.block_run([anc[:50]], None, oracle.mkparams())[0]
+    assert (chain.row_remain() == np.arange(49, -1, -1)).all()
+    gl = [oracle.block_run(calm[:3], None, oracle.mkparams(mode=1, banded=b))[1] for b in (0, 1, 2)]
+    assert (gl[0] == gl[1]).all() and (gl[0] == gl[2]).all()
