@@ -26,9 +26,13 @@
  * What "drop-in" does and does not promise: alignment SCORES are those of the published recurrences and are
  * checked against independent implementations; node ids, topological ranks, tie-breaks between equally good
  * alignments, the consensus and the MSA column order follow the tie rules written down in oracle/poa_oracle.c
- * (S1-S8, B1-B3), NOT necessarily spoa's / abPOA's: both are absent from the reference snapshot, so their
- * choices could not be pinned ("PARITY UNPINNED").  Graphs are valid POA graphs of the same
- * sequences either way -- every path spells its sequence -- but need not be byte-identical to the reference's.
+ * (S1-S8, B1-B4), NOT necessarily spoa's / abPOA's: both are absent from the reference snapshot, so their
+ * choices could not be pinned ("PARITY UNPINNED").  One divergence is KNOWN: after every
+ * AddAlignment spoa re-sorts the whole graph depth-first (node-id order, in-edge tails first, aligned siblings
+ * together), this engine keeps the order incrementally (decree S7: new nodes are slotted next to their aligned
+ * group) -- any such order is a legal POA order, but it decides ties between equally good alignments, the end cell of
+ * a local alignment and the MSA column order.  Graphs are valid POA graphs of the same sequences either way -- every
+ * path spells its sequence -- but need not be byte-identical to the reference's.
  */
 #ifndef SXG_POA_H
 #define SXG_POA_H
