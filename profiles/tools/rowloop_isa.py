@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static look at the row loop of a packed-sweep block kernel: compiles sxg_poa.hip for ONE kernel class to
-ISA, finds the row loop (the deepest loop holding two s_barrier), and prints per basic block the number of
+ISA, finds the row loop (the deepest loop holding two s_barrier; without barriers -- round 3 -- the outermost loop), and prints per basic block the number of
 VALU / SALU / LDS / VMEM instructions and every scratch access inside the loop.
 
     python profiles/tools/rowloop_isa.py [W=11] [TMAX=256] [kernel substring]
@@ -43,7 +43,9 @@ by_depth = {}
 for b in blocks:
     by_depth.setdefault(b["depth"], []).append(b)
 cands = [d for d, bs in by_depth.items() if sum(i.startswith("s_barrier") for b in bs for i in b["ins"]) >= 2]
-row_depth = max(cands) if cands else 1   # (the one-wave banded sweep has no barriers: its row loop is the outermost loop)
+# (round 3: the packed sweep's waves no longer meet at barriers inside the row loop, and the one-wave banded sweep never
+#  did: the row loop is then the outermost loop of the function)
+row_depth = max(cands) if cands else 1
 tot = {"valu": 0, "salu": 0, "lds": 0, "vmem": 0, "scratch": 0}
 print("row loop depth", row_depth)
 for b in blocks:

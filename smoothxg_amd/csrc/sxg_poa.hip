@@ -456,6 +456,15 @@ struct Variant {
 // packed sweep with 10, 12 or 13 columns per strip (128 VGPRs, a handful of spill slots): 20 480 / 24 576 / 26 624 columns.
 static bool variant_for_len(int maxlen, int rm, Variant* v, bool sw = false) {
     static const int kNW[] = {1, 2, 3, 4, 8, 12, 16};
+    if (rm == 2) {   // development knob: SXG_POA_FORCE_P16="W,NW" forces one packed geometry (A/B runs of a single-class build)
+        if (const char* e = getenv("SXG_POA_FORCE_P16")) {
+            int fw = 0, fnw = 0;
+            if (sscanf(e, "%d,%d", &fw, &fnw) == 2 && 128L * fnw * fw >= maxlen + 1) {
+                *v = Variant{fw, fnw, fnw <= 4 ? 256 : (fnw <= 8 ? 512 : 1024), rm};
+                return true;
+            }
+        }
+    }
     // (narrow strips, 4-7 columns, for sequences below 1 kbp -- pggb's -l 700 ... 1100 -- in workgroups of up to 4 waves)
     static const int kW32[] = {16, 12, 8}, kW16[] = {13, 12, 11, 10, 9, 8, 7, 6, 5, 4};
     const int* ws = rm == 2 ? kW16 : kW32;
