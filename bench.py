@@ -342,6 +342,21 @@ def main():
         eng.upload(bases, seq_off, blk_off, None, params)  # inputs resident in HBM from here on
     n_local = len(blk_off) - 1
 
+    # The C-ABI exchange has never run with more than one real rank in the environment this was built in: the first
+    # exchange is a probe.  A failure is returned by ALL ranks (the error code travels in the count exchange; a peer that
+    # never answers ends in a timeout on every rank), so the ranks switch to the torch hand-off together.
+    if exchange == "cabi":
+        ok = 1
+        try:
+            eng.execute_sharded()
+        except Exception as e:
+            print("[bench] rank %d: C-ABI exchange failed: %s" % (rank, e), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            exchange = "torch (the C-ABI exchange failed in the probe step)"
+            a.check = False
     to_root = shard.RootGather() if world > 1 and exchange != "cabi" else None
 
     def step():
