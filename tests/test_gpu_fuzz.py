@@ -55,3 +55,36 @@ def test_random_blocks_random_scores_per_block(engine, seed):
         label = f"fuzz{seed}/block{b} L={len(seqs[0])} S={len(seqs)} scores=({p.m},{p.n},{p.g},{p.e},{p.q},{p.c}) mode={p.mode} banded={p.banded}"
         assert_block_equal(res[b], g_, sc, cells, label=label)
         assert (res[b].consensus == g_.consensus()).all(), label
+
+
+# SXG_FUZZ_LONG=<n>: more seeds of the long-block campaign (default one)
+@pytest.mark.parametrize("seed", [9501 + k for k in range(int(os.environ.get("SXG_FUZZ_LONG", "1")))])
+def test_random_long_banded_blocks(engine, seed):
+    """Blocks of 3-9 kbp (strip widths 8 and 11, a window that slides and re-centres) in the two banded modes, with
+    structural variants of 100-900 bases that push the alignment to and beyond the edge of the band: HIP == oracle."""
+    rng = np.random.default_rng(seed)
+    blocks, gp, op = [], [], []
+    for trial in range(6):
+        L = int(rng.integers(3000, 9000))
+        seqs = random_block(rng, int(rng.integers(3, 7)), L, div=float(rng.choice([0.01, 0.04])))
+        sv = int(rng.integers(100, 900))
+        at = int(rng.integers(L // 5, 4 * L // 5))
+        seqs.append(np.concatenate([seqs[0][:at], rng.integers(0, 4, sv, dtype=np.uint8), seqs[0][at:]]))
+        seqs.append(np.concatenate([seqs[0][:at], seqs[0][min(L, at + sv):]]))
+        if trial % 2:
+            seqs.append(seqs[-2].copy())
+        m, n, g, e, q, c = random_scores(rng)
+        # (the banded kernel is the packed one: a local alignment with m * L >= 30 000 leaves int16 and runs the full matrix
+        #  on the 32-bit sweep, band flag ignored -- documented in INTEGRATION.md; keep the campaign inside the band's domain)
+        m = min(m, 29999 // max(len(x) for x in seqs))
+        banded = 1 + trial % 2
+        blocks.append(seqs)
+        gp.append(Params(m, n, g, e, q, c, 0, banded))
+        op.append(O.mkparams(m, n, g, e, q, c, mode=0, banded=banded))
+    res = engine.run_blocks(blocks, gp, want_consensus=True)
+    for b, seqs in enumerate(blocks):
+        g_, sc, cells = O.block_run(seqs, None, op[b])
+        p = gp[b]
+        label = f"long{seed}/block{b} L={len(seqs[0])} S={len(seqs)} scores=({p.m},{p.n},{p.g},{p.e},{p.q},{p.c}) banded={p.banded}"
+        assert_block_equal(res[b], g_, sc, cells, label=label)
+        assert (res[b].consensus == g_.consensus()).all(), label
