@@ -15,6 +15,7 @@
 #include <omp.h>
 #include <sys/mman.h>
 #include <algorithm>
+#include <thread>
 #include <atomic>
 #include <parallel/algorithm>
 #include <chrono>
@@ -1364,85 +1365,134 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         fprintf(stderr, "[sxg_smooth] %-22s %.3f s\n", what, std::chrono::duration<double>(T1 - T0).count());
         T0 = T1;
     };
-    // phase 1: A2-A4 for every block, in parallel over blocks as the reference's OpenMP loop
-    // (src/smooth.cpp:1931, schedule(dynamic,1)) up to :743; the flat batch is filled in place
-    std::vector<collected_t> col((size_t)nb);
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int64_t k = 0; k < nb; ++k) col[(size_t)k] = collect(*g, b->blocks[(size_t)k], *p);
-    batch_t B;
-    {
-        B.blk_off.assign((size_t)nb + 1, 0);
-        for (int64_t k = 0; k < nb; ++k) B.blk_off[(size_t)k + 1] = B.blk_off[(size_t)k] + (int32_t)col[(size_t)k].seqs.size();
-        const size_t ns = (size_t)B.blk_off[(size_t)nb];
-        B.seq_off.assign(ns + 1, 0);
-        B.weights.assign(ns, 1);
-        for (int64_t k = 0; k < nb; ++k)
-            for (size_t i = 0; i < col[(size_t)k].seqs.size(); ++i) {
-                const size_t sidx = (size_t)B.blk_off[(size_t)k] + i;
-                B.seq_off[sidx + 1] = B.seq_off[sidx] + (int64_t)col[(size_t)k].seqs[i].size();
-                B.weights[sidx] = col[(size_t)k].weights[i];
-            }
-        B.bases.resize((size_t)B.seq_off[ns]);
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int64_t k = 0; k < nb; ++k)
-            for (size_t i = 0; i < col[(size_t)k].seqs.size(); ++i) {
-                const std::string& sq = col[(size_t)k].seqs[i];
-                uint8_t* dst = B.bases.data() + B.seq_off[(size_t)B.blk_off[(size_t)k] + i];
-                for (size_t x = 0; x < sq.size(); ++x) dst[x] = code_of(sq[x]);
-            }
-    }
-    lap("collect + batch");
-    // phase 2: ONE batched POA call (replaces src/smooth.cpp:752-786 of every block)
-    // A14: with -a every block brings its own scores (the engine's per_block_params)
-    std::vector<sxg_poa_params> pps;
-    if (p->adaptive_poa_params) {
-        pps.resize((size_t)nb);
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int64_t k = 0; k < nb; ++k) pps[(size_t)k] = block_poa_params(*g, b->blocks[(size_t)k], *p);
-    }
-    if (pps.empty()) pps.push_back(poa_params(*p));
-    sxg_poa_batch_in in;
-    memset(&in, 0, sizeof(in));
-    uint8_t dummy = 0;
-    in.n_blocks = (int32_t)nb; in.blk_off = B.blk_off.data(); in.seq_off = B.seq_off.data();
-    in.bases = B.bases.empty() ? &dummy : B.bases.data(); in.weights = B.weights.data(); in.params = pps.data();
-    in.per_block_params = p->adaptive_poa_params && nb > 0 ? 1 : 0;
-    in.want_consensus = p->add_consensus;
-    in.want_msa = mp ? 1 : 0;   // the MAF rows (and with them the merge / flip decisions) need the blocks' MSAs
-    sxg_poa_batch_out out;
-    memset(&out, 0, sizeof(out));
-    const int rc = run(ctx, &in, &out);
-    if (rc == SXG_NOT_ROOT) {   // multi-GPU provider (sxg_poa_batch_run_sharded) on a rank that does not lace: its share is done
-        if (fre) fre(&out);
-        return fail(SXG_NOT_ROOT, "not the lacing rank");
-    }
-    if (rc != SXG_OK) { if (fre) fre(&out); return fail(rc, "POA provider failed"); }
-    if (mp && nb > 0 && (!out.msa || !out.msa_off || !out.msa_cols)) { if (fre) fre(&out); return fail(SXG_E_INVALID, "POA provider returned no MSA"); }
-    lap("POA provider");
-    // phase 3: A9/A10 per block in parallel (the second half of the reference's loop), then the
-    // path_mapping rows (src/smooth.cpp:2277-2296)
+    // Phases 1-3 run over CHUNKS of blocks as a three-stage pipeline -- collect(c+1) and block graphs(c-1) on the OpenMP
+    // team while the POA provider works on chunk c in a thread of its own -- so that on batches of many small blocks (the
+    // reference's default -l 700...1100: thousands of ~1 kbp blocks, where the host phases outweigh the kernels) the GPU and
+    // the host cores are busy at the same time.  Blocks are independent (src/smooth.cpp:1931) and their results do not
+    // depend on what else is in a batch, so the output is the same for every chunking.  A batch below 2 x
+    // SXG_SMOOTH_CHUNK_BLOCKS blocks (default 2048; the headline's 1000 x 64 x 5 kbp) is ONE chunk: one provider call, as before.
     struct frag_t { uint64_t path, start, end; int64_t target, block; };
+    std::vector<collected_t> col((size_t)nb);
     std::vector<ograph_t> graphs((size_t)nb);
     std::vector<omap_t> block_mafs(mp ? (size_t)nb : 0);
     std::vector<char> groom(mp ? (size_t)nb : 0, 0);
     std::unordered_map<std::string, size_t> rank_of;
     for (size_t q = 0; q < g->pname.size(); ++q) rank_of[g->pname[q]] = q;
+    struct chunk_t {
+        int64_t k0 = 0, k1 = 0;
+        batch_t B;
+        std::vector<sxg_poa_params> pps;
+        sxg_poa_batch_in in;
+        sxg_poa_batch_out out;
+        uint8_t dummy = 0;
+        int rc = SXG_OK;
+    };
+    int64_t chunk_blocks = 2048;
+    if (const char* e = getenv("SXG_SMOOTH_CHUNK_BLOCKS")) chunk_blocks = std::max<int64_t>(1, atoll(e));
+    const int64_t nc = std::max<int64_t>(1, nb / chunk_blocks);
+    std::vector<chunk_t> chunks((size_t)nc);
+    for (int64_t c = 0; c < nc; ++c) { chunks[(size_t)c].k0 = nb * c / nc; chunks[(size_t)c].k1 = nb * (c + 1) / nc; }
+    double t_collect = 0, t_wait = 0, t_graphs = 0;
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    // stage 1: A2-A4 for every block of the chunk, in parallel over blocks as the reference's OpenMP loop
+    // (src/smooth.cpp:1931, schedule(dynamic,1)) up to :743; the flat batch is filled in place
+    auto prepare = [&](chunk_t& C) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int64_t k0 = C.k0, n = C.k1 - C.k0;
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int64_t k = 0; k < nb; ++k) {
-        if (col[(size_t)k].seqs.empty()) continue;
-        graphs[(size_t)k] = block_graph_from_out(col[(size_t)k], B, out, k, cons_name(*p, k), p->use_abpoa != 0);
-        if (mp) {   // MSA -> MAF rows of the block (src/smooth.cpp:782-905), and its grooming orientation (:1826-1842)
-            const collected_t& c = col[(size_t)k];
-            const size_t nrow = c.seqs.size() + (p->add_consensus ? 1 : 0), cols = (size_t)out.msa_cols[k];
-            std::vector<std::string> msa;
-            for (size_t r = 0; r < nrow; ++r) msa.emplace_back(out.msa + out.msa_off[k] + r * cols, cols);
-            const size_t cons_len = out.cons_off ? (size_t)(out.cons_off[k + 1] - out.cons_off[k]) : 0;
-            block_mafs[(size_t)k] = maf_block_map(maf_rows_from_msa(*g, b->blocks[(size_t)k], c, msa, cons_name(*p, k), cons_len));
-            groom[(size_t)k] = groom_flip(rank_of, graphs[(size_t)k], cons_name(*p, k)) ? 1 : 0;
+        for (int64_t k = k0; k < C.k1; ++k) col[(size_t)k] = collect(*g, b->blocks[(size_t)k], *p);
+        batch_t& B = C.B;
+        B.blk_off.assign((size_t)n + 1, 0);
+        for (int64_t k = 0; k < n; ++k) B.blk_off[(size_t)k + 1] = B.blk_off[(size_t)k] + (int32_t)col[(size_t)(k0 + k)].seqs.size();
+        const size_t ns = (size_t)B.blk_off[(size_t)n];
+        B.seq_off.assign(ns + 1, 0);
+        B.weights.assign(ns, 1);
+        for (int64_t k = 0; k < n; ++k)
+            for (size_t i = 0; i < col[(size_t)(k0 + k)].seqs.size(); ++i) {
+                const size_t sidx = (size_t)B.blk_off[(size_t)k] + i;
+                B.seq_off[sidx + 1] = B.seq_off[sidx] + (int64_t)col[(size_t)(k0 + k)].seqs[i].size();
+                B.weights[sidx] = col[(size_t)(k0 + k)].weights[i];
+            }
+        B.bases.resize((size_t)B.seq_off[ns]);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t k = 0; k < n; ++k)
+            for (size_t i = 0; i < col[(size_t)(k0 + k)].seqs.size(); ++i) {
+                const std::string& sq = col[(size_t)(k0 + k)].seqs[i];
+                uint8_t* dst = B.bases.data() + B.seq_off[(size_t)B.blk_off[(size_t)k] + i];
+                for (size_t x = 0; x < sq.size(); ++x) dst[x] = code_of(sq[x]);
+            }
+        // A14: with -a every block brings its own scores (the engine's per_block_params)
+        if (p->adaptive_poa_params) {
+            C.pps.resize((size_t)n);
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int64_t k = 0; k < n; ++k) C.pps[(size_t)k] = block_poa_params(*g, b->blocks[(size_t)(k0 + k)], *p);
         }
-        collected_t().seqs.swap(col[(size_t)k].seqs);   // the padded sequences are not needed any more
+        if (C.pps.empty()) C.pps.push_back(poa_params(*p));
+        memset(&C.in, 0, sizeof(C.in));
+        memset(&C.out, 0, sizeof(C.out));
+        C.in.n_blocks = (int32_t)n; C.in.blk_off = B.blk_off.data(); C.in.seq_off = B.seq_off.data();
+        C.in.bases = B.bases.empty() ? &C.dummy : B.bases.data(); C.in.weights = B.weights.data(); C.in.params = C.pps.data();
+        C.in.per_block_params = p->adaptive_poa_params && n > 0 ? 1 : 0;
+        C.in.want_consensus = p->add_consensus;
+        C.in.want_msa = mp ? 1 : 0;   // the MAF rows (and with them the merge / flip decisions) need the blocks' MSAs
+        t_collect += since(t0);
+    };
+    // stage 2: ONE batched POA call per chunk (replaces src/smooth.cpp:752-786 of every block)
+    auto call = [&](chunk_t* C) { C->rc = run(ctx, &C->in, &C->out); };
+    // stage 3: A9/A10 per block in parallel (the second half of the reference's loop)
+    auto finish = [&](chunk_t& C) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const sxg_poa_batch_out& out = C.out;
+        const int64_t k0 = C.k0;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t k = C.k0; k < C.k1; ++k) {
+            if (col[(size_t)k].seqs.empty()) continue;
+            const int64_t slot = k - k0;
+            graphs[(size_t)k] = block_graph_from_out(col[(size_t)k], C.B, out, slot, cons_name(*p, k), p->use_abpoa != 0);
+            if (mp) {   // MSA -> MAF rows of the block (src/smooth.cpp:782-905), and its grooming orientation (:1826-1842)
+                const collected_t& c = col[(size_t)k];
+                const size_t nrow = c.seqs.size() + (p->add_consensus ? 1 : 0), cols = (size_t)out.msa_cols[slot];
+                std::vector<std::string> msa;
+                for (size_t r = 0; r < nrow; ++r) msa.emplace_back(out.msa + out.msa_off[slot] + r * cols, cols);
+                const size_t cons_len = out.cons_off ? (size_t)(out.cons_off[slot + 1] - out.cons_off[slot]) : 0;
+                block_mafs[(size_t)k] = maf_block_map(maf_rows_from_msa(*g, b->blocks[(size_t)k], c, msa, cons_name(*p, k), cons_len));
+                groom[(size_t)k] = groom_flip(rank_of, graphs[(size_t)k], cons_name(*p, k)) ? 1 : 0;
+            }
+            collected_t().seqs.swap(col[(size_t)k].seqs);   // the padded sequences are not needed any more
+        }
+        t_graphs += since(t0);
+    };
+    {
+        bool not_root = false;
+        int fail_rc = SXG_OK;
+        std::string fail_msg;
+        std::thread worker;
+        prepare(chunks[0]);
+        if (nc > 1) worker = std::thread(call, &chunks[0]); else call(&chunks[0]);
+        for (int64_t c = 0; c < nc; ++c) {
+            chunk_t& C = chunks[(size_t)c];
+            if (c + 1 < nc) prepare(chunks[(size_t)c + 1]);
+            const auto tw = std::chrono::steady_clock::now();
+            if (worker.joinable()) worker.join();
+            t_wait += since(tw);
+            // (every chunk reaches the provider even after a failure or on a rank that does not lace: a sharded provider is
+            //  a collective, the other ranks are in the same call)
+            if (c + 1 < nc) worker = std::thread(call, &chunks[(size_t)c + 1]);
+            if (C.rc == SXG_NOT_ROOT) not_root = true;   // multi-GPU provider (sxg_poa_batch_run_sharded) on a rank that does not lace
+            else if (C.rc != SXG_OK) { if (fail_rc == SXG_OK) { fail_rc = C.rc; fail_msg = "POA provider failed"; } }
+            else if (mp && C.k1 > C.k0 && (!C.out.msa || !C.out.msa_off || !C.out.msa_cols)) { if (fail_rc == SXG_OK) { fail_rc = SXG_E_INVALID; fail_msg = "POA provider returned no MSA"; } }
+            else if (fail_rc == SXG_OK && !not_root) finish(C);
+            if (fre) fre(&C.out);
+            batch_t().bases.swap(C.B.bases);
+        }
+        if (fail_rc != SXG_OK) return fail(fail_rc, fail_msg);
+        if (not_root) return fail(SXG_NOT_ROOT, "not the lacing rank");
     }
-    if (fre) fre(&out);
+    if (timing) {
+        fprintf(stderr, "[sxg_smooth] %-22s %.3f s  (%lld chunk%s; collect %.3f s, waiting for the POA provider %.3f s, block graphs %.3f s)\n",
+                "collect|POA|graphs", since(T0), (long long)nc, nc == 1 ? "" : "s, pipelined", t_collect, t_wait, t_graphs);
+        T0 = std::chrono::steady_clock::now();
+    }
     // the in-order MAF consumer: merges contiguous blocks, decides which block graphs get flipped (-M), writes the MAF
     merge_state_t mstate;
     if (mp) {
@@ -1629,7 +1679,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         sublap("free S.edges");
         { std::vector<collected_t> x; x.swap(col); }
         sublap("free collected");
-        { batch_t x; std::swap(x, B); }
+        { std::vector<chunk_t> x; x.swap(chunks); }
         sublap("free batch");
         { std::vector<frag_t> x; x.swap(mapping); }
         lap("teardown");

@@ -282,6 +282,27 @@ def test_three_chained_iterations_on_a_synthetic_graph(prov):
     assert sum(nm.startswith("Consensus_") for nm in SO.Graph(text).pname) >= 1
 
 
+@pytest.mark.parametrize("chunk", ["1", "3", "7"])
+def test_chunked_pipeline_gives_the_same_bytes(prov, monkeypatch, chunk):
+    """Phases 1-3 run as a pipeline over chunks of blocks (collect / POA provider in its own thread / block graphs): the
+    GFA, the MAF text and the flip set are the same for every chunk size -- here 1, 3 and 7 blocks per chunk against one
+    chunk, with consensus paths, adaptive scores, and the in-order MAF consumer with merging."""
+    text = synthetic_gfa(31, n_paths=6, n_nodes=140)
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 120)
+    blocks = SO.blockset_by_path_windows(g, 120)
+    assert len(blocks) >= 12
+    p = S.default_params(add_consensus=1, adaptive_poa_params=1, kmer_size=5)
+    monkeypatch.setenv("SXG_SMOOTH_CHUNK_BLOCKS", "1000000")
+    one = sm.smooth_gfa(p, prov.provider())
+    one_maf = sm.smooth_maf_gfa(p, prov.provider(), merge_blocks=True, jaccard=0.5)
+    assert one == SO.smooth(g, blocks, add_consensus=True, adaptive=True, kmer_size=5)
+    monkeypatch.setenv("SXG_SMOOTH_CHUNK_BLOCKS", chunk)
+    assert sm.smooth_gfa(p, prov.provider()) == one
+    got = sm.smooth_maf_gfa(p, prov.provider(), merge_blocks=True, jaccard=0.5)
+    assert got[0] == one_maf[0] and got[1] == one_maf[1] and got[2] == one_maf[2]
+
+
 def test_drb1_chain_fixture_is_well_formed():
     import json
     j = json.load(open(os.path.join(os.path.dirname(DRB1), "drb1_chain.json")))
