@@ -42,11 +42,13 @@
 extern "C" {
 #endif
 
-/* 3: params.banded = 2 (adaptive band); sxg_poa_batch_run_sharded fails on all ranks together and needs the exchange buffer
+/* 4: block graphs on the device: sxg_poa_batch_in gained want_block_graph / bg_consensus_visited_only / bg_trim at its END
+ *    (callers must zero-initialise the struct, as before), sxg_poa_batch_out the bg_* arrays before _owner; stats.bg_ms.
+ * 3: params.banded = 2 (adaptive band); sxg_poa_batch_run_sharded fails on all ranks together and needs the exchange buffer
  *    that sxg_poa_comm_init / _attach allocate; a band miss is repaired inside the engine at any length.
  * 2 (round 2, never numbered): params.reserved became params.banded -- callers must zero it --, stats.reserved became
  *    dom_clock_mhz, status 7 (SXG_ST_BAND_MISS), SXG_POA_MAX_SEQ_LEN 12287 -> 26623 with SXG_POA_MAX_SEQ_LEN_WIDE. */
-#define SXG_POA_ABI_VERSION 3
+#define SXG_POA_ABI_VERSION 4
 
 #define SXG_MODE_LOCAL 0  /* spoa::AlignmentType::kSW */
 #define SXG_MODE_GLOBAL 1 /* spoa::AlignmentType::kNW */
@@ -110,6 +112,18 @@ typedef struct sxg_poa_batch_in {
     int32_t per_block_params;
     int32_t want_consensus; /* GenerateConsensus(), src/smooth.cpp:773 */
     int32_t want_msa;       /* GenerateMultipleSequenceAlignment(), src/smooth.cpp:785 */
+    /* ABI 4.  The NORMALISED BLOCK GRAPH of every block, computed on the device right after the block's chain of
+     * alignments: what smooth_spoa returns to its caller (src/smooth.cpp:931-1010) -- build_odgi_SPOA (:2576-2654: one
+     * node per POA node, a path per sequence with bg_trim[b] = poa_padding steps trimmed at both ends, consensus path,
+     * nodes no path visits dropped), only path-supported edges (:980-994), unchop (:935) and the topological re-numbering
+     * (:947), the last two by the decrees of DESIGN.md section 9 (odgi is absent from the reference snapshot).
+     *   0 = off (the caller builds block graphs from the raw POA results);
+     *   1 = bg_* arrays of the result are filled in addition to the raw results;
+     *   2 = ... and seq_path_nodes (one node id per base: two thirds of the download) is left out (NULL). */
+    int32_t want_block_graph;
+    int32_t bg_consensus_visited_only; /* 1 = the consensus path keeps only nodes some sequence path visits (build_odgi_abPOA,
+                                          src/smooth.cpp:2542-2548); 0 = every consensus node (build_odgi_SPOA, :2624-2627) */
+    const int32_t *bg_trim;            /* [n_blocks] poa_padding of every block (src/smooth.cpp:2611); NULL = 0 */
 } sxg_poa_batch_in;
 
 /* Per-block POA results, dense and block-major.  Node ids are block-local, 0-based, in
@@ -136,6 +150,24 @@ typedef struct sxg_poa_batch_out {
     int64_t *msa_off;        /* [n_blocks+1] byte offsets into msa (NULL unless want_msa) */
     int32_t *msa_cols;       /* [n_blocks] columns; rows = #seqs (+1 consensus row if wanted) */
     char *msa;               /* row-major 'A','C','G','T','N','-' (GAP_CHAR, src/smooth.cpp:8-11) */
+    /* Block graphs (in->want_block_graph; NULL otherwise).  Node ids are block-local, 0-based, in the block graph's final
+     * order -- topological: Kahn over the edges, smallest id first (decree of DESIGN.md section 9) --, so every edge runs
+     * forward-to-forward from a lower to a higher id and the edges listed per tail, heads ascending, ARE the L lines of
+     * the block graph in their order.  A path per (dedup'd) input sequence in the orientation it was aligned in: the caller
+     * reverses + flips it for ranges it collected in reverse (src/smooth.cpp:2612-2615) and repeats it for duplicates
+     * (:2598-2602).  A failed block has no nodes. */
+    int64_t *bg_node_off;     /* [n_blocks+1] */
+    int32_t *bg_node_len;     /* [nodes] bases of every node */
+    int32_t *bg_node_outdeg;  /* [nodes] out-degree: the edges of the nodes follow one another in bg_edge_to (CSR order) */
+    uint8_t *bg_node_indeg;   /* [nodes] in-degree, saturating at 255 */
+    int64_t *bg_seq_off;      /* [n_blocks+1] where the block's node sequences start in bg_seq */
+    char *bg_seq;             /* node sequences back to back in node order, 'A','C','G','T','N' */
+    int64_t *bg_edge_off;     /* [n_blocks+1] */
+    int32_t *bg_edge_to;      /* [edges] head of every edge, ascending per tail */
+    int64_t *bg_step_off;     /* [n_seqs+1] */
+    int32_t *bg_steps;        /* node id of every step of every sequence path */
+    int64_t *bg_cons_off;     /* [n_blocks+1] (NULL unless want_consensus) */
+    int32_t *bg_cons_steps;   /* steps of the consensus path */
     void *_owner;
 } sxg_poa_batch_out;
 
@@ -183,6 +215,7 @@ typedef struct sxg_poa_stats {
     int32_t dom_threads, dom_cols_per_lane; /* launch geometry */
     int32_t dom_row_mode;  /* 0/1 = 32-bit sweep (int16 / int32 row words), 2 = packed-int16 sweep, 3 = banded packed sweep */
     int32_t dom_clock_mhz; /* shader clock that launch ran at (cycles of its slots / their 100 MHz wall ticks); 0 = unknown */
+    double bg_ms;          /* HIP-event time of the block-graph kernel (want_block_graph), not part of kernel_ms */
 } sxg_poa_stats;
 
 int sxg_poa_abi_version(void);

@@ -448,7 +448,11 @@ def unchop(G):
         last_of.append(last)
     ne = set()
     for (a, b) in G.edges:
+        # the merged link u+ -> v+ goes away, in whichever canonical form it is stored: (u+, v+) or, when u > v, (v-, u-)
+        # (round 4: the second form used to survive as a self loop of the merged node)
         if not (a & 1) and not (b & 1) and nxt[a >> 1] == (b >> 1):
+            continue
+        if (a & 1) and (b & 1) and nxt[b >> 1] == (a >> 1):
             continue
         ne.add(OGraph.canon((chain_of[a >> 1] << 1) | (a & 1), (chain_of[b >> 1] << 1) | (b & 1)))
     for k, (name, st) in enumerate(G.paths):
@@ -465,13 +469,17 @@ def unchop(G):
 
 
 def topo_renumber(G):
-    """Decree: Kahn over forward-forward edges, smallest node first; leftovers in id order."""
+    """Decree: Kahn over the edges between forward nodes in their walking direction, smallest node first; leftovers in
+    id order.  The canonical form (a-, b-) is the edge b+ -> a+ (round 4: such edges used to be left out, so the order
+    was not topological whenever an edge ran from a higher to a lower id)."""
     n = len(G.seq)
     succ, indeg = [[] for _ in range(n)], [0] * n
     for (a, b) in sorted(G.edges):
-        if not (a & 1) and not (b & 1) and (a >> 1) != (b >> 1):
-            succ[a >> 1].append(b >> 1)
-            indeg[b >> 1] += 1
+        if (a & 1) != (b & 1) or (a >> 1) == (b >> 1):
+            continue
+        t, h = ((b >> 1), (a >> 1)) if (a & 1) else ((a >> 1), (b >> 1))
+        succ[t].append(h)
+        indeg[h] += 1
     heap = [u for u in range(n) if not indeg[u]]
     heapq.heapify(heap)
     newid, k = [-1] * n, 0

@@ -662,6 +662,10 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     // adaptive band (B4): the sweep left every row's band -- first | last strip << 16 -- in word 6 of its descriptor
     const bool ada = BANDED && __builtin_amdgcn_readfirstlane(B.band_mode) == 2;
     const int HW = ada ? 6 : 7;   // descriptor word that says which strips the row kept
+    // The adaptive sweep rewrote words 6, 7 of every row descriptor with device-scope (sc1) stores; the chunk the sweep
+    // staged earlier may still sit in this CU's L1, and __syncthreads does not invalidate it: drop the L1 copies once per
+    // walk (buffer_inv sc1) so that the plain loads below see the band words the sweep left.
+    if (ada) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // is strip s of a row with band hint `hint` kept in the plane?
     auto kept = [&](int hint, int s) -> bool {
         if (BANDED) {

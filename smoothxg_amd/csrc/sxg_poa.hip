@@ -25,6 +25,7 @@
 #include "poa_dp16.hip.h"
 #include "poa_band16.hip.h"
 #include "poa_graph_dev.h"
+#include "poa_bgraph_dev.h"
 
 using namespace sxg;
 
@@ -415,6 +416,73 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Block graphs (sxg_poa_batch_in::want_block_graph): after the POA kernels, one workgroup per block turns the block's POA
+// result -- letters, edges, one node id per base, consensus -- into its normalised block graph (poa_bgraph_dev.h: trim,
+// path-supported edges, unchop, topological re-numbering, compact step lists) in a slot-private scratch arena.
+struct BgArgs {
+    const int32_t* blk_off; const int64_t* seq_off; const uint8_t* bases; const int32_t* paths;
+    const uint8_t* node_code; const int32_t* edge_tail; const int32_t* edge_head; const int32_t* cons;
+    const int32_t *nn, *ne, *nc; const int32_t* trim; int cons_mode;
+    const int32_t* work; int n_work; int32_t* queue;
+    uint8_t* arena; size_t slot_bytes; int capV, capE, capC, capT;
+    const int64_t *node_o, *edge_o;   // where block b's nodes / edges go in the output arrays
+    int32_t *o_len, *o_outdeg; uint8_t* o_indeg; char* o_seq; int32_t* o_eto; int32_t* o_steps; int32_t* o_nsteps;
+    int32_t* o_cons; int32_t* o_counts;
+};
+constexpr int BG_THREADS = 256, BG_HEAP = 3072;
+static size_t bg_slot_bytes(int capV, int capE, int capC, int capT) {
+    return 4 * (27 * ((size_t)capV + 2) + 3 * ((size_t)capE + capC + 2) + ((size_t)capC + 2) + ((size_t)capT + 2) + 4) + 256;
+}
+struct BgCtx : WgCtx {
+    int* hp;
+    __device__ __forceinline__ int load_fresh(const int32_t* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ int* heap() const { return hp; }
+    __device__ __forceinline__ int heap_cap() const { return BG_HEAP; }
+};
+__global__ __launch_bounds__(BG_THREADS) void block_graph_kernel(const BgArgs A) {
+    __shared__ int s_scan[64];
+    __shared__ int s_heap[BG_HEAP];
+    __shared__ int s_work;
+    BgCtx ctx;
+    ctx.lds = (sxg_lds_int*)s_scan;
+    ctx.hp = s_heap;
+    const int t = threadIdx.x;
+    int32_t* w = (int32_t*)(A.arena + (size_t)blockIdx.x * A.slot_bytes);
+    const size_t C = (size_t)A.capV + 2, EC = (size_t)A.capE + A.capC + 2;
+    BgScratch W;
+    auto take = [&](size_t n) { int32_t* q = w; w += n; return q; };
+    W.vis = take(C); W.front = take(C); W.back = take(C); W.ecnt = take(C); W.eoff = take(C);
+    W.ehead = take(EC); W.eused = take(EC);
+    W.outdeg = take(C); W.indeg = take(C); W.only = take(C); W.nxt = take(C); W.prv = take(C);
+    W.pj0 = take(C); W.pj1 = take(C); W.pd0 = take(C); W.pd1 = take(C); W.cid = take(C);
+    W.head_of = take(C); W.tail_of = take(C); W.clen = take(C); W.indc = take(C); W.coff = take(C); W.newid = take(C);
+    W.csucc = take(EC); W.cc = take((size_t)A.capC + 2); W.tmp = take((size_t)A.capT + 2);
+    W.lenN = take(C); W.odN = take(C); W.soffN = take(C); W.eoffN = take(C); W.flag = take(4);
+    for (;;) {
+        __syncthreads();
+        if (t == 0) s_work = atomicAdd(A.queue, 1);
+        __syncthreads();
+        const int wi = s_work;
+        if (wi >= A.n_work) break;
+        const int b = A.work[wi];
+        const int s0 = A.blk_off[b], s1 = A.blk_off[b + 1];
+        const int64_t base0 = A.seq_off[s0];
+        BgIn I;
+        I.node_code = A.node_code + base0; I.V = A.nn[b]; I.E = A.ne[b];
+        I.e_tail = A.edge_tail + base0; I.e_head = A.edge_head + base0;
+        I.paths = A.paths + base0; I.bases = A.bases + base0; I.seq_off = A.seq_off; I.s0 = s0; I.s1 = s1;
+        I.trim = A.trim ? A.trim[b] : 0;
+        I.cons = A.cons ? A.cons + base0 : nullptr; I.n_cons = A.cons ? A.nc[b] : 0; I.cons_mode = A.cons ? A.cons_mode : 0;
+        BgOut O;
+        const int64_t no = A.node_o[b], eo = A.edge_o[b];
+        O.node_len = A.o_len + no; O.node_outdeg = A.o_outdeg + no; O.node_indeg = A.o_indeg + no; O.seq = A.o_seq + no;
+        O.eto = A.o_eto + eo; O.steps = A.o_steps + base0; O.nsteps = A.o_nsteps + s0; O.cons_steps = A.o_cons + no;
+        O.counts = A.o_counts + (size_t)BGC_N * b;
+        block_graph(ctx, I, W, O);
+    }
+}
+
 // dense <- worst-case gather (one workgroup per block, grid-stride over blocks)
 template <class Tv>
 __global__ void gather_kernel(const Tv* __restrict__ src, Tv* __restrict__ dst, const int64_t* __restrict__ src_off,
@@ -429,8 +497,18 @@ __global__ void gather_kernel(const Tv* __restrict__ src, Tv* __restrict__ dst, 
 // host side
 // =======================================================================================
 
+// Error text: per calling thread (as the header promises) plus the most recent one of ANY thread -- a caller that ran the
+// engine on a worker thread (sxg_smooth's chunk pipeline) and asks from its own thread gets that one instead of nothing.
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#include <mutex>
+static std::mutex g_err_mu;
+static std::string g_err_any;
+static thread_local std::string g_err_ret;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    { std::lock_guard<std::mutex> lk(g_err_mu); g_err_any = msg; }
+    return code;
+}
 #define HIPCHK(x)                                                                              \
     do {                                                                                       \
         hipError_t _e = (x);                                                                   \
@@ -617,6 +695,7 @@ struct BlockMeta {
     int maxlen = 0, nseq = 0, rm = 0; bool fits = false; Variant variant{16, 1, 256, 0};
     int tier = 0;      // arena capacity tier the block runs at next (raised by ROWS/POOL/TBX overflow only)
     bool wide_band = false;   // packed sweep re-run with a traceback plane that keeps EVERY strip (after ST_BAND_MISS)
+    bool no_wide = false;     // that plane did not fit the arena budget: the block takes the widening ladder instead
     int64_t sumlen = 0;
     double cost = 0;
     bool cvx = false, sw = true;
@@ -650,6 +729,13 @@ struct sxg_poa_handle {
     DevBuf d_status, d_nn, d_ne, d_nc, d_node_code, d_node_rank, d_node_group, d_edge_tail, d_edge_head, d_edge_w,
         d_paths, d_score, d_cells, d_cons, d_work, d_queue, d_arena;
     DevBuf d_tmp_a, d_tmp_b, d_tmp_c, d_tmp_d;
+    // block graphs (want_block_graph): inputs, outputs in per-block layouts, the per-block counts of the last execute
+    int want_block_graph = 0, bg_cons_visited_only = 0;
+    bool bg_done = false;
+    DevBuf d_trim, d_bg_no, d_bg_eo, d_bg_len, d_bg_od, d_bg_id, d_bg_seq, d_bg_eto, d_bg_steps, d_bg_nsteps, d_bg_cons, d_bg_counts,
+        d_bg_work, d_bg_queue, d_bg_arena;
+    std::vector<int64_t> bg_node_o, bg_edge_o;
+    std::vector<int32_t> bg_counts;
     sxg_poa_stats stats{};
     // multi-GPU (sxg_poa_batch_run_sharded): communicator of this rank, result blob of the local shard, and -- on the
     // root -- the blobs of the other ranks, delivered by RCCL
@@ -668,7 +754,11 @@ struct sxg_poa_handle {
 };
 
 extern "C" int sxg_poa_abi_version(void) { return SXG_POA_ABI_VERSION; }
-extern "C" const char* sxg_poa_last_error(void) { return g_err.c_str(); }
+extern "C" const char* sxg_poa_last_error(void) {
+    if (!g_err.empty()) return g_err.c_str();
+    { std::lock_guard<std::mutex> lk(g_err_mu); g_err_ret = g_err_any; }
+    return g_err_ret.c_str();
+}
 extern "C" int sxg_poa_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -703,7 +793,9 @@ static void release_all(sxg_poa_handle* h) {
     DevBuf* bufs[] = {&h->d_blk_off, &h->d_seq_off, &h->d_bases, &h->d_weights, &h->d_params, &h->d_status, &h->d_nn,
                       &h->d_ne, &h->d_nc, &h->d_node_code, &h->d_node_rank, &h->d_node_group, &h->d_edge_tail,
                       &h->d_edge_head, &h->d_edge_w, &h->d_paths, &h->d_score, &h->d_cells, &h->d_cons, &h->d_work,
-                      &h->d_queue, &h->d_arena, &h->d_tmp_a, &h->d_tmp_b, &h->d_tmp_c, &h->d_tmp_d};
+                      &h->d_queue, &h->d_arena, &h->d_tmp_a, &h->d_tmp_b, &h->d_tmp_c, &h->d_tmp_d, &h->d_trim, &h->d_bg_no, &h->d_bg_eo,
+                      &h->d_bg_len, &h->d_bg_od, &h->d_bg_id, &h->d_bg_seq, &h->d_bg_eto, &h->d_bg_steps, &h->d_bg_nsteps, &h->d_bg_cons,
+                      &h->d_bg_counts, &h->d_bg_work, &h->d_bg_queue, &h->d_bg_arena};
     for (DevBuf* b : bufs) b->release();
 }
 
@@ -774,6 +866,10 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     }
     h->n_blocks = nb; h->n_seqs = ns; h->n_bases = nbases;
     h->want_consensus = in->want_consensus; h->want_msa = in->want_msa;
+    h->want_block_graph = in->want_block_graph < 0 || in->want_block_graph > 2 ? 0 : in->want_block_graph;
+    if (h->want_block_graph == 2 && in->want_msa) h->want_block_graph = 1;   // (the MSA is formatted from the per-base paths)
+    h->bg_cons_visited_only = in->bg_consensus_visited_only ? 1 : 0;
+    h->bg_done = false;
     h->per_block_params = in->per_block_params;
     h->h_blk_off.assign(in->blk_off, in->blk_off + nb + 1);
     h->h_seq_off.assign(in->seq_off, in->seq_off + ns + 1);
@@ -834,6 +930,15 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     if (h->has_weights) {
         if ((rc = h->d_weights.ensure(4 * (size_t)std::max<int64_t>(ns, 1)))) return rc;
         if (ns) HIPCHK(hipMemcpyAsync(h->d_weights.p, in->weights, 4 * (size_t)ns, hipMemcpyHostToDevice, h->stream));
+    }
+    if (h->want_block_graph) {
+        std::vector<int32_t> trim((size_t)std::max(nb, 1), 0);
+        for (int b = 0; b < nb; ++b) {
+            trim[b] = in->bg_trim ? in->bg_trim[b] : 0;
+            if (trim[b] < 0) return fail(SXG_E_INVALID, "bg_trim must not be negative");
+        }
+        if ((rc = h->d_trim.ensure(4 * trim.size()))) return rc;
+        HIPCHK(hipMemcpy(h->d_trim.p, trim.data(), 4 * trim.size(), hipMemcpyHostToDevice));
     }
     const size_t NB = (size_t)std::max<int64_t>(nbases, 1), NS = (size_t)std::max<int64_t>(ns, 1), NBL = (size_t)std::max(nb, 1);
     if ((rc = h->d_status.ensure(4 * NBL)) || (rc = h->d_nn.ensure(4 * NBL)) || (rc = h->d_ne.ensure(4 * NBL)) ||
@@ -1061,6 +1166,82 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
     return SXG_OK;
 }
 
+// A9 + A10 of every block on the device (block_graph_kernel), after the batch's alignments: outputs in per-block
+// layouts (nodes: prefix of the POA node counts, edges: prefix of POA edges + consensus nodes, steps: the input layout).
+static int run_block_graphs(sxg_poa_handle* h, std::vector<int32_t>& status) {
+    const int nb = h->n_blocks;
+    h->bg_done = false;
+    std::vector<int32_t> nn(std::max(nb, 1), 0), ne(std::max(nb, 1), 0), nc(std::max(nb, 1), 0);
+    if (nb) {
+        HIPCHK(hipMemcpy(nn.data(), h->d_nn.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ne.data(), h->d_ne.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(nc.data(), h->d_nc.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+    }
+    h->bg_node_o.assign((size_t)nb + 1, 0); h->bg_edge_o.assign((size_t)nb + 1, 0);
+    int capV = 1, capE = 1, capC = 1, capT = 1;
+    std::vector<int32_t> work;
+    for (int b = 0; b < nb; ++b) {
+        const bool ok = status[b] == ST_OK && h->meta[b].nseq > 0;
+        const int cn = h->want_consensus ? nc[b] : 0;
+        h->bg_node_o[(size_t)b + 1] = h->bg_node_o[(size_t)b] + (ok ? nn[b] : 0);
+        h->bg_edge_o[(size_t)b + 1] = h->bg_edge_o[(size_t)b] + (ok ? ne[b] + cn : 0);
+        if (!ok) continue;
+        work.push_back(b);
+        capV = std::max(capV, nn[b]); capE = std::max(capE, ne[b]); capC = std::max(capC, cn);
+        capT = std::max(capT, std::max(std::max(nn[b], h->meta[b].maxlen), cn));
+    }
+    std::stable_sort(work.begin(), work.end(), [&](int a, int b) { return h->meta[a].sumlen > h->meta[b].sumlen; });
+    const size_t NT = (size_t)std::max<int64_t>(h->bg_node_o[(size_t)nb], 1), ET = (size_t)std::max<int64_t>(h->bg_edge_o[(size_t)nb], 1);
+    const size_t NB = (size_t)std::max<int64_t>(h->n_bases, 1), NS = (size_t)std::max<int64_t>(h->n_seqs, 1), NBL = (size_t)std::max(nb, 1);
+    int rc;
+    if ((rc = h->d_bg_no.ensure(8 * (NBL + 1))) || (rc = h->d_bg_eo.ensure(8 * (NBL + 1))) || (rc = h->d_bg_len.ensure(4 * NT)) ||
+        (rc = h->d_bg_od.ensure(4 * NT)) || (rc = h->d_bg_id.ensure(NT)) || (rc = h->d_bg_seq.ensure(NT)) || (rc = h->d_bg_eto.ensure(4 * ET)) ||
+        (rc = h->d_bg_steps.ensure(4 * NB)) || (rc = h->d_bg_nsteps.ensure(4 * NS)) || (rc = h->d_bg_cons.ensure(4 * NT)) ||
+        (rc = h->d_bg_counts.ensure(4 * (size_t)BGC_N * NBL)) || (rc = h->d_bg_work.ensure(4 * std::max<size_t>(work.size(), 1))) ||
+        (rc = h->d_bg_queue.ensure(256)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(h->d_bg_no.p, h->bg_node_o.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_bg_eo.p, h->bg_edge_o.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_bg_counts.p, 0, 4 * (size_t)BGC_N * NBL, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_bg_nsteps.p, 0, 4 * NS, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_bg_queue.p, 0, 256, h->stream));
+    if (!work.empty()) {
+        HIPCHK(hipMemcpyAsync(h->d_bg_work.p, work.data(), 4 * work.size(), hipMemcpyHostToDevice, h->stream));
+        const size_t slot = bg_slot_bytes(capV, capE, capC, capT);
+        int per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)block_graph_kernel, BG_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        int64_t slots = std::min<int64_t>((int64_t)work.size(), (int64_t)h->num_cu * per_cu);
+        slots = std::max<int64_t>(1, std::min<int64_t>(slots, (int64_t)(arena_budget(h) / slot)));
+        if ((rc = h->d_bg_arena.ensure((size_t)slots * slot))) return rc;
+        BgArgs A;
+        A.blk_off = h->d_blk_off.as<int32_t>(); A.seq_off = h->d_seq_off.as<int64_t>(); A.bases = h->d_bases.as<uint8_t>();
+        A.paths = h->d_paths.as<int32_t>(); A.node_code = h->d_node_code.as<uint8_t>(); A.edge_tail = h->d_edge_tail.as<int32_t>();
+        A.edge_head = h->d_edge_head.as<int32_t>(); A.cons = h->want_consensus ? h->d_cons.as<int32_t>() : nullptr;
+        A.nn = h->d_nn.as<int32_t>(); A.ne = h->d_ne.as<int32_t>(); A.nc = h->d_nc.as<int32_t>(); A.trim = h->d_trim.as<int32_t>();
+        A.cons_mode = h->bg_cons_visited_only ? 2 : 1;
+        A.work = h->d_bg_work.as<int32_t>(); A.n_work = (int)work.size(); A.queue = h->d_bg_queue.as<int32_t>();
+        A.arena = h->d_bg_arena.as<uint8_t>(); A.slot_bytes = slot; A.capV = capV; A.capE = capE; A.capC = capC; A.capT = capT;
+        A.node_o = h->d_bg_no.as<int64_t>(); A.edge_o = h->d_bg_eo.as<int64_t>();
+        A.o_len = h->d_bg_len.as<int32_t>(); A.o_outdeg = h->d_bg_od.as<int32_t>(); A.o_indeg = h->d_bg_id.as<uint8_t>();
+        A.o_seq = h->d_bg_seq.as<char>(); A.o_eto = h->d_bg_eto.as<int32_t>(); A.o_steps = h->d_bg_steps.as<int32_t>();
+        A.o_nsteps = h->d_bg_nsteps.as<int32_t>(); A.o_cons = h->d_bg_cons.as<int32_t>(); A.o_counts = h->d_bg_counts.as<int32_t>();
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        hipLaunchKernelGGL(block_graph_kernel, dim3((unsigned)slots), dim3(BG_THREADS), 0, h->stream, A);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!work.empty()) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->stats.bg_ms = ms; }
+    h->bg_counts.assign((size_t)BGC_N * NBL, 0);
+    if (nb) HIPCHK(hipMemcpy(h->bg_counts.data(), h->d_bg_counts.p, 4 * (size_t)BGC_N * (size_t)nb, hipMemcpyDeviceToHost));
+    bool changed = false;
+    for (int b : work)
+        if (h->bg_counts[(size_t)BGC_N * b + BGC_STATUS] != ST_OK) { status[b] = ST_INTERNAL; changed = true; }
+    if (changed) HIPCHK(hipMemcpy(h->d_status.p, status.data(), 4 * (size_t)nb, hipMemcpyHostToDevice));
+    h->bg_done = true;
+    return SXG_OK;
+}
+
 extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
     if (!h) return fail(SXG_E_INVALID, "handle is NULL");
     if (!h->have_batch) return fail(SXG_E_INVALID, "no batch uploaded");
@@ -1145,7 +1326,13 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         // A geometry whose single arena does not fit the budget fails ITS blocks (per-block status, as the
         // ABI promises) and the rest of the batch goes on.
         for (size_t i = 0; i < plans.size();) {
-            if ((uint64_t)plans[i].lay.total > budget) {
+            if ((uint64_t)plans[i].lay.total > budget && plans[i].wide_band) {
+                // the every-strip plane (rows x columns dwords) is what does not fit: these blocks are not final -- their
+                // status stays ST_BAND_MISS and the round's bookkeeping below sends them down the widening ladder
+                // (packed -> 32-bit sweep, one byte per cell), which is where a band miss went before the wide plane existed
+                for (int b : plans[i].work) { h->meta[b].wide_band = false; h->meta[b].no_wide = true; }
+                plans.erase(plans.begin() + (long)i);
+            } else if ((uint64_t)plans[i].lay.total > budget) {
                 for (int b : plans[i].work) status[b] = plans[i].tier >= 2 ? ST_POOL_OVERFLOW : ST_ROWS_OVERFLOW;
                 g_err = "memory budget too small for a block arena of " + std::to_string(plans[i].lay.total) + " bytes";
                 nomem_blocks.insert(nomem_blocks.end(), plans[i].work.begin(), plans[i].work.end());
@@ -1237,7 +1424,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             if (std::find(nomem_blocks.begin(), nomem_blocks.end(), b) != nomem_blocks.end()) continue;
             if (status[b] == ST_ROWS_OVERFLOW || status[b] == ST_POOL_OVERFLOW || status[b] == ST_TBX_OVERFLOW || status[b] == ST_NODES_OVERFLOW) {
                 if (m.tier < 3) { m.tier += 1; again.push_back(b); }
-            } else if (status[b] == ST_BAND_MISS && m.rm == 2 && !m.wide_band) {
+            } else if (status[b] == ST_BAND_MISS && m.rm == 2 && !m.wide_band && !m.no_wide) {
                 // The traceback kept leaving the ~1100 columns the plane holds around the backbone hints (a structural variant
                 // that carries the alignment further off).  The same packed sweep is repeated with a plane that keeps EVERY
                 // strip of every row -- rows x columns dwords, up to ~6 GB for a 26 kbp block, but it cannot miss, it covers
@@ -1293,6 +1480,11 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
     h->stats.cells = total;
     h->stats.algo_bytes = bytes;
     h->executed = true;
+    if (h->want_block_graph) {
+        int rc = run_block_graphs(h, status);
+        if (rc) return rc;
+        lap("block graphs");
+    }
     for (int b = 0; b < nb; ++b)
         if (status[b] != ST_OK) return fail(SXG_E_BLOCK, "block " + std::to_string(b) + " failed with status " + std::to_string(status[b]));
     return SXG_OK;
@@ -1332,6 +1524,10 @@ struct OutOwner {
     hvec<uint32_t> edge_weight;
     std::vector<uint64_t> cells;
     std::vector<char> msa;
+    // block graphs
+    std::vector<int64_t> bg_node_off, bg_seq_off, bg_edge_off, bg_step_off, bg_cons_off;
+    hvec<int32_t> bg_node_len, bg_node_outdeg, bg_edge_to, bg_steps, bg_cons_steps;
+    hvec<uint8_t> bg_node_indeg, bg_seq;
 };
 
 template <class Tv>
@@ -1397,11 +1593,55 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
     GD(uint32_t, h->d_edge_w, o->edge_off, o->edge_weight)
     if (h->want_consensus) { GD(int32_t, h->d_cons, o->cons_off, o->cons_nodes) }
 #undef GD
-    o->seq_path_nodes = (int32_t*)host_big_alloc(4 * (size_t)std::max<int64_t>(h->n_bases, 1));
-    if (!o->seq_path_nodes) { sxg_poa_batch_free(out); return fail(SXG_E_NOMEM, "host allocation of the path array failed"); }
+    const bool with_paths = !(h->want_block_graph == 2 && h->bg_done);
+    if (with_paths) {
+        o->seq_path_nodes = (int32_t*)host_big_alloc(4 * (size_t)std::max<int64_t>(h->n_bases, 1));
+        if (!o->seq_path_nodes) { sxg_poa_batch_free(out); return fail(SXG_E_NOMEM, "host allocation of the path array failed"); }
+        if (h->n_bases) HIPCHK(hipMemcpy(o->seq_path_nodes, h->d_paths.p, 4 * (size_t)h->n_bases, hipMemcpyDeviceToHost));
+    }
     o->score.resize((size_t)std::max<int64_t>(ns, 1));
     o->cells.resize((size_t)std::max<int64_t>(ns, 1));
-    if (h->n_bases) HIPCHK(hipMemcpy(o->seq_path_nodes, h->d_paths.p, 4 * (size_t)h->n_bases, hipMemcpyDeviceToHost));
+    if (h->want_block_graph && h->bg_done) {
+        // dense offsets from the per-block counts of the block-graph kernel; the arrays are gathered on the device
+        o->bg_node_off.assign(nb + 1, 0); o->bg_seq_off.assign(nb + 1, 0); o->bg_edge_off.assign(nb + 1, 0); o->bg_cons_off.assign(nb + 1, 0);
+        std::vector<int64_t> blk_steps(nb + 1, 0), src_no(nb + 1, 0), src_eo(nb + 1, 0);
+        std::vector<int32_t> nsteps((size_t)std::max<int64_t>(ns, 1), 0);
+        if (ns) HIPCHK(hipMemcpy(nsteps.data(), h->d_bg_nsteps.p, 4 * (size_t)ns, hipMemcpyDeviceToHost));
+        o->bg_step_off.assign((size_t)ns + 1, 0);
+        for (int64_t sq = 0; sq < ns; ++sq) o->bg_step_off[(size_t)sq + 1] = o->bg_step_off[(size_t)sq] + nsteps[(size_t)sq];
+        for (int b = 0; b < nb; ++b) {
+            const int32_t* c = h->bg_counts.data() + (size_t)BGC_N * b;
+            const bool ok = o->status[b] == ST_OK;
+            o->bg_node_off[b + 1] = o->bg_node_off[b] + (ok ? c[BGC_NODES] : 0);
+            o->bg_seq_off[b + 1] = o->bg_seq_off[b] + (ok ? c[BGC_SEQ] : 0);
+            o->bg_edge_off[b + 1] = o->bg_edge_off[b] + (ok ? c[BGC_EDGES] : 0);
+            o->bg_cons_off[b + 1] = o->bg_cons_off[b] + (ok && h->want_consensus ? c[BGC_CONS] : 0);
+            blk_steps[b + 1] = o->bg_step_off[(size_t)h->h_blk_off[b + 1]];
+            src_no[b] = h->bg_node_o[(size_t)b]; src_eo[b] = h->bg_edge_o[(size_t)b];
+        }
+        auto put_src = [&](const std::vector<int64_t>& off) -> int {
+            hipError_t e = hipMemcpy(h->d_tmp_a.p, off.data(), 8 * (size_t)(nb + 1), hipMemcpyHostToDevice);
+            return e == hipSuccess ? SXG_OK : fail(SXG_E_NODEVICE, hipGetErrorString(e));
+        };
+#define GB_(T, srcoff, src, off, dst)                                                                                      \
+        if ((rc = put_src(srcoff)) || (rc = put_off(off)) || (rc = gather_download<T>(h, src, off, h->d_tmp_a, h->d_tmp_b, h->d_tmp_c, dst))) { \
+            sxg_poa_batch_free(out);                                                                                       \
+            return rc;                                                                                                     \
+        }
+        GB_(int32_t, src_no, h->d_bg_len, o->bg_node_off, o->bg_node_len)
+        GB_(int32_t, src_no, h->d_bg_od, o->bg_node_off, o->bg_node_outdeg)
+        GB_(uint8_t, src_no, h->d_bg_id, o->bg_node_off, o->bg_node_indeg)
+        GB_(uint8_t, src_no, h->d_bg_seq, o->bg_seq_off, o->bg_seq)
+        GB_(int32_t, src_eo, h->d_bg_eto, o->bg_edge_off, o->bg_edge_to)
+        GB_(int32_t, src_off, h->d_bg_steps, blk_steps, o->bg_steps)
+        if (h->want_consensus) { GB_(int32_t, src_no, h->d_bg_cons, o->bg_cons_off, o->bg_cons_steps) }
+#undef GB_
+        out->bg_node_off = o->bg_node_off.data(); out->bg_node_len = o->bg_node_len.data(); out->bg_node_outdeg = o->bg_node_outdeg.data();
+        out->bg_node_indeg = o->bg_node_indeg.data(); out->bg_seq_off = o->bg_seq_off.data(); out->bg_seq = (char*)o->bg_seq.data();
+        out->bg_edge_off = o->bg_edge_off.data(); out->bg_edge_to = o->bg_edge_to.data(); out->bg_step_off = o->bg_step_off.data();
+        out->bg_steps = o->bg_steps.data();
+        if (h->want_consensus) { out->bg_cons_off = o->bg_cons_off.data(); out->bg_cons_steps = o->bg_cons_steps.data(); }
+    }
     if (ns) {
         HIPCHK(hipMemcpy(o->score.data(), h->d_score.p, 4 * (size_t)ns, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(o->cells.data(), h->d_cells.p, 8 * (size_t)ns, hipMemcpyDeviceToHost));
@@ -1412,7 +1652,7 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
     out->edge_head = o->edge_head.data(); out->edge_weight = o->edge_weight.data();
     out->seq_path_nodes = o->seq_path_nodes; out->score = o->score.data(); out->cells = o->cells.data();
     if (h->want_consensus) { out->cons_off = o->cons_off.data(); out->cons_nodes = o->cons_nodes.data(); }
-    if (h->want_msa) {
+    if (h->want_msa && o->seq_path_nodes) {
         // S8: MSA column = aligned group in rank order; pure formatting of device results
         static const char dec[5] = {'A', 'C', 'G', 'T', 'N'};
         o->msa_off.assign(nb + 1, 0); o->msa_cols.assign(std::max(nb, 1), 0);
@@ -1519,9 +1759,17 @@ RcclApi& rccl_api() {
     static RcclApi A = [] {
         RcclApi a;
         void* lib = nullptr;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!lib) { a.why = std::string("librccl.so not found (") + (dlerror() ? dlerror() : "dlopen failed") + ")"; return a; }
+        // SXG_POA_RCCL_LIB names the library instead of the default search (tests point it at a file that does not exist to
+        // take the RCCL-missing path: SXG_E_NODEVICE with a message, not a crash)
+        if (const char* forced = getenv("SXG_POA_RCCL_LIB")) lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        else
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) {   // (dlerror() clears the error it returns: ask once)
+            const char* e = dlerror();
+            a.why = std::string("librccl.so not found (") + (e ? e : "dlopen failed") + ")";
+            return a;
+        }
         bool all = true;
 #define SXG_RCCL_SYM(f) do { a.f = (decltype(a.f))dlsym(lib, "nccl" #f); if (!a.f) { all = false; a.why += " nccl" #f; } } while (0)
         SXG_RCCL_SYM(GetUniqueId); SXG_RCCL_SYM(CommInitRank); SXG_RCCL_SYM(CommDestroy); SXG_RCCL_SYM(CommAbort);

@@ -27,6 +27,7 @@
 #include <set>
 #include <cmath>
 #include <deque>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -418,7 +419,12 @@ void unchop(ograph_t& G) {
     {
         const int64_t CHK = 1 << 16, nch = (ne + CHK - 1) / CHK;
         std::vector<size_t> cnt((size_t)nch + 1, 0);
-        auto interior = [&](const edge_t& e) { return !rev(e.first) && !rev(e.second) && next[nid(e.first)] == (int64_t)nid(e.second); };
+        // the merged link u+ -> v+ in whichever canonical form it is stored: (u+, v+) or, when u > v, (v-, u-)
+        // (round 4: the second form used to survive as a self loop of the merged node)
+        auto interior = [&](const edge_t& e) {
+            return (!rev(e.first) && !rev(e.second) && next[nid(e.first)] == (int64_t)nid(e.second)) ||
+                   (rev(e.first) && rev(e.second) && next[nid(e.second)] == (int64_t)nid(e.first));
+        };
 #pragma omp parallel for schedule(static) if (par)
         for (int64_t q = 0; q < nch; ++q) {
             size_t k = 0;
@@ -458,17 +464,21 @@ void unchop(ograph_t& G) {
     if (par) sublap("unchop: sort edges");
 }
 
-// topological order, by decree (odgi::algorithms::topological_order is absent): Kahn over the
-// forward-to-forward edges, smallest node first; leftovers (cycles) in id order.  Renumbers.
+// topological order, by decree (odgi::algorithms::topological_order is absent): Kahn over the edges between
+// forward nodes in their walking direction -- (a+, b+) is a -> b, the canonical form (a-, b-) is b -> a (round 4: those
+// used to be left out, so the order was not topological whenever an edge ran from a higher to a lower id) --,
+// smallest node first; leftovers (cycles) in id order.  Renumbers.
 void topo_renumber(ograph_t& G) {
     const size_t n = G.seq.size();
     std::vector<uint32_t> off(n + 1, 0);
     std::vector<int> indeg(n, 0);
-    auto fwd = [](const edge_t& e) { return !rev(e.first) && !rev(e.second) && nid(e.first) != nid(e.second); };
-    for (auto& e : G.edges) if (fwd(e)) { off[nid(e.first) + 1]++; indeg[nid(e.second)]++; }
+    auto fwd = [](const edge_t& e) { return rev(e.first) == rev(e.second) && nid(e.first) != nid(e.second); };
+    auto tail = [](const edge_t& e) { return rev(e.first) ? nid(e.second) : nid(e.first); };
+    auto head = [](const edge_t& e) { return rev(e.first) ? nid(e.first) : nid(e.second); };
+    for (auto& e : G.edges) if (fwd(e)) { off[tail(e) + 1]++; indeg[head(e)]++; }
     for (size_t u = 0; u < n; ++u) off[u + 1] += off[u];
     std::vector<uint32_t> succ(off[n]), fill(off.begin(), off.end() - 1);
-    for (auto& e : G.edges) if (fwd(e)) succ[fill[nid(e.first)]++] = (uint32_t)nid(e.second);
+    for (auto& e : G.edges) if (fwd(e)) succ[fill[tail(e)]++] = (uint32_t)head(e);
     std::priority_queue<size_t, std::vector<size_t>, std::greater<size_t>> q;
     for (size_t u = 0; u < n; ++u) if (!indeg[u]) q.push(u);
     std::vector<int64_t> newid(n, -1);
@@ -1111,6 +1121,623 @@ ograph_t block_graph_from_out(const collected_t& c, const batch_t& B, const sxg_
     const int64_t nc = out.cons_nodes && out.cons_off ? out.cons_off[slot + 1] - out.cons_off[slot] : 0;
     return build_block_graph(c, out.node_code + n0, nn, sp, cons, nc, cname, abpoa);
 }
+// ---------------------------------------------------------------------------------------------
+// Compact block graphs + the flat lacing path.
+//
+// A block's normalised graph (A9 + A10) as flat arrays -- node lengths, out-degrees (CSR), edge heads, one path of
+// node ids per DEDUP'D sequence, the consensus path -- is what the GPU engine returns when it is asked for block graphs
+// (sxg_poa_batch_in::want_block_graph, include/sxg_poa.h): the block's workgroup-sized scans do the trim, the
+// path-supported edge filter, the 1-bp chain unchop and the renumbering on the device.  A provider that returns only raw
+// POA results (the CPU oracle callback of the tests, a sharded provider) gets the same arrays built here, on the host,
+// from build_block_graph's own steps.  Either way the iteration never materialises per-node strings or per-duplicate
+// step vectors again: lacing, validation, the global unchop and the GFA text work on these arrays.
+struct cstore_t {   // arrays of a block graph built on the host
+    uvec<int32_t> len, outdeg, eto, steps, cons;
+    uvec<uint8_t> indeg;
+    uvec<char> seq;
+};
+// A block graph is topologically numbered, so every edge runs forward-forward from a lower to a higher id: the edges
+// are listed per tail (CSR), heads ascending -- the block's L lines in their order.
+struct cblock_t {
+    int64_t n = 0, ne = 0;
+    bool has_paths = false;                                   // the block had sequences (its consensus path exists, even if empty)
+    const int32_t *len = nullptr, *outdeg = nullptr, *eto = nullptr;
+    const uint8_t* indeg = nullptr;                           // saturating at 255
+    const char* seq = nullptr;
+    std::vector<std::pair<const int32_t*, int64_t>> upath;    // steps of every dedup'd sequence, in alignment order
+    const int32_t* cons = nullptr;
+    int64_t ncons = 0;
+    uvec<uint32_t> soff, eoff;                                // [n+1] prefix sums of len / outdeg
+    std::vector<int32_t> range_useq;                          // path range (rank in the block) -> dedup'd sequence
+    std::vector<char> range_rev;                              //                                  -> collected in reverse
+    std::unique_ptr<cstore_t> own;
+    void index(const collected_t& c, size_t n_ranges) {
+        soff.resize((size_t)n + 1); eoff.resize((size_t)n + 1);
+        uint32_t a = 0, e = 0;
+        for (int64_t v = 0; v < n; ++v) { soff[(size_t)v] = a; eoff[(size_t)v] = e; a += (uint32_t)len[v]; e += (uint32_t)outdeg[v]; }
+        soff[(size_t)n] = a; eoff[(size_t)n] = e;
+        ne = e;
+        range_useq.assign(n_ranges, -1); range_rev.assign(n_ranges, 0);
+        for (size_t i = 0; i < c.dup_rank_in_path_ranges.size(); ++i)
+            for (size_t j = 0; j < c.dup_rank_in_path_ranges[i].size(); ++j) {
+                range_useq[(size_t)c.dup_rank_in_path_ranges[i][j]] = (int32_t)i;
+                range_rev[(size_t)c.dup_rank_in_path_ranges[i][j]] = c.dup_is_revs[i][j] ? 1 : 0;
+            }
+    }
+    bool has_edge(uint64_t v, uint64_t w) const {
+        for (uint32_t x = eoff[(size_t)v]; x < eoff[(size_t)v + 1]; ++x) if ((uint64_t)eto[x] == w) return true;
+        return false;
+    }
+};
+// A9 + A10 on the host from raw POA results, for ONE path per dedup'd sequence: the duplicates of a sequence walk the
+// same nodes (reversed and flipped when collected in reverse, src/smooth.cpp:2612-2615), so they add neither nodes nor
+// canonical edges nor path ends to what unchop and the ordering see -- the graph is build_block_graph's.
+void cblock_from_raw(cblock_t& B, const collected_t& c, size_t n_ranges, const uint8_t* node_code, int64_t n_nodes,
+                     const std::vector<const int32_t*>& seq_paths, const int32_t* cons, int64_t n_cons, bool want_cons, bool abpoa) {
+    static const char dec[5] = {'A', 'C', 'G', 'T', 'N'};
+    ograph_t G;
+    const size_t S = c.seqs.size();
+    G.paths.resize(S + (want_cons ? 1 : 0));
+    for (size_t i = 0; i < S; ++i) {
+        const int64_t len = (int64_t)c.seqs[i].size();
+        steps_t& st = G.paths[i].second;
+        st.reserve((size_t)std::max<int64_t>(0, len - 2 * (int64_t)c.poa_padding));
+        for (int64_t k = c.poa_padding; k < len - c.poa_padding; ++k) st.push_back(mk((uint64_t)seq_paths[i][k], false));
+    }
+    if (want_cons) {
+        steps_t& st = G.paths[S].second;
+        std::vector<char> visited;
+        if (abpoa) {
+            visited.assign((size_t)n_nodes, 0);
+            for (size_t i = 0; i < S; ++i) for (handle_t h : G.paths[i].second) visited[nid(h)] = 1;
+        }
+        for (int64_t k = 0; k < n_cons; ++k)
+            if (!abpoa || visited[(size_t)cons[k]]) st.push_back(mk((uint64_t)cons[k], false));
+    }
+    std::vector<int64_t> keep((size_t)n_nodes, -1);
+    for (auto& pth : G.paths) for (handle_t h : pth.second) keep[nid(h)] = 0;
+    for (int64_t v = 0, k = 0; v < n_nodes; ++v) if (keep[(size_t)v] == 0) { keep[(size_t)v] = k++; G.seq.push_back(std::string(1, dec[node_code[v] > 4 ? 4 : node_code[v]])); }
+    edge_acc_t acc(G.seq.size());
+    for (auto& pth : G.paths) {
+        for (auto& h : pth.second) h = mk((uint64_t)keep[nid(h)], rev(h));
+        for (size_t k = 1; k < pth.second.size(); ++k) acc.add(pth.second[k - 1], pth.second[k]);
+    }
+    acc.into(G.edges);
+    unchop(G);
+    topo_renumber(G);
+    B.own.reset(new cstore_t());
+    cstore_t& O = *B.own;
+    const size_t n = G.seq.size();
+    O.len.resize(n); O.outdeg.resize(n); O.indeg.resize(n);
+    size_t bytes = 0;
+    for (size_t v = 0; v < n; ++v) { O.len[v] = (int32_t)G.seq[v].size(); O.outdeg[v] = 0; O.indeg[v] = 0; bytes += G.seq[v].size(); }
+    O.seq.resize(bytes + 1);
+    { size_t a = 0; for (size_t v = 0; v < n; ++v) { memcpy(O.seq.data() + a, G.seq[v].data(), G.seq[v].size()); a += G.seq[v].size(); } }
+    O.eto.resize(G.edges.size() + 1);
+    for (size_t x = 0; x < G.edges.size(); ++x) {   // (canonical and sorted: by tail, then head)
+        const edge_t& e = G.edges[x];
+        if (rev(e.first) || rev(e.second) || nid(e.first) >= nid(e.second)) abort();   // (a topologically numbered DAG has no other kind)
+        O.outdeg[nid(e.first)] += 1;
+        if (O.indeg[nid(e.second)] < 255) O.indeg[nid(e.second)] += 1;
+        O.eto[x] = (int32_t)nid(e.second);
+    }
+    size_t total = 0;
+    for (size_t i = 0; i < S; ++i) total += G.paths[i].second.size();
+    O.steps.resize(total + 1);
+    B.upath.resize(S);
+    size_t a = 0;
+    for (size_t i = 0; i < S; ++i) {
+        const steps_t& st = G.paths[i].second;
+        for (size_t k = 0; k < st.size(); ++k) O.steps[a + k] = (int32_t)nid(st[k]);
+        B.upath[i] = std::make_pair(O.steps.data() + a, (int64_t)st.size());
+        a += st.size();
+    }
+    if (want_cons) {
+        const steps_t& st = G.paths[S].second;
+        O.cons.resize(st.size() + 1);
+        for (size_t k = 0; k < st.size(); ++k) O.cons[k] = (int32_t)nid(st[k]);
+        B.cons = O.cons.data(); B.ncons = (int64_t)st.size();
+    }
+    B.n = (int64_t)n; B.len = O.len.data(); B.outdeg = O.outdeg.data(); B.indeg = O.indeg.data(); B.eto = O.eto.data(); B.seq = O.seq.data();
+    B.has_paths = S > 0;
+    B.index(c, n_ranges);
+}
+// ... or views of the arrays the provider returned for block `slot` of its batch
+void cblock_from_out(cblock_t& B, const collected_t& c, size_t n_ranges, const batch_t& Bt, const sxg_poa_batch_out& out, int64_t slot, bool want_cons) {
+    const int64_t n0 = out.bg_node_off[slot];
+    B.n = out.bg_node_off[slot + 1] - n0;
+    B.len = out.bg_node_len + n0; B.outdeg = out.bg_node_outdeg + n0; B.indeg = out.bg_node_indeg + n0;
+    B.seq = out.bg_seq + out.bg_seq_off[slot];
+    B.eto = out.bg_edge_to + out.bg_edge_off[slot];
+    const int32_t s0 = Bt.blk_off[(size_t)slot], s1 = Bt.blk_off[(size_t)slot + 1];
+    B.upath.resize((size_t)(s1 - s0));
+    for (int32_t sq = s0; sq < s1; ++sq) B.upath[(size_t)(sq - s0)] = std::make_pair(out.bg_steps + out.bg_step_off[sq], out.bg_step_off[sq + 1] - out.bg_step_off[sq]);
+    if (want_cons && out.bg_cons_off && out.bg_cons_steps) { B.cons = out.bg_cons_steps + out.bg_cons_off[slot]; B.ncons = out.bg_cons_off[slot + 1] - out.bg_cons_off[slot]; }
+    B.has_paths = s1 > s0;
+    B.index(c, n_ranges);
+}
+
+// Output sinks of the GFA writer: the size pass and the write pass run the same code.
+struct count_sink_t {
+    size_t n = 0;
+    void raw(const char*, size_t len) { n += len; }
+    void ch(char) { n += 1; }
+    void num(uint64_t v) { n += digits_u64(v); }
+};
+struct write_sink_t {
+    char* o;
+    void raw(const char* q, size_t len) { memcpy(o, q, len); o += len; }
+    void ch(char c) { *o++ = c; }
+    void num(uint64_t v) {
+        static const char lut[201] =
+            "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263"
+            "646566676869707172737475767778798081828384858687888990919293949596979899";
+        char buf[24];
+        int k = 24;
+        while (v >= 100) { const unsigned r = (unsigned)(v % 100); v /= 100; buf[--k] = lut[2 * r + 1]; buf[--k] = lut[2 * r]; }
+        if (v >= 10) { buf[--k] = lut[2 * v + 1]; buf[--k] = lut[2 * v]; } else buf[--k] = (char)('0' + v);
+        memcpy(o, buf + k, (size_t)(24 - k));
+        o += 24 - k;
+    }
+};
+
+// The lacing half of the iteration on compact block graphs (src/main.cpp:599-1061), for the run without MAF merging
+// (no flips, every block keeps its own consensus path): fragments by (path, start), validation, links between the
+// fragments, the global unchop, GFA text.  Same bytes as the laced-graph path below (ograph_t; SXG_SMOOTH_LEGACY=1 keeps
+// taking it, and the MAF / merge iteration always does), without building the laced graph:
+//   * a laced path is its list of fragments -- (block, dedup'd sequence, orientation) -- and its steps are read from the
+//     block's step array with the block's id offset when they are counted and when they are written;
+//   * unchop (decree of DESIGN.md section 9) runs its test on every node -- out-degree from the block's CSR plus the
+//     links that attach to the node, in-degree of the one successor, path ends -- but a block graph is already
+//     unchopped, so what it finds are the few links and block edges whose path ends went away with lacing: the merged
+//     chains live in small per-block tables, node ids shift by the number of removed nodes in front of them;
+//   * edges keep their order under that renumbering except those that leave a merged chain and the links, which are
+//     sorted apart and merged in by position while the L lines are written.
+struct lace_timer_t { std::function<void(const char*)> lap; };
+int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, std::vector<cblock_t>& cb, char** out_gfa,
+              const std::function<void(const char*)>& lap) {
+    const int64_t nb = (int64_t)cb.size();
+    struct frag_t { uint64_t path, start, end; int64_t target, block; };
+    std::vector<frag_t> mapping;
+    for (int64_t k = 0; k < nb; ++k) {
+        if (cb[(size_t)k].n == 0) continue;
+        int64_t path_id = 0;
+        for (auto& r : b->blocks[(size_t)k]) mapping.push_back(frag_t{r.path, g->pos[r.path][r.begin], g->pos[r.path][r.end], path_id++, k});
+    }
+    std::stable_sort(mapping.begin(), mapping.end(), [](const frag_t& a, const frag_t& c) { return a.path < c.path || (a.path == c.path && a.start < c.start); });
+    std::vector<uint64_t> id_trans((size_t)nb + 1, 0);
+    for (int64_t k = 0; k < nb; ++k) id_trans[(size_t)k + 1] = id_trans[(size_t)k] + (uint64_t)cb[(size_t)k].n;
+    const uint64_t n_laced = id_trans[(size_t)nb];
+    auto block_of = [&](uint64_t X) { return (int64_t)(std::upper_bound(id_trans.begin(), id_trans.end(), X) - id_trans.begin()) - 1; };
+    std::vector<std::pair<size_t, size_t>> runs;   // [a, z) of every path's fragments
+    for (size_t a = 0; a < mapping.size();) {
+        size_t z = a;
+        while (z < mapping.size() && mapping[z].path == mapping[a].path) ++z;
+        runs.emplace_back(a, z);
+        a = z;
+    }
+    const size_t nf = mapping.size(), nruns = runs.size();
+    // a fragment's steps: the path of its dedup'd sequence, walked backwards with flipped handles when the range was collected in reverse
+    struct fview_t { const int32_t* st; int64_t cnt; bool rv; uint64_t o; };
+    auto fview = [&](size_t f) {
+        const cblock_t& B = cb[(size_t)mapping[f].block];
+        const int32_t u = B.range_useq[(size_t)mapping[f].target];
+        fview_t v;
+        v.st = u >= 0 ? B.upath[(size_t)u].first : nullptr; v.cnt = u >= 0 ? B.upath[(size_t)u].second : 0;
+        v.rv = B.range_rev[(size_t)mapping[f].target] != 0; v.o = id_trans[(size_t)mapping[f].block];
+        return v;
+    };
+    auto ffront = [&](const fview_t& v) { return v.rv ? mk(v.o + (uint64_t)v.st[v.cnt - 1], true) : mk(v.o + (uint64_t)v.st[0], false); };
+    auto fback = [&](const fview_t& v) { return v.rv ? mk(v.o + (uint64_t)v.st[0], true) : mk(v.o + (uint64_t)v.st[v.cnt - 1], false); };
+    // coverage, links between the fragments of a path, the ends of the laced paths (parallel over paths, src/main.cpp:706-764)
+    std::vector<std::string> errs(nruns);
+    std::vector<std::vector<edge_t>> links(nruns);
+    std::vector<handle_t> pfront(nruns, 0), pback(nruns, 0);
+    std::vector<char> pany(nruns, 0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t q = 0; q < (int64_t)nruns; ++q) {
+        const size_t a = runs[(size_t)q].first, z = runs[(size_t)q].second;
+        uint64_t last_end = 0;
+        bool any = false;
+        handle_t last = 0;
+        for (size_t f = a; f < z; ++f) {
+            if (mapping[f].start != last_end) { errs[(size_t)q] = "path " + g->pname[mapping[a].path] + " is not covered by the blocks"; break; }
+            const fview_t v = fview(f);
+            if (v.cnt > 0) {
+                if (any) links[(size_t)q].push_back(ograph_t::canon(last, ffront(v)));
+                else pfront[(size_t)q] = ffront(v);
+                last = fback(v);
+                any = true;
+            }
+            last_end = mapping[f].end;
+        }
+        if (errs[(size_t)q].empty() && last_end != g->pos[mapping[a].path].back())
+            errs[(size_t)q] = "path " + g->pname[mapping[a].path] + " is not covered to its end";
+        pany[(size_t)q] = any ? 1 : 0; pback[(size_t)q] = last;
+    }
+    for (auto& e : errs) if (!e.empty()) return fail(SXG_E_INVALID, e);
+    lap("lacing");
+    // validation (src/main.cpp:770-810): every laced path spells its original sequence.  The fragments tile their path
+    // (checked above), so that is: every fragment spells its range.
+    {
+        size_t nonempty = 0;
+        for (auto& st : g->steps) if (!st.empty()) ++nonempty;
+        if (nruns != nonempty) return fail(SXG_E_INVALID, "path count mismatch between input and smoothed graph");
+        int64_t bad = -1;
+#pragma omp parallel for schedule(dynamic, 16)
+        for (int64_t f = 0; f < (int64_t)nf; ++f) {
+            const fview_t v = fview((size_t)f);
+            const cblock_t& B = cb[(size_t)mapping[(size_t)f].block];
+            const path_range_t& r = b->blocks[(size_t)mapping[(size_t)f].block][(size_t)mapping[(size_t)f].target];
+            uint64_t st = r.begin, at = 0;          // cursor in the original: step, offset inside its node
+            bool ok = true;
+            for (int64_t j = 0; j < v.cnt && ok; ++j) {
+                const int32_t x = v.st[v.rv ? v.cnt - 1 - j : j];
+                const char* ns = B.seq + B.soff[(size_t)x];
+                const size_t nl = (size_t)(B.soff[(size_t)x + 1] - B.soff[(size_t)x]);
+                for (size_t t = 0; t < nl && ok;) {
+                    if (st >= r.end) { ok = false; break; }
+                    const handle_t h = g->steps[r.path][st];
+                    const std::string& os = g->seq[nid(h)];
+                    if (at >= os.size()) { ++st; at = 0; continue; }
+                    const size_t m = std::min(nl - t, os.size() - (size_t)at);
+                    if (!v.rv && !rev(h)) { if (memcmp(ns + t, os.data() + at, m) != 0) ok = false; }
+                    else
+                        for (size_t y = 0; y < m && ok; ++y) {
+                            const char sc = v.rv ? comp(ns[nl - 1 - (t + y)]) : ns[t + y];
+                            const char oc = rev(h) ? comp(os[os.size() - 1 - ((size_t)at + y)]) : os[(size_t)at + y];
+                            if (sc != oc) ok = false;
+                        }
+                    t += m; at += m;
+                }
+            }
+            // the original must be used up as well (empty trailing nodes aside)
+            while (ok && st < r.end && at >= g->seq[nid(g->steps[r.path][st])].size()) { ++st; at = 0; }
+            if (!ok || st != r.end) {
+#pragma omp critical(sxg_lace_bad)
+                if (bad < 0 || f < bad) bad = f;
+            }
+        }
+        if (bad >= 0) return fail(SXG_E_INVALID, "path " + g->pname[mapping[(size_t)bad].path] + " was corrupted in the smoothed graph");
+    }
+    lap("validation");
+    // consensus paths (src/main.cpp:812-869): one per block that had sequences, after the input paths
+    std::vector<int64_t> cons_blocks;
+    if (p->add_consensus) for (int64_t k = 0; k < nb; ++k) if (cb[(size_t)k].has_paths) cons_blocks.push_back(k);
+    // ---- the global unchop (src/main.cpp:1021), incrementally ----
+    // nodes at which a path starts or ends block a merge on that side
+    std::vector<uint64_t> rblk, lblk;   // rblk: a path ends at u+ / starts at u-; lblk: a path starts at v+ / ends at v-
+    auto path_ends = [&](handle_t front, handle_t back) {
+        if (rev(front)) rblk.push_back(nid(front)); else lblk.push_back(nid(front));
+        if (rev(back)) lblk.push_back(nid(back)); else rblk.push_back(nid(back));
+    };
+    for (size_t q = 0; q < nruns; ++q) if (pany[q]) path_ends(pfront[q], pback[q]);
+    for (int64_t k : cons_blocks) {
+        const cblock_t& B = cb[(size_t)k];
+        if (B.ncons > 0) path_ends(mk(id_trans[(size_t)k] + (uint64_t)B.cons[0], false), mk(id_trans[(size_t)k] + (uint64_t)B.cons[B.ncons - 1], false));
+    }
+    std::sort(rblk.begin(), rblk.end()); std::sort(lblk.begin(), lblk.end());
+    // links that the blocks do not hold already
+    std::vector<edge_t> lk;
+    for (auto& l : links) lk.insert(lk.end(), l.begin(), l.end());
+    std::sort(lk.begin(), lk.end());
+    lk.erase(std::unique(lk.begin(), lk.end()), lk.end());
+    {
+        size_t w = 0;
+        for (size_t j = 0; j < lk.size(); ++j) {
+            const edge_t& e = lk[j];
+            bool have = false;
+            if (!rev(e.first) && !rev(e.second) && nid(e.first) < nid(e.second)) {
+                const int64_t k = block_of(nid(e.first));
+                if (k == block_of(nid(e.second))) have = cb[(size_t)k].has_edge(nid(e.first) - id_trans[(size_t)k], nid(e.second) - id_trans[(size_t)k]);
+            }
+            if (!have) lk[w++] = e;
+        }
+        lk.resize(w);
+    }
+    // what the links add to the sides of their nodes: (handle the edge leaves, handle it arrives at)
+    std::vector<edge_t> adj;
+    adj.reserve(2 * lk.size());
+    for (auto& e : lk) { adj.emplace_back(e.first, e.second); adj.emplace_back(flip(e.second), flip(e.first)); }
+    std::sort(adj.begin(), adj.end());
+    auto adj_count = [&](handle_t h) {
+        auto lo = std::lower_bound(adj.begin(), adj.end(), edge_t(h, 0));
+        size_t c = 0;
+        while (lo != adj.end() && lo->first == h) { ++c; ++lo; }
+        return c;
+    };
+    std::vector<std::vector<std::pair<uint64_t, uint64_t>>> found((size_t)nb);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t k = 0; k < nb; ++k) {
+        const cblock_t& B = cb[(size_t)k];
+        if (B.n == 0) continue;
+        const uint64_t o = id_trans[(size_t)k];
+        size_t ai = (size_t)(std::lower_bound(adj.begin(), adj.end(), edge_t(mk(o, false), 0)) - adj.begin());
+        for (int64_t u = 0; u < B.n; ++u) {
+            const uint64_t U = o + (uint64_t)u;
+            const handle_t uf = mk(U, false);
+            while (ai < adj.size() && adj[ai].first < uf) ++ai;
+            size_t cr = 0;
+            handle_t other = 0;
+            for (size_t j = ai; j < adj.size() && adj[j].first == uf; ++j) { ++cr; other = adj[j].second; }
+            if ((size_t)B.outdeg[u] + cr != 1) continue;
+            const handle_t vf = B.outdeg[u] == 1 ? mk(o + (uint64_t)B.eto[B.eoff[(size_t)u]], false) : other;
+            if (rev(vf) || nid(vf) == U) continue;
+            const uint64_t V = nid(vf);
+            const int64_t kv = B.outdeg[u] == 1 ? k : block_of(V);
+            const unsigned ind = cb[(size_t)kv].indeg[V - id_trans[(size_t)kv]];
+            if (ind > 1) continue;
+            if (ind + adj_count(mk(V, true)) != 1) continue;   // (the one edge on v's left side is then the one from u+)
+            if (std::binary_search(rblk.begin(), rblk.end(), U) || std::binary_search(lblk.begin(), lblk.end(), V)) continue;
+            found[(size_t)k].emplace_back(U, V);
+        }
+    }
+    std::unordered_map<uint64_t, uint64_t> nxt, prv;
+    for (auto& fv : found) for (auto& m : fv) { nxt[m.first] = m.second; prv[m.second] = m.first; }
+    // chains hang off their heads; what no head reaches is a pure cycle, broken at its smallest member
+    struct cmem_t { uint32_t local; uint8_t first, last; uint64_t head; };   // head: the chain's head (laced id), later its new id
+    std::vector<std::vector<cmem_t>> cmem((size_t)nb);
+    std::vector<std::vector<uint32_t>> rem((size_t)nb);      // removed nodes (chain members that are not heads), by block
+    std::vector<std::vector<uint64_t>> chains;
+    {
+        std::vector<uint64_t> keys;
+        for (auto& kv : nxt) keys.push_back(kv.first);
+        for (auto& kv : prv) keys.push_back(kv.first);
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        std::unordered_map<uint64_t, char> reached;
+        auto walk = [&](uint64_t h) {
+            chains.emplace_back();
+            for (uint64_t x = h;;) { reached[x] = 1; chains.back().push_back(x); auto it = nxt.find(x); if (it == nxt.end()) break; x = it->second; }
+        };
+        for (uint64_t u : keys) if (!prv.count(u)) walk(u);
+        for (uint64_t u : keys) {
+            if (reached.count(u)) continue;
+            nxt.erase(prv[u]); prv.erase(u);   // u is the smallest member of its cycle: smaller ones would have been met first
+            walk(u);
+        }
+        std::sort(chains.begin(), chains.end(), [](const std::vector<uint64_t>& a, const std::vector<uint64_t>& c) { return a[0] < c[0]; });
+        for (auto& ch : chains)
+            for (size_t x = 0; x < ch.size(); ++x) {
+                const int64_t k = block_of(ch[x]);
+                cmem[(size_t)k].push_back(cmem_t{(uint32_t)(ch[x] - id_trans[(size_t)k]), (uint8_t)(x == 0), (uint8_t)(x + 1 == ch.size()), ch[0]});
+                if (x) rem[(size_t)k].push_back((uint32_t)(ch[x] - id_trans[(size_t)k]));
+            }
+        for (int64_t k = 0; k < nb; ++k) {
+            std::sort(cmem[(size_t)k].begin(), cmem[(size_t)k].end(), [](const cmem_t& a, const cmem_t& c) { return a.local < c.local; });
+            std::sort(rem[(size_t)k].begin(), rem[(size_t)k].end());
+        }
+    }
+    std::vector<uint64_t> basem((size_t)nb + 1, 0);
+    for (int64_t k = 0; k < nb; ++k) basem[(size_t)k + 1] = basem[(size_t)k] + rem[(size_t)k].size();
+    // new (0-based) id of a node that is not removed
+    auto newid_in = [&](int64_t k, uint64_t x) {
+        const auto& r = rem[(size_t)k];
+        return id_trans[(size_t)k] + x - basem[(size_t)k] - (uint64_t)(std::lower_bound(r.begin(), r.end(), (uint32_t)x) - r.begin());
+    };
+    for (int64_t k = 0; k < nb; ++k)
+        for (auto& m : cmem[(size_t)k]) { const int64_t kh = block_of(m.head); m.head = newid_in(kh, m.head - id_trans[(size_t)kh]); }
+    auto find_cm = [&](int64_t k, uint64_t x) -> const cmem_t* {
+        const auto& c = cmem[(size_t)k];
+        for (auto& m : c) if (m.local == (uint32_t)x) return &m;
+        return nullptr;
+    };
+    // new id of any node (a chain member maps to its chain)
+    auto newid_any = [&](uint64_t X) {
+        const int64_t k = block_of(X);
+        const uint64_t x = X - id_trans[(size_t)k];
+        if (!cmem[(size_t)k].empty()) if (const cmem_t* m = find_cm(k, x)) return m->head;
+        return newid_in(k, x);
+    };
+    auto remap = [&](handle_t h) { return mk(newid_any(nid(h)), rev(h)); };
+    // edges that do not keep their place: the links (mapped) and every block edge that touches a chain member (its
+    // canonical form and its place among the L lines follow the chain's new id); the edges inside a chain go away
+    auto is_member = [&](int64_t k, uint64_t x) {
+        const auto& c = cmem[(size_t)k];
+        return !c.empty() && x >= c.front().local && x <= c.back().local && find_cm(k, x) != nullptr;
+    };
+    auto interior = [&](uint64_t tail, uint64_t head) { auto it = nxt.find(tail); return it != nxt.end() && it->second == head; };
+    std::vector<edge_t> extra;
+    for (auto& e : lk) {   // (the merged link u+ -> v+ may be stored as (u+, v+) or as (v-, u-))
+        if (!rev(e.first) && !rev(e.second) && interior(nid(e.first), nid(e.second))) continue;
+        if (rev(e.first) && rev(e.second) && interior(nid(e.second), nid(e.first))) continue;
+        extra.push_back(ograph_t::canon(remap(e.first), remap(e.second)));
+    }
+    for (int64_t k = 0; k < nb; ++k) {
+        if (cmem[(size_t)k].empty()) continue;
+        const cblock_t& B = cb[(size_t)k];
+        const uint64_t o = id_trans[(size_t)k];
+        for (int64_t u = 0; u < B.n; ++u) {
+            const bool mu = is_member(k, (uint64_t)u);
+            for (uint32_t x = B.eoff[(size_t)u]; x < B.eoff[(size_t)u + 1]; ++x) {
+                const uint64_t w = (uint64_t)B.eto[x];
+                if (!mu && !is_member(k, w)) continue;
+                const uint64_t tail = o + (uint64_t)u, head = o + w;
+                if (interior(tail, head)) continue;
+                extra.push_back(ograph_t::canon(mk(newid_any(tail), false), mk(newid_any(head), false)));
+            }
+        }
+    }
+    std::sort(extra.begin(), extra.end());
+    extra.erase(std::unique(extra.begin(), extra.end()), extra.end());
+    // ... handed to the block whose (new) id range holds their first node
+    std::vector<uint64_t> nstart((size_t)nb + 1);
+    for (int64_t k = 0; k <= nb; ++k) nstart[(size_t)k] = id_trans[(size_t)k] - basem[(size_t)k];
+    std::vector<size_t> xlo((size_t)nb + 1, extra.size());
+    {
+        size_t j = 0;
+        for (int64_t k = 0; k < nb; ++k) {
+            xlo[(size_t)k] = j;
+            while (j < extra.size() && nid(extra[j].first) < nstart[(size_t)k + 1]) ++j;
+        }
+        xlo[(size_t)nb] = j;
+        // (nothing is left over: every first node lies in some block's range; ids beyond the last block cannot occur)
+        if (j != extra.size()) return fail(SXG_E_INVALID, "internal: edge outside the laced graph");
+    }
+    lap("unchop");
+    // ---- GFA text: sizes, then every piece in place ----
+    auto emit_S = [&](auto& sk, int64_t k) {
+        const cblock_t& B = cb[(size_t)k];
+        const auto& r = rem[(size_t)k];
+        size_t ri = 0;
+        uint64_t id = nstart[(size_t)k] + 1;
+        for (int64_t v = 0; v < B.n; ++v) {
+            if (ri < r.size() && r[ri] == (uint32_t)v) { ++ri; continue; }
+            sk.ch('S'); sk.ch('\t'); sk.num(id++); sk.ch('\t');
+            const cmem_t* m = cmem[(size_t)k].empty() ? nullptr : find_cm(k, (uint64_t)v);
+            if (!m) sk.raw(B.seq + B.soff[(size_t)v], (size_t)(B.soff[(size_t)v + 1] - B.soff[(size_t)v]));
+            else {   // a chain head: the sequences of its members
+                const auto it = std::lower_bound(chains.begin(), chains.end(), id_trans[(size_t)k] + (uint64_t)v,
+                                                 [](const std::vector<uint64_t>& c, uint64_t x) { return c[0] < x; });
+                for (uint64_t X : *it) {
+                    const int64_t kx = block_of(X);
+                    const cblock_t& Bx = cb[(size_t)kx];
+                    const uint64_t x = X - id_trans[(size_t)kx];
+                    sk.raw(Bx.seq + Bx.soff[(size_t)x], (size_t)(Bx.soff[(size_t)x + 1] - Bx.soff[(size_t)x]));
+                }
+            }
+            sk.ch('\n');
+        }
+    };
+    auto put_L = [&](auto& sk, const edge_t& e) {
+        sk.ch('L'); sk.ch('\t'); sk.num(nid(e.first) + 1); sk.ch('\t'); sk.ch(rev(e.first) ? '-' : '+'); sk.ch('\t');
+        sk.num(nid(e.second) + 1); sk.ch('\t'); sk.ch(rev(e.second) ? '-' : '+'); sk.raw("\t0M\n", 4);
+    };
+    auto emit_L = [&](auto& sk, int64_t k) {
+        const cblock_t& B = cb[(size_t)k];
+        const auto& r = rem[(size_t)k];
+        const bool members = !cmem[(size_t)k].empty();
+        size_t xj = xlo[(size_t)k];
+        const size_t xz = xlo[(size_t)k + 1];
+        size_t ri = 0;
+        uint64_t id = nstart[(size_t)k];
+        const uint64_t base = nstart[(size_t)k];
+        for (int64_t u = 0; u < B.n; ++u) {
+            if (ri < r.size() && r[ri] == (uint32_t)u) { ++ri; continue; }
+            const uint64_t nu = id++;
+            if (members && is_member(k, (uint64_t)u)) continue;   // (a chain head: its edges are in `extra`)
+            for (uint32_t x = B.eoff[(size_t)u]; x < B.eoff[(size_t)u + 1]; ++x) {
+                const uint64_t w = (uint64_t)B.eto[x];
+                if (members && is_member(k, w)) continue;           // (in `extra`)
+                const uint64_t nw = members ? newid_in(k, w) : base + w;
+                const edge_t e(mk(nu, false), mk(nw, false));
+                while (xj < xz && extra[xj] < e) put_L(sk, extra[xj++]);
+                if (xj < xz && extra[xj] == e) ++xj;
+                put_L(sk, e);
+            }
+        }
+        while (xj < xz) put_L(sk, extra[xj++]);
+    };
+    // steps of one fragment; `first` = nothing of this path has been written yet.  Returns the steps written.
+    auto emit_F = [&](auto& sk, size_t f, bool first) -> uint64_t {
+        const fview_t v = fview(f);
+        const int64_t k = mapping[f].block;
+        const auto& cm = cmem[(size_t)k];
+        const uint64_t base = nstart[(size_t)k] + 1;
+        const char sign = v.rv ? '-' : '+';
+        uint64_t n = 0;
+        if (cm.empty()) {
+            for (int64_t j = 0; j < v.cnt; ++j) {
+                const uint64_t x = (uint64_t)v.st[v.rv ? v.cnt - 1 - j : j];
+                if (!first) sk.ch(',');
+                first = false;
+                sk.num(base + x); sk.ch(sign); ++n;
+            }
+            return n;
+        }
+        const uint32_t lo = cm.front().local, hi = cm.back().local;
+        const uint64_t nrem = rem[(size_t)k].size();
+        for (int64_t j = 0; j < v.cnt; ++j) {
+            const uint64_t x = (uint64_t)v.st[v.rv ? v.cnt - 1 - j : j];
+            uint64_t id;
+            if (x < lo) id = base + x;
+            else if (x > hi) id = base + x - nrem;
+            else if (const cmem_t* m = find_cm(k, x)) {
+                if (v.rv ? !m->last : !m->first) continue;   // a chain is stepped on once: at its head forwards, at its last node backwards
+                id = m->head + 1;
+            } else id = newid_in(k, x) + 1;
+            if (!first) sk.ch(',');
+            first = false;
+            sk.num(id); sk.ch(sign); ++n;
+        }
+        return n;
+    };
+    auto emit_C = [&](auto& sk, int64_t k) {   // the consensus path of block k (forward steps)
+        const cblock_t& B = cb[(size_t)k];
+        const std::string name = cons_name(*p, k);
+        sk.ch('P'); sk.ch('\t'); sk.raw(name.data(), name.size()); sk.ch('\t');
+        bool first = true;
+        for (int64_t j = 0; j < B.ncons; ++j) {
+            const uint64_t x = (uint64_t)B.cons[j];
+            uint64_t id;
+            if (cmem[(size_t)k].empty()) id = nstart[(size_t)k] + 1 + x;
+            else if (const cmem_t* m = find_cm(k, x)) { if (!m->first) continue; id = m->head + 1; }
+            else id = newid_in(k, x) + 1;
+            if (!first) sk.ch(',');
+            first = false;
+            sk.num(id); sk.ch('+');
+        }
+        sk.raw("\t*\n", 3);
+    };
+    // pieces: header | S of every block | L of every block | every fragment | every consensus path
+    static const char head[] = "H\tVN:Z:1.0\n";
+    const size_t P_S = 1, P_L = P_S + (size_t)nb, P_F = P_L + (size_t)nb, P_C = P_F + nf, pieces = P_C + cons_blocks.size();
+    std::vector<size_t> off(pieces + 1, 0);
+    std::vector<uint64_t> fsteps(nf, 0);   // steps every fragment writes (a path's comma logic needs the fragments before it)
+    off[1] = sizeof(head) - 1;
+    std::vector<size_t> run_of(nf);
+    for (size_t q = 0; q < nruns; ++q) for (size_t f = runs[q].first; f < runs[q].second; ++f) run_of[f] = q;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t q = 1; q < (int64_t)pieces; ++q) {
+        count_sink_t sk;
+        const size_t x = (size_t)q;
+        if (x < P_L) emit_S(sk, (int64_t)(x - P_S));
+        else if (x < P_F) emit_L(sk, (int64_t)(x - P_L));
+        else if (x < P_C) {
+            // (counted as if the fragment opened its path: the commas between fragments are added below)
+            const size_t f = x - P_F;
+            fsteps[f] = emit_F(sk, f, true);
+        } else emit_C(sk, cons_blocks[x - P_C]);
+        off[x + 1] = sk.n;
+    }
+    // path prefix / suffix and the comma in front of every fragment that is not the first to write steps
+    std::vector<char> lead(nf, 0);
+    for (size_t q = 0; q < nruns; ++q) {
+        const size_t a = runs[q].first, z = runs[q].second;
+        bool any = false;
+        for (size_t f = a; f < z; ++f) {
+            if (fsteps[f] > 0) { if (any) { lead[f] = 1; off[P_F + f + 1] += 1; } any = true; }
+        }
+        off[P_F + a + 1] += 3 + g->pname[mapping[a].path].size();   // "P\t" name "\t"
+        off[P_F + (z - 1) + 1] += 3;                                // "\t*\n"
+    }
+    for (size_t q = 0; q < pieces; ++q) off[q + 1] += off[q];
+    char* buf = (char*)big_alloc(off.back() + 1);
+    if (!buf) return fail(SXG_E_NOMEM, "out of memory for the GFA text");
+    memcpy(buf, head, sizeof(head) - 1);
+    int64_t wrong = 0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : wrong)
+    for (int64_t q = 1; q < (int64_t)pieces; ++q) {
+        const size_t x = (size_t)q;
+        write_sink_t sk{buf + off[x]};
+        if (x < P_L) emit_S(sk, (int64_t)(x - P_S));
+        else if (x < P_F) emit_L(sk, (int64_t)(x - P_L));
+        else if (x < P_C) {
+            const size_t f = x - P_F, rq = run_of[f];
+            if (f == runs[rq].first) { const std::string& nm = g->pname[mapping[f].path]; sk.ch('P'); sk.ch('\t'); sk.raw(nm.data(), nm.size()); sk.ch('\t'); }
+            emit_F(sk, f, !lead[f]);
+            if (f + 1 == runs[rq].second) sk.raw("\t*\n", 3);
+        } else emit_C(sk, cons_blocks[x - P_C]);
+        if (sk.o != buf + off[x + 1]) ++wrong;
+    }
+    if (wrong) { free(buf); return fail(SXG_E_INVALID, "internal: GFA size and write passes disagree"); }
+    buf[off.back()] = 0;
+    (void)n_laced;
+    *out_gfa = buf;
+    lap("GFA text");
+    return SXG_OK;
+}
+
 char* dup_out(const std::string& s) {
     char* r = (char*)malloc(s.size() + 1);
     if (r) memcpy(r, s.c_str(), s.size() + 1);
@@ -1372,8 +1999,13 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
     // depend on what else is in a batch, so the output is the same for every chunking.  A batch below 2 x
     // SXG_SMOOTH_CHUNK_BLOCKS blocks (default 2048; the headline's 1000 x 64 x 5 kbp) is ONE chunk: one provider call, as before.
     struct frag_t { uint64_t path, start, end; int64_t target, block; };
+    // Without the MAF consumer (no flips, no merged consensus paths) the iteration works on compact block graphs -- asked of
+    // the provider (the GPU engine builds them on the device), built here from raw results otherwise -- and laces them
+    // without materialising the laced graph (lace_fast).  SXG_SMOOTH_LEGACY=1 keeps the ograph_t path for A/B runs and tests.
+    const bool fast = !mp && !getenv("SXG_SMOOTH_LEGACY");
     std::vector<collected_t> col((size_t)nb);
-    std::vector<ograph_t> graphs((size_t)nb);
+    std::vector<ograph_t> graphs(fast ? 0 : (size_t)nb);
+    std::vector<cblock_t> cblocks(fast ? (size_t)nb : 0);
     std::vector<omap_t> block_mafs(mp ? (size_t)nb : 0);
     std::vector<char> groom(mp ? (size_t)nb : 0, 0);
     std::unordered_map<std::string, size_t> rank_of;
@@ -1382,6 +2014,8 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         int64_t k0 = 0, k1 = 0;
         batch_t B;
         std::vector<sxg_poa_params> pps;
+        std::vector<int32_t> trims;
+        bool keep_out = false;   // block graphs of this chunk are views of `out`: released when the text is written
         sxg_poa_batch_in in;
         sxg_poa_batch_out out;
         uint8_t dummy = 0;
@@ -1435,6 +2069,11 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         C.in.per_block_params = p->adaptive_poa_params && n > 0 ? 1 : 0;
         C.in.want_consensus = p->add_consensus;
         C.in.want_msa = mp ? 1 : 0;   // the MAF rows (and with them the merge / flip decisions) need the blocks' MSAs
+        if (fast) {   // A9 + A10 asked of the provider: trim = the block's padding, consensus filter of the abPOA path
+            C.trims.resize((size_t)std::max<int64_t>(n, 1), 0);
+            for (int64_t k = 0; k < n; ++k) C.trims[(size_t)k] = col[(size_t)(k0 + k)].poa_padding;
+            C.in.want_block_graph = 2; C.in.bg_trim = C.trims.data(); C.in.bg_consensus_visited_only = p->use_abpoa ? 1 : 0;
+        }
         t_collect += since(t0);
     };
     // stage 2: ONE batched POA call per chunk (replaces src/smooth.cpp:752-786 of every block)
@@ -1444,10 +2083,28 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         const auto t0 = std::chrono::steady_clock::now();
         const sxg_poa_batch_out& out = C.out;
         const int64_t k0 = C.k0;
+        const bool have_bg = fast && out.bg_node_off && out.bg_node_len && out.bg_node_outdeg && out.bg_node_indeg && out.bg_seq_off &&
+                             out.bg_edge_off && out.bg_step_off && (out.bg_seq || out.bg_seq_off[C.k1 - C.k0] == 0);
+        if (have_bg) C.keep_out = true;
 #pragma omp parallel for schedule(dynamic, 1)
         for (int64_t k = C.k0; k < C.k1; ++k) {
             if (col[(size_t)k].seqs.empty()) continue;
             const int64_t slot = k - k0;
+            if (fast) {
+                const collected_t& c = col[(size_t)k];
+                cblock_t& Bk = cblocks[(size_t)k];
+                if (have_bg) cblock_from_out(Bk, c, b->blocks[(size_t)k].size(), C.B, out, slot, p->add_consensus != 0);
+                else {
+                    std::vector<const int32_t*> sp;
+                    for (int32_t sq = C.B.blk_off[(size_t)slot]; sq < C.B.blk_off[(size_t)slot + 1]; ++sq) sp.push_back(out.seq_path_nodes + C.B.seq_off[(size_t)sq]);
+                    const int64_t n0 = out.node_off[slot], nn = out.node_off[slot + 1] - n0;
+                    const bool hc = p->add_consensus && out.cons_nodes && out.cons_off;
+                    cblock_from_raw(Bk, c, b->blocks[(size_t)k].size(), out.node_code + n0, nn, sp, hc ? out.cons_nodes + out.cons_off[slot] : nullptr,
+                                    hc ? out.cons_off[slot + 1] - out.cons_off[slot] : 0, p->add_consensus != 0, p->use_abpoa != 0);
+                }
+                collected_t().seqs.swap(col[(size_t)k].seqs);
+                continue;
+            }
             graphs[(size_t)k] = block_graph_from_out(col[(size_t)k], C.B, out, slot, cons_name(*p, k), p->use_abpoa != 0);
             if (mp) {   // MSA -> MAF rows of the block (src/smooth.cpp:782-905), and its grooming orientation (:1826-1842)
                 const collected_t& c = col[(size_t)k];
@@ -1481,17 +2138,31 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
             if (C.rc == SXG_NOT_ROOT) not_root = true;   // multi-GPU provider (sxg_poa_batch_run_sharded) on a rank that does not lace
             else if (C.rc != SXG_OK) { if (fail_rc == SXG_OK) { fail_rc = C.rc; fail_msg = "POA provider failed"; } }
             else if (mp && C.k1 > C.k0 && (!C.out.msa || !C.out.msa_off || !C.out.msa_cols)) { if (fail_rc == SXG_OK) { fail_rc = SXG_E_INVALID; fail_msg = "POA provider returned no MSA"; } }
+            else if (fast && C.k1 > C.k0 && !C.out.bg_node_off && (!C.out.seq_path_nodes || !C.out.node_off || !C.out.node_code)) {
+                if (fail_rc == SXG_OK) { fail_rc = SXG_E_INVALID; fail_msg = "POA provider returned neither block graphs nor per-base paths"; }
+            }
             else if (fail_rc == SXG_OK && !not_root) finish(C);
-            if (fre) fre(&C.out);
+            if (fre && !C.keep_out) fre(&C.out);
             batch_t().bases.swap(C.B.bases);
         }
-        if (fail_rc != SXG_OK) return fail(fail_rc, fail_msg);
-        if (not_root) return fail(SXG_NOT_ROOT, "not the lacing rank");
+        auto release_outs = [&]() { for (auto& C : chunks) if (C.keep_out && fre) { fre(&C.out); C.keep_out = false; } };
+        if (fail_rc != SXG_OK) { release_outs(); return fail(fail_rc, fail_msg); }
+        if (not_root) { release_outs(); return fail(SXG_NOT_ROOT, "not the lacing rank"); }
     }
     if (timing) {
         fprintf(stderr, "[sxg_smooth] %-22s %.3f s  (%lld chunk%s; collect %.3f s, waiting for the POA provider %.3f s, block graphs %.3f s)\n",
                 "collect|POA|graphs", since(T0), (long long)nc, nc == 1 ? "" : "s, pipelined", t_collect, t_wait, t_graphs);
         T0 = std::chrono::steady_clock::now();
+    }
+    if (fast) {
+        const int rc = lace_fast(g, b, p, cblocks, out_gfa, lap);
+        {   // the block graphs (views of the providers' results, or built here) go in parallel
+#pragma omp parallel for schedule(dynamic, 16)
+            for (int64_t k = 0; k < nb; ++k) { cblock_t none; std::swap(none, cblocks[(size_t)k]); }
+            for (auto& C : chunks) if (C.keep_out && fre) { fre(&C.out); C.keep_out = false; }
+        }
+        lap("teardown");
+        return rc;
     }
     // the in-order MAF consumer: merges contiguous blocks, decides which block graphs get flipped (-M), writes the MAF
     merge_state_t mstate;

@@ -34,7 +34,8 @@ _i32p, _i64p, _u8p, _u32p, _u64p = (C.POINTER(C.c_int32), C.POINTER(C.c_int64), 
 class BatchIn(C.Structure):
     _fields_ = [("n_blocks", C.c_int32), ("blk_off", _i32p), ("seq_off", _i64p), ("bases", _u8p),
                 ("weights", _u32p), ("params", C.POINTER(Params)), ("per_block_params", C.c_int32),
-                ("want_consensus", C.c_int32), ("want_msa", C.c_int32)]
+                ("want_consensus", C.c_int32), ("want_msa", C.c_int32),
+                ("want_block_graph", C.c_int32), ("bg_consensus_visited_only", C.c_int32), ("bg_trim", _i32p)]
 
 
 class BatchOut(C.Structure):
@@ -43,6 +44,9 @@ class BatchOut(C.Structure):
                 ("edge_tail", _i32p), ("edge_head", _i32p), ("edge_weight", _u32p),
                 ("seq_path_nodes", _i32p), ("score", _i32p), ("cells", _u64p), ("cons_off", _i64p),
                 ("cons_nodes", _i32p), ("msa_off", _i64p), ("msa_cols", _i32p), ("msa", C.c_void_p),
+                ("bg_node_off", _i64p), ("bg_node_len", _i32p), ("bg_node_outdeg", _i32p), ("bg_node_indeg", _u8p),
+                ("bg_seq_off", _i64p), ("bg_seq", C.c_void_p), ("bg_edge_off", _i64p), ("bg_edge_to", _i32p),
+                ("bg_step_off", _i64p), ("bg_steps", _i32p), ("bg_cons_off", _i64p), ("bg_cons_steps", _i32p),
                 ("_owner", C.c_void_p)]
 
 
@@ -62,7 +66,7 @@ class Stats(C.Structure):
                 ("algo_bytes", C.c_uint64), ("n_slots", C.c_int32), ("retries", C.c_int32),
                 ("device_bytes", C.c_uint64), ("dom_kernel_ms", C.c_double), ("dom_cells", C.c_uint64),
                 ("dom_algo_bytes", C.c_uint64), ("dom_threads", C.c_int32), ("dom_cols_per_lane", C.c_int32),
-                ("dom_row_mode", C.c_int32), ("dom_clock_mhz", C.c_int32)]
+                ("dom_row_mode", C.c_int32), ("dom_clock_mhz", C.c_int32), ("bg_ms", C.c_double)]
 
 
 class DeviceView(C.Structure):
@@ -144,7 +148,27 @@ def _arr(ptr, n, dtype):
 class BlockResult:
     """POA result of one block (what build_odgi_SPOA reads from spoa::Graph)."""
     __slots__ = ("status", "node_code", "node_rank", "node_group", "edge_tail", "edge_head", "edge_weight",
-                 "paths", "scores", "cells", "consensus", "msa")
+                 "paths", "scores", "cells", "consensus", "msa", "bg")
+
+
+class BlockGraph:
+    """Normalised block graph of one block (want_block_graph): node sequences, forward edges (from, to) sorted, one path
+    of node ids per dedup'd sequence, the consensus path."""
+    __slots__ = ("node_seq", "node_indeg", "edges", "paths", "consensus")
+
+    def gfa(self, names, revs=None, consensus_name=None):
+        """GFA text in the convention of sxg_block_graph_gfa (names[i]: names of the duplicates of sequence i,
+        revs[i][j]: collected in reverse)."""
+        o = ["H\tVN:Z:1.0"]
+        o += ["S\t%d\t%s" % (i + 1, s) for i, s in enumerate(self.node_seq)]
+        o += ["L\t%d\t+\t%d\t+\t0M" % (a + 1, b + 1) for a, b in self.edges]
+        for i, p in enumerate(self.paths):
+            for j, nm in enumerate(names[i]):
+                st = ["%d-" % (v + 1) for v in p[::-1]] if revs is not None and revs[i][j] else ["%d+" % (v + 1) for v in p]
+                o.append("P\t%s\t%s\t*" % (nm, ",".join(st)))
+        if consensus_name is not None:
+            o.append("P\t%s\t%s\t*" % (consensus_name, ",".join("%d+" % (v + 1) for v in self.consensus)))
+        return "\n".join(o) + "\n"
 
 
 class PoaEngine:
@@ -180,7 +204,8 @@ class PoaEngine:
         self.lib.sxg_poa_set_memory_budget(self.h, int(nbytes))
 
     # -- flat batch -----------------------------------------------------------------
-    def _mk_in(self, bases, seq_off, blk_off, weights, params, want_consensus, want_msa):
+    def _mk_in(self, bases, seq_off, blk_off, weights, params, want_consensus, want_msa, block_graph=0, bg_trim=None,
+               bg_cons_visited_only=False):
         bases = np.ascontiguousarray(bases, np.uint8)
         seq_off = np.ascontiguousarray(seq_off, np.int64)
         blk_off = np.ascontiguousarray(blk_off, np.int32)
@@ -193,14 +218,19 @@ class PoaEngine:
             per = 1
         w = None if weights is None else np.ascontiguousarray(weights, np.uint32)
         bpad = bases if len(bases) else np.zeros(1, np.uint8)
+        trim = None if bg_trim is None else np.ascontiguousarray(bg_trim, np.int32)
         bi = BatchIn(nb, _p(blk_off, C.c_int32), _p(seq_off, C.c_int64), _p(bpad, C.c_uint8),
                      _p(w, C.c_uint32) if w is not None else None, parr, per, int(want_consensus),
-                     int(want_msa))
-        self._keep = (bpad, seq_off, blk_off, w, parr)
+                     int(want_msa), int(block_graph), int(bool(bg_cons_visited_only)),
+                     _p(trim, C.c_int32) if trim is not None else None)
+        self._keep = (bpad, seq_off, blk_off, w, parr, trim)
         return bi
 
-    def upload(self, bases, seq_off, blk_off, weights, params, want_consensus=False, want_msa=False):
-        bi = self._mk_in(bases, seq_off, blk_off, weights, params, want_consensus, want_msa)
+    def upload(self, bases, seq_off, blk_off, weights, params, want_consensus=False, want_msa=False, block_graph=0,
+               bg_trim=None, bg_cons_visited_only=False):
+        """block_graph: 1 = also the normalised block graphs (BlockResult.bg), 2 = ... without the per-base paths."""
+        bi = self._mk_in(bases, seq_off, blk_off, weights, params, want_consensus, want_msa, block_graph, bg_trim,
+                         bg_cons_visited_only)
         if self.lib.sxg_poa_batch_upload(self.h, C.byref(bi)):
             raise self._err("sxg_poa_batch_upload")
         self._shape = (np.asarray(blk_off).copy(), np.asarray(seq_off).copy())
@@ -247,7 +277,20 @@ class PoaEngine:
         eh = _arr(out.edge_head, ne, np.int32)
         ew = _arr(out.edge_weight, ne, np.uint32)
         nbases = int(seq_off[-1]) if ns else 0
-        paths = _arr(out.seq_path_nodes, nbases, np.int32)
+        paths = _arr(out.seq_path_nodes, nbases, np.int32) if out.seq_path_nodes else None
+        bg = None
+        if out.bg_node_off:
+            bno = _arr(out.bg_node_off, nb + 1, np.int64)
+            bso = _arr(out.bg_seq_off, nb + 1, np.int64)
+            beo = _arr(out.bg_edge_off, nb + 1, np.int64)
+            bpo = _arr(out.bg_step_off, ns + 1, np.int64)
+            bg = dict(no=bno, so=bso, eo=beo, po=bpo, ln=_arr(out.bg_node_len, int(bno[-1]), np.int32),
+                      od=_arr(out.bg_node_outdeg, int(bno[-1]), np.int32), idg=_arr(out.bg_node_indeg, int(bno[-1]), np.uint8),
+                      sq=C.string_at(out.bg_seq, int(bso[-1])) if bso[-1] else b"", to=_arr(out.bg_edge_to, int(beo[-1]), np.int32),
+                      st=_arr(out.bg_steps, int(bpo[-1]), np.int32))
+            if out.bg_cons_off:
+                bg["co"] = _arr(out.bg_cons_off, nb + 1, np.int64)
+                bg["cs"] = _arr(out.bg_cons_steps, int(bg["co"][-1]), np.int32)
         score = _arr(out.score, ns, np.int32)
         cells = _arr(out.cells, ns, np.uint64)
         cons_off = _arr(out.cons_off, nb + 1, np.int64) if out.cons_off else None
@@ -266,7 +309,20 @@ class PoaEngine:
             a, z = edge_off[b], edge_off[b + 1]
             r.edge_tail, r.edge_head, r.edge_weight = et[a:z], eh[a:z], ew[a:z]
             s0, s1 = int(blk_off[b]), int(blk_off[b + 1])
-            r.paths = [paths[int(seq_off[s]):int(seq_off[s + 1])] for s in range(s0, s1)]
+            r.paths = [paths[int(seq_off[s]):int(seq_off[s + 1])] for s in range(s0, s1)] if paths is not None else None
+            r.bg = None
+            if bg is not None:
+                g = BlockGraph()
+                a, z = int(bg["no"][b]), int(bg["no"][b + 1])
+                ln, od = bg["ln"][a:z], bg["od"][a:z]
+                g.node_indeg = bg["idg"][a:z]
+                so = int(bg["so"][b]) + np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+                g.node_seq = [bg["sq"][int(so[i]):int(so[i + 1])].decode() for i in range(z - a)]
+                to = bg["to"][int(bg["eo"][b]):int(bg["eo"][b + 1])]
+                g.edges = list(zip(np.repeat(np.arange(z - a), od).tolist(), to.tolist()))
+                g.paths = [bg["st"][int(bg["po"][s]):int(bg["po"][s + 1])] for s in range(s0, s1)]
+                g.consensus = bg["cs"][int(bg["co"][b]):int(bg["co"][b + 1])] if "co" in bg else None
+                r.bg = g
             r.scores, r.cells = score[s0:s1], cells[s0:s1]
             r.consensus = cons[cons_off[b]:cons_off[b + 1]] if cons is not None else None
             r.msa = None
@@ -278,8 +334,9 @@ class PoaEngine:
         return res
 
     def run_flat(self, bases, seq_off, blk_off, weights, params, want_consensus=False, want_msa=False,
-                 check=True):
-        self.upload(bases, seq_off, blk_off, weights, params, want_consensus, want_msa)
+                 check=True, block_graph=0, bg_trim=None, bg_cons_visited_only=False):
+        self.upload(bases, seq_off, blk_off, weights, params, want_consensus, want_msa, block_graph, bg_trim,
+                    bg_cons_visited_only)
         self.execute(check=check)
         return self.download()
 

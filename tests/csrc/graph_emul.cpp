@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include "../../smoothxg_amd/csrc/poa_graph_dev.h"
+#include "../../smoothxg_amd/csrc/poa_bgraph_dev.h"
 #include "../../oracle/poa_oracle.h"
 
 using namespace sxg;
@@ -18,6 +19,10 @@ struct SerialCtx {
     int scan_excl_max(int v, int* total) { *total = v; return -0x7fffffff; }
     int reduce_max(int v) { return v; }
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
+    int load_fresh(const int32_t* p) { return *p; }
+    std::vector<int> hp = std::vector<int>(4);   // (tiny on purpose: the ordering phase's spill to HBM gets exercised)
+    int* heap() { return hp.data(); }
+    int heap_cap() { return (int)hp.size(); }
 };
 
 extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int n_seqs,
@@ -78,4 +83,28 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
     if (row_hints) for (int r = 0; r < hdr[0]; ++r) row_hints[r] = xps[ord[r]];   // band hints of the packed sweep (decree B2)
     if (row_remain && hdr[0] > 0) rows_remain(c, G, hdr[0], row_remain);          // decree B4 (pointer jumping over heaviest out-edges)
     return 0;
+}
+
+
+// The block-graph phase (poa_bgraph_dev.h) on one block's POA results.  Outputs are sized by the caller:
+// node arrays [V], eto [E + n_cons], steps [total bases], nsteps [n_seqs], cons_steps [n_cons], counts [5].
+extern "C" int emul_block_graph(const uint8_t* node_code, int V, const int32_t* e_tail, const int32_t* e_head, int E,
+                                const int32_t* paths, const uint8_t* bases, const int64_t* seq_off, int n_seqs, int trim,
+                                const int32_t* cons, int n_cons, int cons_mode, int32_t* node_len, int32_t* node_outdeg,
+                                uint8_t* node_indeg, char* seq, int32_t* eto, int32_t* steps, int32_t* nsteps, int32_t* cons_steps,
+                                int32_t* counts) {
+    int64_t maxlen = 1;
+    for (int s = 0; s < n_seqs; ++s) maxlen = std::max<int64_t>(maxlen, seq_off[s + 1] - seq_off[s]);
+    const size_t C = (size_t)V + 2, EC = (size_t)E + (size_t)n_cons + 2, TC = (size_t)std::max<int64_t>(std::max<int64_t>(V, maxlen), n_cons) + 2;
+    std::vector<std::vector<int32_t>> a(32, std::vector<int32_t>(C));
+    std::vector<int32_t> ehead(EC), eused(EC), csucc(EC), cc((size_t)n_cons + 2), tmp(TC), flag(4);
+    BgScratch W{a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), ehead.data(), eused.data(), a[5].data(), a[6].data(), a[7].data(),
+                a[8].data(), a[9].data(), a[10].data(), a[11].data(), a[12].data(), a[13].data(), a[14].data(), a[15].data(), a[16].data(),
+                a[17].data(), a[18].data(), a[19].data(), a[20].data(), csucc.data(), cc.data(), tmp.data(), a[21].data(), a[22].data(),
+                a[23].data(), a[24].data(), flag.data()};
+    BgIn I{node_code, V, E, e_tail, e_head, paths, bases, seq_off, 0, n_seqs, trim, cons, n_cons, cons_mode};
+    BgOut O{node_len, node_outdeg, node_indeg, seq, eto, steps, nsteps, cons_steps, counts};
+    SerialCtx c;
+    block_graph(c, I, W, O);
+    return counts[BGC_STATUS];
 }

@@ -25,14 +25,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "missing export " + n
     from smoothxg_amd import poa
     assert sorted(poa.EXPORTS) == names
-    assert lib.sxg_poa_abi_version() == 3
+    assert lib.sxg_poa_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
     from smoothxg_amd import poa
     assert C.sizeof(poa.Params) == 8
-    assert C.sizeof(poa.BatchIn) == 8 + 5 * 8 + 3 * 4 + 4  # n_blocks(+pad), 5 pointers, 3 ints (+pad)
-    assert C.sizeof(poa.Stats) == 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 4 + 4 + 4 + 4
+    assert C.sizeof(poa.BatchIn) == 8 + 5 * 8 + 5 * 4 + 4 + 8  # n_blocks(+pad), 5 pointers, 5 ints (+pad), bg_trim
+    assert C.sizeof(poa.BatchOut) == 8 + 8 + 17 * 8 + 12 * 8 + 8   # n_blocks(+pad), n_seqs, 17 + 12 (block graph) pointers, _owner
+    assert C.sizeof(poa.Stats) == 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 4 + 4 + 4 + 4 + 8
 
 
 def test_xxh64_product_matches_python_xxhash():
@@ -66,3 +67,21 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"#\s*include[^\n]*oracle", txt), f
                 assert not re.search(r"^\s*(from|import)\s+[^\n]*oracle", txt, flags=re.M), f
                 assert "libpoa_oracle" not in txt, f
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """sxg_poa_comm_* with no loadable librccl: SXG_E_NODEVICE and a message (the dlerror text used to be read twice,
+    the second read returning NULL into a std::string)."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, smoothxg_amd as S\n"
+            "L = S.load_library()\n"
+            "buf = (C.c_uint8 * 128)()\n"
+            "rc = L.sxg_poa_comm_unique_id(buf)\n"
+            "msg = L.sxg_poa_last_error().decode()\n"
+            "assert rc == -2, rc\n"
+            "assert 'librccl' in msg and 'no-such-rccl' in msg, msg\n"
+            "print('ok')\n")
+    env = dict(os.environ, SXG_POA_RCCL_LIB="/no-such-rccl.so", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

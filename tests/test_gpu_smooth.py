@@ -166,3 +166,67 @@ def test_drb1_three_chained_iterations_as_the_reference_ctest_runs_them(engine):
         assert sorted(names) == sorted(g0.pname) and len(out.pname) == gold[it]["paths"]
         for q, nm in enumerate(g0.pname):
             assert out.path_sequence(out.pname.index(nm)) == g0.path_sequence(q)
+
+
+@pytest.mark.parametrize("cons_mode", [0, 1, 2])
+def test_device_block_graphs_equal_the_restatement(engine, oracle, cons_mode):
+    """sxg_poa_batch_in::want_block_graph: A9 + A10 computed by the block-graph kernel right after the alignments (trim,
+    path-supported edges, unchop, Kahn order, compact step lists) through the C ABI, against the Python restatement
+    (oracle/smooth_oracle.py::build_block_graph) fed with the oracle's POA of the same block; with and without padding trim,
+    spoa-style and abPOA-style (visited nodes only) consensus; mode 2 leaves the per-base paths out."""
+    import numpy as np
+    import smoothxg_amd as SX
+    from helpers import random_block
+    rng = np.random.default_rng(170 + cons_mode)
+    blocks, trims = [], []
+    for trial in range(24):
+        S_ = int(rng.integers(1, 14))
+        if trial % 6 == 0:
+            seqs = [rng.integers(0, 5, int(rng.integers(1, 40)), dtype=np.uint8) for _ in range(S_)]
+        elif trial % 6 == 1:
+            seqs = random_block(rng, S_, int(rng.integers(1500, 2600)), div=0.03)
+        else:
+            seqs = random_block(rng, S_, int(rng.integers(2, 500)), div=0.08)
+        blocks.append(seqs)
+        trims.append(0 if trial % 3 == 0 else int(rng.integers(1, 30)))
+    prm = SX.Params(1, -4, -6, -2, -26, -1, 0, 0)
+    flat = [s for blk in blocks for s in blk]
+    bases = np.concatenate(flat).astype(np.uint8)
+    seq_off = np.zeros(len(flat) + 1, np.int64)
+    seq_off[1:] = np.cumsum([len(s) for s in flat])
+    blk_off = np.zeros(len(blocks) + 1, np.int32)
+    blk_off[1:] = np.cumsum([len(b) for b in blocks])
+    for mode in (1, 2):
+        res = engine.run_flat(bases, seq_off, blk_off, None, prm, want_consensus=cons_mode > 0, block_graph=mode, bg_trim=trims,
+                              bg_cons_visited_only=(cons_mode == 2))
+        assert (res[0].paths is None) == (mode == 2)
+        for b, seqs in enumerate(blocks):
+            assert res[b].status == 0
+            g, _, _ = oracle.block_run(seqs, None, oracle.mkparams(1, -4, -6, -2, -26, -1, 0))
+            c = SO.Collected()
+            c.poa_padding = trims[b]
+            c.seqs = ["".join("ACGTN"[min(int(x), 4)] for x in s) for s in seqs]
+            c.dup_seq_names = [["s%d" % i] for i in range(len(seqs))]
+            c.dup_is_revs = [[False] for _ in seqs]
+            c.all_names = ["s%d" % i for i in range(len(seqs))]
+            G = SO.build_block_graph(c, g.nodes()[0], [g.seq_path(k) for k in range(len(seqs))], g.consensus(),
+                                     "cons" if cons_mode else "", abpoa=(cons_mode == 2))
+            assert res[b].bg.gfa(c.dup_seq_names, None, "cons" if cons_mode else None) == SO.to_gfa(G), (mode, b)
+
+
+def test_device_block_graphs_feed_the_same_gfa_as_host_built_ones(engine, monkeypatch):
+    """The iteration asks the engine for block graphs (want_block_graph = 2) and laces them without the laced graph;
+    SXG_SMOOTH_LEGACY=1 builds block graphs on the host from the per-base paths and laces through ograph_t: same bytes,
+    with padding and consensus paths, on DRB1 with real block discovery."""
+    text = open(DRB1).read()
+    for cons in (0, 1):
+        sm = S.Smoother(text, discover=dict(target_poa_length=700, n_haps=12, max_path_jump=5000, max_edge_jump=5000))
+        p = S.default_params(add_consensus=cons)
+        monkeypatch.delenv("SXG_SMOOTH_LEGACY", raising=False)
+        fast = sm.smooth_gfa(p, S.gpu_provider(engine))
+        assert engine.stats()["bg_ms"] > 0
+        monkeypatch.setenv("SXG_SMOOTH_LEGACY", "1")
+        legacy = sm.smooth_gfa(p, S.gpu_provider(engine))
+        monkeypatch.delenv("SXG_SMOOTH_LEGACY", raising=False)
+        sm.close()
+        assert fast == legacy

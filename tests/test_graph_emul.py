@@ -82,3 +82,77 @@ def test_row_pool_overflow_is_reported(emul, oracle):
     assert st == 2
     st, _ = run_emul(emul, seqs + [anc.copy()], [1, 1, 1, 1], oparams("convex_default", 1), pool=64)
     assert st == 0
+
+
+def run_block_graph_emul(L, g, seqs, trim, cons_mode):
+    """poa_bgraph_dev.h (one-thread context) on the oracle's POA result of a block -> smoothxg_amd.poa.BlockGraph"""
+    from smoothxg_amd.poa import BlockGraph
+    code = np.ascontiguousarray(g.nodes()[0], np.uint8)
+    et, eh, _ = g.edges()
+    et, eh = np.ascontiguousarray(et, np.int32), np.ascontiguousarray(eh, np.int32)
+    paths = np.ascontiguousarray(np.concatenate([g.seq_path(s) for s in range(g.n_seqs)]), np.int32)
+    bases = np.ascontiguousarray(np.concatenate(seqs), np.uint8)
+    off = np.zeros(len(seqs) + 1, np.int64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    cons = np.ascontiguousarray(g.consensus(), np.int32)
+    V, E, nc = len(code), len(et), len(cons)
+    pad = lambda a: a if len(a) else np.zeros(1, a.dtype)
+    nl, od = np.zeros(V + 1, np.int32), np.zeros(V + 1, np.int32)
+    idg = np.zeros(V + 1, np.uint8)
+    sq = np.zeros(V + 1, np.uint8)
+    eto = np.zeros(E + nc + 1, np.int32)
+    steps, nst = np.zeros(len(bases) + 1, np.int32), np.zeros(len(seqs) + 1, np.int32)
+    cst, cnt = np.zeros(nc + 1, np.int32), np.zeros(5, np.int32)
+    st = L.emul_block_graph(_p(pad(code), C.c_uint8), V, _p(pad(et), C.c_int32), _p(pad(eh), C.c_int32), E, _p(pad(paths), C.c_int32),
+                            _p(pad(bases), C.c_uint8), _p(off, C.c_int64), len(seqs), trim, _p(pad(cons), C.c_int32), nc, cons_mode,
+                            _p(nl, C.c_int32), _p(od, C.c_int32), _p(idg, C.c_uint8), sq.ctypes.data_as(C.c_char_p), _p(eto, C.c_int32),
+                            _p(steps, C.c_int32), _p(nst, C.c_int32), _p(cst, C.c_int32), _p(cnt, C.c_int32))
+    assert st == 0
+    n, ne, nb, ncs = (int(x) for x in cnt[:4])
+    B = BlockGraph()
+    so = np.concatenate([[0], np.cumsum(nl[:n])])
+    assert so[-1] == nb
+    text = sq[:nb].tobytes().decode()
+    B.node_seq = [text[so[i]:so[i + 1]] for i in range(n)]
+    B.node_indeg = idg[:n]
+    assert od[:n].sum() == ne
+    B.edges = list(zip(np.repeat(np.arange(n), od[:n]).tolist(), eto[:ne].tolist()))
+    po = np.concatenate([[0], np.cumsum(nst[:len(seqs)])])
+    B.paths = [steps[po[s]:po[s + 1]] for s in range(len(seqs))]
+    B.consensus = cst[:ncs]
+    return B
+
+
+@pytest.mark.parametrize("cons_mode", [0, 1, 2])
+def test_block_graph_phase_matches_the_restatement(emul, oracle, cons_mode):
+    """A9 + A10 as the GPU computes them (trim, path-supported edges, unchop, Kahn order, compact paths) against the Python
+    restatement (oracle/smooth_oracle.py::build_block_graph), on POA graphs of random blocks, with and without padding
+    trim, with the spoa-style and the abPOA-style (visited nodes only) consensus path."""
+    from oracle import smooth_oracle as SO
+    rng = np.random.default_rng(70 + cons_mode)
+    p = oparams("convex_default", 0)
+    for trial in range(40):
+        S = int(rng.integers(1, 14))
+        if trial % 5 == 0:
+            seqs = [rng.integers(0, 5, int(rng.integers(1, 40)), dtype=np.uint8) for _ in range(S)]
+        else:
+            seqs = random_block(rng, S, int(rng.integers(2, 400)), div=0.08)
+        trim = 0 if trial % 3 == 0 else int(rng.integers(1, 30))
+        g, _, _ = oracle.block_run(seqs, None, p)
+        B = run_block_graph_emul(emul, g, seqs, trim, cons_mode)
+        c = SO.Collected()
+        c.poa_padding = trim
+        c.seqs = ["".join("ACGTN"[min(int(x), 4)] for x in s) for s in seqs]
+        c.dup_seq_names = [["s%d" % i] for i in range(len(seqs))]
+        c.dup_is_revs = [[False] for _ in seqs]
+        c.all_names = ["s%d" % i for i in range(len(seqs))]
+        G = SO.build_block_graph(c, g.nodes()[0], [g.seq_path(k) for k in range(len(seqs))], g.consensus(),
+                                 "cons" if cons_mode else "", abpoa=(cons_mode == 2))
+        want = SO.to_gfa(G)
+        got = B.gfa(c.dup_seq_names, None, "cons" if cons_mode else None)
+        assert got == want, (trial, trim)
+        # in-degrees (the lacing's unchop test reads them)
+        ind = np.zeros(len(B.node_seq), np.int64)
+        for a, b in B.edges:
+            ind[b] += 1
+        assert (np.minimum(ind, 255) == B.node_indeg).all()

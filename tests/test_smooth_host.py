@@ -642,3 +642,38 @@ def test_parallel_forms_of_unchop_and_gfa_writer_equal_the_serial_ones():
         e.update(env)
         outs.append(subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True, timeout=600).stdout)
     assert outs[0] == outs[1] and outs[0].startswith("H\tVN:Z:1.0")
+
+
+@pytest.mark.parametrize("case", ["synthetic", "synthetic_cons", "haplotypes", "haplotypes_nopad", "inversion", "abpoa_cons", "drb1", "drb1_cons"])
+def test_flat_lacing_equals_the_laced_graph_path(case, monkeypatch):
+    """The iteration without the MAF consumer laces compact block graphs without building the laced graph (lace_fast:
+    fragments, incremental global unchop, edges merged by position).  SXG_SMOOTH_LEGACY=1 takes the ograph_t path instead:
+    same bytes on graphs with reverse steps, merges across block boundaries (no consensus paths to block them), padding on
+    and off, the abPOA consensus filter and the reference's DRB1 input with real block discovery."""
+    prov = OracleProvider()
+    kw = {}
+    if case.startswith("synthetic"):
+        jobs = [(synthetic_gfa(seed), dict(target_bp=tb)) for seed in (0, 1, 2, 3) for tb in (90, 200)]
+    elif case.startswith("haplotypes"):
+        jobs = [(haplotype_gfa(seed, n_paths=6, length=1500), dict(target_bp=tb)) for seed in (0, 1) for tb in (300, 500)]
+        if case.endswith("nopad"):
+            kw["poa_padding_fraction"] = 0.0
+    elif case == "inversion":
+        jobs = [(inversion_gfa(3), dict(target_bp=300))]
+    elif case == "abpoa_cons":
+        jobs = [(haplotype_gfa(4, n_paths=5, length=1200), dict(target_bp=400))]
+        kw.update(use_abpoa=1, add_consensus=1)
+    else:
+        jobs = [(open(DRB1).read(), dict(discover=dict(target_poa_length=700, n_haps=12, max_path_jump=5000, max_edge_jump=5000)))]
+    if case.endswith("_cons"):
+        kw["add_consensus"] = 1
+    for gfa, how in jobs:
+        sm = S.Smoother(gfa, **how)
+        p = S.default_params(**kw)
+        monkeypatch.delenv("SXG_SMOOTH_LEGACY", raising=False)
+        fast = sm.smooth_gfa(p, prov.provider())
+        monkeypatch.setenv("SXG_SMOOTH_LEGACY", "1")
+        legacy = sm.smooth_gfa(p, prov.provider())
+        monkeypatch.delenv("SXG_SMOOTH_LEGACY", raising=False)
+        sm.close()
+        assert fast == legacy
