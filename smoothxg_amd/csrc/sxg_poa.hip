@@ -671,6 +671,18 @@ static int row_mode(const Scoring& S, int maxlen, int rows, int at_least = 2) {
     return 1;
 }
 
+// SXG_POA_DEBUG: wall-clock laps of the host side (stderr)
+struct HostLaps {
+    bool on = getenv("SXG_POA_DEBUG") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sxg] host %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -847,6 +859,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     if (in->n_blocks < 0 || (in->n_blocks > 0 && (!in->blk_off || !in->seq_off || !in->params)))
         return fail(SXG_E_INVALID, "batch_in has NULL arrays");
     HIPCHK(hipSetDevice(h->device));
+    HostLaps laps;
     h->have_batch = false; h->executed = false;
     const int nb = in->n_blocks;
     if (nb > 0 && in->blk_off[0] != 0) return fail(SXG_E_INVALID, "blk_off[0] must be 0");
@@ -911,6 +924,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
             dirty = acc != 0;
         }
     }
+    laps.lap("upload: checks");
     std::vector<uint8_t> stage;
     if (dirty) {
         stage.resize((size_t)nbases);
@@ -950,6 +964,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
         return rc;
     if (h->want_consensus && (rc = h->d_cons.ensure(4 * NB))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
+    laps.lap("upload: copies");
     h->have_batch = true;
     h->sh_dealt = false; h->sh_exchanged = false;   // (a plain upload: no deal the root could reassemble by)
     return SXG_OK;
@@ -1552,6 +1567,7 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
     memset(out, 0, sizeof(*out));
     if (!h->have_batch || !h->executed) return fail(SXG_E_INVALID, "no executed batch to download");
     HIPCHK(hipSetDevice(h->device));
+    HostLaps laps;
     const int nb = h->n_blocks;
     const int64_t ns = h->n_seqs;
     OutOwner* o = new OutOwner();
@@ -1593,6 +1609,7 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
     GD(uint32_t, h->d_edge_w, o->edge_off, o->edge_weight)
     if (h->want_consensus) { GD(int32_t, h->d_cons, o->cons_off, o->cons_nodes) }
 #undef GD
+    laps.lap("download: POA graphs");
     const bool with_paths = !(h->want_block_graph == 2 && h->bg_done);
     if (with_paths) {
         o->seq_path_nodes = (int32_t*)host_big_alloc(4 * (size_t)std::max<int64_t>(h->n_bases, 1));
@@ -1601,6 +1618,7 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
     }
     o->score.resize((size_t)std::max<int64_t>(ns, 1));
     o->cells.resize((size_t)std::max<int64_t>(ns, 1));
+    laps.lap("download: paths");
     if (h->want_block_graph && h->bg_done) {
         // dense offsets from the per-block counts of the block-graph kernel; the arrays are gathered on the device
         o->bg_node_off.assign(nb + 1, 0); o->bg_seq_off.assign(nb + 1, 0); o->bg_edge_off.assign(nb + 1, 0); o->bg_cons_off.assign(nb + 1, 0);
@@ -1641,6 +1659,7 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
         out->bg_edge_off = o->bg_edge_off.data(); out->bg_edge_to = o->bg_edge_to.data(); out->bg_step_off = o->bg_step_off.data();
         out->bg_steps = o->bg_steps.data();
         if (h->want_consensus) { out->bg_cons_off = o->bg_cons_off.data(); out->bg_cons_steps = o->bg_cons_steps.data(); }
+        laps.lap("download: block graphs");
     }
     if (ns) {
         HIPCHK(hipMemcpy(o->score.data(), h->d_score.p, 4 * (size_t)ns, hipMemcpyDeviceToHost));

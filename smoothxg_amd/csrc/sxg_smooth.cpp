@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <set>
 #include <cmath>
@@ -143,8 +144,9 @@ collected_t collect(const sxg_graph& g, const std::vector<path_range_t>& ranges,
         append_to_sequence(g, r.path, r.begin, seq, fwd_bp, rev_bp, c.poa_padding, true);
         for (uint64_t s = r.begin; s != r.end; ++s) {
             const handle_t h = g.steps[r.path][s];
-            seq.append(g.sequence(h));
-            if (rev(h)) rev_bp += g.seq[nid(h)].size(); else fwd_bp += g.seq[nid(h)].size();
+            const std::string& ns = g.seq[nid(h)];
+            if (rev(h)) { const size_t a0 = seq.size(); seq.resize(a0 + ns.size()); for (size_t y = 0; y < ns.size(); ++y) seq[a0 + y] = comp(ns[ns.size() - 1 - y]); rev_bp += ns.size(); }
+            else { seq.append(ns); fwd_bp += ns.size(); }
         }
         append_to_sequence(g, r.path, r.end, seq, fwd_bp, rev_bp, c.poa_padding, false);
         const bool is_rev = rev_bp > fwd_bp;
@@ -154,7 +156,7 @@ collected_t collect(const sxg_graph& g, const std::vector<path_range_t>& ranges,
         auto it = seq_to_rank.find(hash);
         if (it == seq_to_rank.end()) {
             seq_to_rank[hash] = c.seqs.size();
-            c.seqs.push_back(seq);
+            c.seqs.push_back(std::move(seq));
             c.weights.push_back(1);
             c.dup_is_revs.push_back({is_rev});
             c.dup_seq_names.push_back({name});
@@ -660,7 +662,7 @@ ograph_t build_block_graph(const collected_t& c, const uint8_t* node_code, int64
 struct batch_t {
     std::vector<int32_t> blk_off{0};
     std::vector<int64_t> seq_off{0};
-    std::vector<uint8_t> bases;
+    uvec<uint8_t> bases;   // (320 MB on the headline batch: no serial zero-fill)
     std::vector<uint32_t> weights;
 };
 void add_to_batch(batch_t& B, const collected_t& c) {
@@ -1268,10 +1270,20 @@ struct write_sink_t {
     char* o;
     void raw(const char* q, size_t len) { memcpy(o, q, len); o += len; }
     void ch(char c) { *o++ = c; }
-    void num(uint64_t v) {
+    void num(uint64_t v) {   // digits written in place, two at a time from the end
         static const char lut[201] =
             "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263"
             "646566676869707172737475767778798081828384858687888990919293949596979899";
+        if (v < 4000000000ull) {
+            uint32_t x = (uint32_t)v;
+            const int d = x < 100000u ? (x < 100u ? (x < 10u ? 1 : 2) : (x < 10000u ? (x < 1000u ? 3 : 4) : 5))
+                                      : (x < 10000000u ? (x < 1000000u ? 6 : 7) : (x < 1000000000u ? (x < 100000000u ? 8 : 9) : 10));
+            char* e = o + d;
+            while (x >= 100u) { const uint32_t r = x % 100u; x /= 100u; e -= 2; memcpy(e, lut + 2 * r, 2); }
+            if (x >= 10u) { e -= 2; memcpy(e, lut + 2 * x, 2); } else *--e = (char)('0' + x);
+            o += d;
+            return;
+        }
         char buf[24];
         int k = 24;
         while (v >= 100) { const unsigned r = (unsigned)(v % 100); v /= 100; buf[--k] = lut[2 * r + 1]; buf[--k] = lut[2 * r]; }
@@ -1369,31 +1381,35 @@ int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params
             const fview_t v = fview((size_t)f);
             const cblock_t& B = cb[(size_t)mapping[(size_t)f].block];
             const path_range_t& r = b->blocks[(size_t)mapping[(size_t)f].block][(size_t)mapping[(size_t)f].target];
-            uint64_t st = r.begin, at = 0;          // cursor in the original: step, offset inside its node
+            // the range's original sequence, once, into a thread-local buffer; then the fragment's nodes against it
+            static thread_local std::string os;
+            os.clear();
+            for (uint64_t st = r.begin; st < r.end; ++st) {
+                const handle_t h = g->steps[r.path][st];
+                const std::string& sq = g->seq[nid(h)];
+                if (!rev(h)) os.append(sq);
+                else { const size_t a0 = os.size(); os.resize(a0 + sq.size()); for (size_t y = 0; y < sq.size(); ++y) os[a0 + y] = comp(sq[sq.size() - 1 - y]); }
+            }
+            const char* ob = os.data();
+            const size_t on = os.size();
+            size_t at = 0;
             bool ok = true;
-            for (int64_t j = 0; j < v.cnt && ok; ++j) {
-                const int32_t x = v.st[v.rv ? v.cnt - 1 - j : j];
-                const char* ns = B.seq + B.soff[(size_t)x];
-                const size_t nl = (size_t)(B.soff[(size_t)x + 1] - B.soff[(size_t)x]);
-                for (size_t t = 0; t < nl && ok;) {
-                    if (st >= r.end) { ok = false; break; }
-                    const handle_t h = g->steps[r.path][st];
-                    const std::string& os = g->seq[nid(h)];
-                    if (at >= os.size()) { ++st; at = 0; continue; }
-                    const size_t m = std::min(nl - t, os.size() - (size_t)at);
-                    if (!v.rv && !rev(h)) { if (memcmp(ns + t, os.data() + at, m) != 0) ok = false; }
-                    else
-                        for (size_t y = 0; y < m && ok; ++y) {
-                            const char sc = v.rv ? comp(ns[nl - 1 - (t + y)]) : ns[t + y];
-                            const char oc = rev(h) ? comp(os[os.size() - 1 - ((size_t)at + y)]) : os[(size_t)at + y];
-                            if (sc != oc) ok = false;
-                        }
-                    t += m; at += m;
+            const char* bs = B.seq;
+            const uint32_t* so = B.soff.data();
+            if (!v.rv) {
+                for (int64_t j = 0; j < v.cnt; ++j) {
+                    const uint32_t a0 = so[v.st[j]], a1 = so[v.st[j] + 1];
+                    if (at + (a1 - a0) > on) { ok = false; break; }
+                    for (uint32_t y = a0; y < a1; ++y) ok &= bs[y] == ob[at++];
+                }
+            } else {
+                for (int64_t j = v.cnt - 1; j >= 0; --j) {
+                    const uint32_t a0 = so[v.st[j]], a1 = so[v.st[j] + 1];
+                    if (at + (a1 - a0) > on) { ok = false; break; }
+                    for (uint32_t y = a1; y > a0; --y) ok &= comp(bs[y - 1]) == ob[at++];
                 }
             }
-            // the original must be used up as well (empty trailing nodes aside)
-            while (ok && st < r.end && at >= g->seq[nid(g->steps[r.path][st])].size()) { ++st; at = 0; }
-            if (!ok || st != r.end) {
+            if (!ok || at != on) {
 #pragma omp critical(sxg_lace_bad)
                 if (bad < 0 || f < bad) bad = f;
             }
@@ -1696,7 +1712,27 @@ int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params
         else if (x < P_C) {
             // (counted as if the fragment opened its path: the commas between fragments are added below)
             const size_t f = x - P_F;
-            fsteps[f] = emit_F(sk, f, true);
+            // A block's ids mostly have one digit count, and a path walks a topologically numbered block in ascending
+            // ids: then the size follows from the number of steps -- minus the chain members the walk passes without
+            // writing them, found by bisection -- and the steps (1 GB on the headline batch) are not read in this pass.
+            const fview_t v = fview(f);
+            const int64_t k = mapping[f].block;
+            const uint64_t lo_id = nstart[(size_t)k] + 1, hi_id = nstart[(size_t)k] + (uint64_t)cb[(size_t)k].n;
+            if (v.cnt > 0 && digits_u64(lo_id) == digits_u64(hi_id)) {
+                uint64_t n = (uint64_t)v.cnt;
+                bool plain = true;
+                for (auto& m : cmem[(size_t)k]) {
+                    if (v.rv ? m.last : m.first) {   // written under the chain's id, which may have another digit count
+                        if (digits_u64(m.head + 1) != digits_u64(lo_id) && std::binary_search(v.st, v.st + v.cnt, (int32_t)m.local)) { plain = false; break; }
+                        continue;
+                    }
+                    if (std::binary_search(v.st, v.st + v.cnt, (int32_t)m.local)) --n;
+                }
+                if (plain) {
+                    fsteps[f] = n;
+                    sk.n = n ? n * (digits_u64(lo_id) + 1) + (n - 1) : 0;
+                } else fsteps[f] = emit_F(sk, f, true);
+            } else fsteps[f] = emit_F(sk, f, true);
         } else emit_C(sk, cons_blocks[x - P_C]);
         off[x + 1] = sk.n;
     }
@@ -1977,6 +2013,21 @@ struct OmpTeamGuard {
     ~OmpTeamGuard() { omp_set_num_threads(saved); }
 };
 
+// one background thread that releases what an iteration leaves behind (see smooth_iteration); SXG_SMOOTH_NO_REAPER=1: inline
+struct reaper_t {
+    std::thread th;
+    std::mutex mu;
+    void run(std::function<void()> fn) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (th.joinable()) th.join();
+        if (getenv("SXG_SMOOTH_NO_REAPER")) { fn(); return; }
+        th = std::thread(std::move(fn));
+    }
+    ~reaper_t() { if (th.joinable()) th.join(); }
+};
+static reaper_t g_reaper;
+static void reap(std::function<void()> fn) { g_reaper.run(std::move(fn)); }
+
 static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, const sxg_merge_params* mp,
                             sxg_poa_run_fn run, sxg_poa_free_fn fre, void* ctx, char** out_gfa, char** out_maf, int64_t* n_flipped) {
     if (!g || !b || !p || !run || !out_gfa) return fail(SXG_E_INVALID, "NULL argument");
@@ -2053,7 +2104,8 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
             for (size_t i = 0; i < col[(size_t)(k0 + k)].seqs.size(); ++i) {
                 const std::string& sq = col[(size_t)(k0 + k)].seqs[i];
                 uint8_t* dst = B.bases.data() + B.seq_off[(size_t)B.blk_off[(size_t)k] + i];
-                for (size_t x = 0; x < sq.size(); ++x) dst[x] = code_of(sq[x]);
+                static const struct lut_t { uint8_t v[256]; lut_t() { for (int x = 0; x < 256; ++x) v[x] = code_of((char)x); } } lut;
+                for (size_t x = 0; x < sq.size(); ++x) dst[x] = lut.v[(uint8_t)sq[x]];
             }
         // A14: with -a every block brings its own scores (the engine's per_block_params)
         if (p->adaptive_poa_params) {
@@ -2156,10 +2208,17 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
     }
     if (fast) {
         const int rc = lace_fast(g, b, p, cblocks, out_gfa, lap);
-        {   // the block graphs (views of the providers' results, or built here) go in parallel
-#pragma omp parallel for schedule(dynamic, 16)
-            for (int64_t k = 0; k < nb; ++k) { cblock_t none; std::swap(none, cblocks[(size_t)k]); }
-            for (auto& C : chunks) if (C.keep_out && fre) { fre(&C.out); C.keep_out = false; }
+        // The block graphs and the providers' results (1 GB of steps on the headline batch) are released behind the
+        // caller's back: unmapping them is not on anybody's critical path.  The reaper is joined by the next iteration
+        // (and when the library is unloaded).
+        {
+            auto* graveyard = new std::pair<std::vector<cblock_t>, std::vector<chunk_t>>();
+            graveyard->first.swap(cblocks);
+            graveyard->second.swap(chunks);
+            reap([graveyard, fre]() {
+                for (auto& C : graveyard->second) if (C.keep_out && fre) fre(&C.out);
+                delete graveyard;
+            });
         }
         lap("teardown");
         return rc;

@@ -492,7 +492,7 @@ def test_integration_snippet_compiles_and_links_against_the_c_abi(tmp_path):
                            "-Wl,-rpath," + os.path.join(root, "smoothxg_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 3" in r.stdout
+    assert "abi 4" in r.stdout
 
 
 def test_ready_made_and_multi_gpu_snippets_compile_and_link(tmp_path):
