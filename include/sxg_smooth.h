@@ -37,7 +37,14 @@ typedef int (*sxg_poa_run_fn)(void *ctx, const sxg_poa_batch_in *in, sxg_poa_bat
 typedef void (*sxg_poa_free_fn)(sxg_poa_batch_out *out);
 
 /* smoothxg's knobs on this path with their defaults (src/main.cpp:291-361,487). */
+/* 2: sxg_smooth_params starts with struct_size (set by sxg_smooth_default_params, checked by every entry point: a caller
+ *    built against another header gets SXG_E_INVALID instead of fields read from whatever follows its struct) and ends
+ *    with abpoa_band_local; scores whose engine form leaves int8 are rejected. */
+#define SXG_SMOOTH_ABI_VERSION 2
+int sxg_smooth_abi_version(void);
+
 typedef struct sxg_smooth_params {
+    uint32_t struct_size;                             /* sizeof(sxg_smooth_params) of the caller's header */
     int32_t poa_m, poa_n, poa_g, poa_e, poa_q, poa_c; /* CLI convention: positive penalties (1,4,6,2,26,1) */
     int32_t local_alignment;                          /* 1 = default; 0 = -Z */
     float poa_padding_fraction;                       /* -O, default 0.001 */
@@ -53,6 +60,12 @@ typedef struct sxg_smooth_params {
                                                          (params.banded = 2: wb = 311, wf = 0.03, src/smooth.cpp:266-271,2090) and the
                                                          consensus path keeps only nodes some sequence visits (build_odgi_abPOA,
                                                          src/smooth.cpp:2542-2548).  Default 0. */
+    int32_t abpoa_band_local;                         /* use_abpoa with LOCAL alignment (the default mode): 1 = banded as the call
+                                                         site asks (src/smooth.cpp:266-271 sets wb / wf for both modes; default);
+                                                         0 = full matrix -- upstream abPOA is believed to switch its adaptive band
+                                                         off in local mode (abpoa_post_set_para; unverifiable here, the library is
+                                                         absent from the snapshot), in which case this is what -A without -Z runs.
+                                                         Global alignment (-Z) is banded either way. */
 } sxg_smooth_params;
 
 void sxg_smooth_default_params(sxg_smooth_params *p);
@@ -93,11 +106,21 @@ int sxg_blockset_from_ranges(const sxg_graph *g, int64_t n_blocks, const int64_t
 int sxg_blockset_smoothable(const sxg_graph *g, uint64_t max_block_weight, uint64_t max_block_path_length,
                             uint64_t max_path_jump, uint64_t max_edge_jump, int order_paths_from_longest,
                             sxg_blockset **out);
-/* The cutting half of break_blocks, src/breaks.cpp:210-330: ranges longer than max_poa_length (-q, default
- * 2 * target) are cut; repeat-aware cut lengths (sautocorr, absent) and identity splitting (off by default)
- * are not applied. */
+/* The cutting half of break_blocks, src/breaks.cpp:210-330: a block that holds a range longer than max_poa_length (-q,
+ * default 2 * target) is cut.  As the reference always does (break_repeats = true, src/main.cpp:476), the ranges of such a
+ * block of at least 2 * min_copy_length bases are searched for a tandem repeat first (src/breaks.cpp:224-272); if any is
+ * found, EVERY range of the block is cut at half the mean repeat length, otherwise the long ranges are cut blindly at
+ * max_poa_length.  sxg_blockset_break uses the reference's repeat parameters (min_copy_length 1000, max_copy_length 20000,
+ * min_autocorr_z 5, autocorr_stride 50: src/main.cpp:285-286,457-458); sxg_blockset_break_ex takes them (break_repeats = 0:
+ * blind cuts only).  The repeat detector stands in for sautocorr::repeat, an un-vendored dependency absent from the
+ * snapshot, BY DECREE: match-fraction autocorrelation at every lag in [min_copy_length,
+ * max_copy_length] over positions sampled every autocorr_stride bases, z-score across the lags, first lag of greatest z
+ * if that z reaches min_autocorr_z.  Identity splitting (src/breaks.cpp:335+; off by default) is not applied. */
 int sxg_blockset_break(const sxg_graph *g, const sxg_blockset *in, uint64_t max_poa_length, int order_paths_from_longest,
                        sxg_blockset **out);
+int sxg_blockset_break_ex(const sxg_graph *g, const sxg_blockset *in, uint64_t max_poa_length, int break_repeats,
+                          uint64_t min_copy_length, uint64_t max_copy_length, double min_autocorr_z, uint64_t autocorr_stride,
+                          int order_paths_from_longest, sxg_blockset **out);
 int64_t sxg_blockset_block_size(const sxg_blockset *b, int64_t block_id);              /* ranges of a block, -1 on error */
 int sxg_blockset_block_ranges(const sxg_blockset *b, int64_t block_id, sxg_path_range *out); /* out[block size] */
 void sxg_blockset_free(sxg_blockset *b);

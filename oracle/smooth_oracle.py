@@ -218,22 +218,73 @@ def _cround(x):
     return math.floor(x + 0.5) if x >= 0 else math.ceil(x - 0.5)
 
 
-def break_blocks(g, blocks, max_poa_length, from_longest=True):
-    """The cutting half of src/breaks.cpp:210-330 (no repeat detection, no identity splitting)."""
+def repeat_length(seq, min_copy, max_copy, min_z, stride):
+    """sautocorr::repeat(vec, min_copy, max_copy, min_copy, min_z, stride) as src/breaks.cpp:236-245 calls it -- BY DECREE
+    (ekg/sautocorr is an un-vendored dependency, absent from the reference snapshot):
+    for every lag L in [min_copy, min(max_copy, n - min_copy)] the autocorrelation is the fraction of the sampled positions
+    i = 0, stride, 2 stride, ... < n - L whose letter comes back L bases later; a lag whose z-score over all lags is at least
+    min_z is a repeat, and the repeat's length is the FIRST lag of greatest z.  0.0 = no repeat.  Sums run in lag order in
+    double precision (the C++ side does the same, so both sides take the same decisions)."""
+    n = len(seq)
+    hi = min(max_copy, n - min_copy)
+    if n < 2 * min_copy or hi < min_copy:
+        return 0.0
+    a = np.frombuffer(seq.encode(), np.uint8)
+    r = []
+    for L in range(min_copy, hi + 1):
+        idx = np.arange(0, n - L, stride)
+        r.append(int((a[idx] == a[idx + L]).sum()) / float(len(idx)))
+    mean = 0.0
+    for v in r:
+        mean += v
+    mean /= len(r)
+    var = 0.0
+    for v in r:
+        var += (v - mean) * (v - mean)
+    sd = math.sqrt(var / len(r))
+    if sd == 0.0:
+        return 0.0
+    best, best_z = -1, 0.0
+    for k, v in enumerate(r):
+        z = (v - mean) / sd
+        if best < 0 or z > best_z:
+            best, best_z = k, z
+    return float(min_copy + best) if best_z >= min_z else 0.0
+
+
+def break_blocks(g, blocks, max_poa_length, from_longest=True, repeats=(1000, 20000, 5, 50)):
+    """The cutting half of src/breaks.cpp:210-330.  repeats = (min_copy_length, max_copy_length, min_autocorr_z,
+    autocorr_stride): the repeat-aware cut length of :224-272, which the reference always asks for (break_repeats = true,
+    src/main.cpp:476; defaults :285-286, 457-458) -- a block that is cut and holds a repeat is cut at half the mean repeat
+    length, EVERY range of it; None = blind cuts only.  No identity splitting (off by default, :335)."""
     out = []
     for blk in blocks:
         if not (len(blk) > 1 and any(r[3] > max_poa_length for r in blk)):
             out.append(list(blk))
             continue
+        cut_length, found = max_poa_length, False
+        if repeats is not None:
+            lengths = []
+            for p, b, e, ln in blk:
+                seq = "".join(g.sequence(g.steps[p][k]) for k in range(b, e))
+                if len(seq) >= 2 * repeats[0]:
+                    rl = repeat_length(seq, repeats[0], repeats[1], float(repeats[2]), repeats[3])
+                    if rl > 0:
+                        lengths.append(rl)
+            if lengths:
+                total = 0.0
+                for v in lengths:
+                    total += v
+                found, cut_length = True, int(_cround(total / len(lengths) / 2.0))
         chopped = []
         for p, b, e, ln in blk:
-            if ln < max_poa_length:
+            if not found and ln < cut_length:
                 chopped.append((p, b, e, ln))
                 continue
             last_cut, last_end, pos = 0, b, 0
             for k in range(b, e):
                 pos += len(g.seq[g.steps[p][k] >> 1])
-                if pos - last_cut > max_poa_length:
+                if pos - last_cut > cut_length:
                     chopped.append((p, last_end, k + 1, pos - last_cut))
                     last_end, last_cut = k + 1, pos
             if e != last_end:

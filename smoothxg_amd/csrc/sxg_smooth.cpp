@@ -1137,6 +1137,7 @@ struct cstore_t {   // arrays of a block graph built on the host
     uvec<int32_t> len, outdeg, eto, steps, cons;
     uvec<uint8_t> indeg;
     uvec<char> seq;
+    uvec<uint32_t> soff, eoff;
 };
 // A block graph is topologically numbered, so every edge runs forward-forward from a lower to a higher id: the edges
 // are listed per tail (CSR), heads ascending -- the block's L lines in their order.
@@ -1149,15 +1150,15 @@ struct cblock_t {
     std::vector<std::pair<const int32_t*, int64_t>> upath;    // steps of every dedup'd sequence, in alignment order
     const int32_t* cons = nullptr;
     int64_t ncons = 0;
-    uvec<uint32_t> soff, eoff;                                // [n+1] prefix sums of len / outdeg
+    const uint32_t *soff = nullptr, *eoff = nullptr;          // [n+1] prefix sums of len / outdeg (storage: the chunk's, or `own`)
     std::vector<int32_t> range_useq;                          // path range (rank in the block) -> dedup'd sequence
     std::vector<char> range_rev;                              //                                  -> collected in reverse
     std::unique_ptr<cstore_t> own;
-    void index(const collected_t& c, size_t n_ranges) {
-        soff.resize((size_t)n + 1); eoff.resize((size_t)n + 1);
+    void index(const collected_t& c, size_t n_ranges, uint32_t* so, uint32_t* eo) {
         uint32_t a = 0, e = 0;
-        for (int64_t v = 0; v < n; ++v) { soff[(size_t)v] = a; eoff[(size_t)v] = e; a += (uint32_t)len[v]; e += (uint32_t)outdeg[v]; }
-        soff[(size_t)n] = a; eoff[(size_t)n] = e;
+        for (int64_t v = 0; v < n; ++v) { so[(size_t)v] = a; eo[(size_t)v] = e; a += (uint32_t)len[v]; e += (uint32_t)outdeg[v]; }
+        so[(size_t)n] = a; eo[(size_t)n] = e;
+        soff = so; eoff = eo;
         ne = e;
         range_useq.assign(n_ranges, -1); range_rev.assign(n_ranges, 0);
         for (size_t i = 0; i < c.dup_rank_in_path_ranges.size(); ++i)
@@ -1242,10 +1243,13 @@ void cblock_from_raw(cblock_t& B, const collected_t& c, size_t n_ranges, const u
     }
     B.n = (int64_t)n; B.len = O.len.data(); B.outdeg = O.outdeg.data(); B.indeg = O.indeg.data(); B.eto = O.eto.data(); B.seq = O.seq.data();
     B.has_paths = S > 0;
-    B.index(c, n_ranges);
+    O.soff.resize(n + 1); O.eoff.resize(n + 1);
+    B.index(c, n_ranges, O.soff.data(), O.eoff.data());
 }
 // ... or views of the arrays the provider returned for block `slot` of its batch
-void cblock_from_out(cblock_t& B, const collected_t& c, size_t n_ranges, const batch_t& Bt, const sxg_poa_batch_out& out, int64_t slot, bool want_cons) {
+// (so / eo: room for the block's n + 1 offsets in the chunk's arrays)
+void cblock_from_out(cblock_t& B, const collected_t& c, size_t n_ranges, const batch_t& Bt, const sxg_poa_batch_out& out, int64_t slot, bool want_cons,
+                     uint32_t* so, uint32_t* eo) {
     const int64_t n0 = out.bg_node_off[slot];
     B.n = out.bg_node_off[slot + 1] - n0;
     B.len = out.bg_node_len + n0; B.outdeg = out.bg_node_outdeg + n0; B.indeg = out.bg_node_indeg + n0;
@@ -1256,7 +1260,7 @@ void cblock_from_out(cblock_t& B, const collected_t& c, size_t n_ranges, const b
     for (int32_t sq = s0; sq < s1; ++sq) B.upath[(size_t)(sq - s0)] = std::make_pair(out.bg_steps + out.bg_step_off[sq], out.bg_step_off[sq + 1] - out.bg_step_off[sq]);
     if (want_cons && out.bg_cons_off && out.bg_cons_steps) { B.cons = out.bg_cons_steps + out.bg_cons_off[slot]; B.ncons = out.bg_cons_off[slot + 1] - out.bg_cons_off[slot]; }
     B.has_paths = s1 > s0;
-    B.index(c, n_ranges);
+    B.index(c, n_ranges, so, eo);
 }
 
 // Output sinks of the GFA writer: the size pass and the write pass run the same code.
@@ -1395,7 +1399,7 @@ int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params
             size_t at = 0;
             bool ok = true;
             const char* bs = B.seq;
-            const uint32_t* so = B.soff.data();
+            const uint32_t* so = B.soff;
             if (!v.rv) {
                 for (int64_t j = 0; j < v.cnt; ++j) {
                     const uint32_t a0 = so[v.st[j]], a1 = so[v.st[j] + 1];
@@ -1678,6 +1682,65 @@ int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params
         }
         return n;
     };
+    // The write pass of a fragment.  A path walks a topologically numbered block in ascending ids (descending when the
+    // range was collected in reverse) and mostly in small strides, so the decimal digits of the last id are kept and
+    // bumped in place instead of being derived again for every step; ids go out with one blind 16-byte store while that stays
+    // inside the fragment's piece (the steps behind them overwrite what it spills), with exact ones at its end.
+    struct inc_digits_t {
+        char dig[32];
+        int d = 0;
+        uint64_t cur = 0;
+        void set(uint64_t v) { d = (int)digits_u64(v); cur = v; for (int i = d - 1; i >= 0; --i) { dig[i] = (char)('0' + v % 10); v /= 10; } }
+        void to(uint64_t v) {
+            const int64_t dl = (int64_t)(v - cur);
+            if (d == 0 || dl >= 10 || dl <= -10) { set(v); return; }
+            cur = v;
+            int i = d - 1;
+            const int c = dig[i] + (int)dl;
+            if (c > '9') {
+                dig[i] = (char)(c - 10);
+                for (--i; i >= 0; --i) { if (dig[i] != '9') { dig[i]++; return; } dig[i] = '0'; }
+                set(v);   // (one digit more)
+            } else if (c < '0') {
+                dig[i] = (char)(c + 10);
+                for (--i; i >= 0; --i) { if (dig[i] != '0') { dig[i]--; if (i == 0 && dig[0] == '0') set(v); return; } dig[i] = '9'; }
+                set(v);
+            } else dig[i] = (char)c;
+        }
+    };
+    auto write_F = [&](char* o, const char* lim, size_t f, bool first) -> char* {   // lim: end of the fragment's piece
+        const fview_t v = fview(f);
+        const int64_t k = mapping[f].block;
+        const auto& cm = cmem[(size_t)k];
+        const uint64_t base = nstart[(size_t)k] + 1;
+        const char sign = v.rv ? '-' : '+';
+        const bool members = !cm.empty();
+        const uint32_t lo = members ? cm.front().local : 0xffffffffu, hi = members ? cm.back().local : 0;
+        const uint64_t nrem = rem[(size_t)k].size();
+        inc_digits_t w;
+        if (base + (uint64_t)cb[(size_t)k].n >= 100000000000000ull) {   // (ids beyond 14 digits: the plain writer)
+            write_sink_t sk{o};
+            emit_F(sk, f, first);
+            return sk.o;
+        }
+        for (int64_t j = 0; j < v.cnt; ++j) {
+            const uint64_t x = (uint64_t)v.st[v.rv ? v.cnt - 1 - j : j];
+            uint64_t id;
+            if (x < lo) id = base + x;
+            else if (x > hi) id = base + x - nrem;
+            else if (const cmem_t* m = find_cm(k, x)) {
+                if (v.rv ? !m->last : !m->first) continue;
+                id = m->head + 1;
+            } else id = newid_in(k, x) + 1;
+            if (!first) *o++ = ',';
+            first = false;
+            w.to(id);
+            if (o + 16 <= lim) memcpy(o, w.dig, 16); else memcpy(o, w.dig, (size_t)w.d);
+            o += w.d;
+            *o++ = sign;
+        }
+        return o;
+    };
     auto emit_C = [&](auto& sk, int64_t k) {   // the consensus path of block k (forward steps)
         const cblock_t& B = cb[(size_t)k];
         const std::string name = cons_name(*p, k);
@@ -1761,7 +1824,7 @@ int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params
         else if (x < P_C) {
             const size_t f = x - P_F, rq = run_of[f];
             if (f == runs[rq].first) { const std::string& nm = g->pname[mapping[f].path]; sk.ch('P'); sk.ch('\t'); sk.raw(nm.data(), nm.size()); sk.ch('\t'); }
-            emit_F(sk, f, !lead[f]);
+            sk.o = write_F(sk.o, buf + off[x + 1], f, !lead[f]);
             if (f + 1 == runs[rq].second) sk.raw("\t*\n", 3);
         } else emit_C(sk, cons_blocks[x - P_C]);
         if (sk.o != buf + off[x + 1]) ++wrong;
@@ -1771,6 +1834,21 @@ int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params
     (void)n_laced;
     *out_gfa = buf;
     lap("GFA text");
+    return SXG_OK;
+}
+
+// every entry point that takes the parameters: the caller's struct is this header's, and the scores fit the engine's int8
+int check_params(const sxg_smooth_params* p) {
+    if (!p) return fail(SXG_E_INVALID, "NULL parameters");
+    if (p->struct_size != sizeof(sxg_smooth_params))
+        return fail(SXG_E_INVALID, "sxg_smooth_params was not initialised by sxg_smooth_default_params of this library's header (struct_size " +
+                                       std::to_string(p->struct_size) + ", expected " + std::to_string(sizeof(sxg_smooth_params)) + ")");
+    const int v[6] = {p->poa_m, p->poa_n, p->poa_g, p->poa_e, p->poa_q, p->poa_c};
+    for (int x : v) if (x < 0) return fail(SXG_E_INVALID, "POA scores are given as non-negative numbers (CLI convention)");
+    int worst = 0;
+    if (!p->use_abpoa) for (int x : v) worst = std::max(worst, x);
+    else worst = std::max(std::max(p->poa_m, p->poa_n), std::max(p->poa_g + p->poa_e, p->poa_q + p->poa_c));   // g = -(o + e)
+    if (worst > 127) return fail(SXG_E_INVALID, "POA scores beyond 127 do not fit the engine's int8 parameters (src/smooth.cpp:631-632 narrows them the same way)");
     return SXG_OK;
 }
 
@@ -1785,8 +1863,12 @@ char* dup_out(const std::string& s) {
 // =============================================================================================
 extern "C" {
 
+int sxg_smooth_abi_version(void) { return SXG_SMOOTH_ABI_VERSION; }
+
 void sxg_smooth_default_params(sxg_smooth_params* p) {
     if (!p) return;
+    p->struct_size = (uint32_t)sizeof(sxg_smooth_params);
+    p->abpoa_band_local = 1;
     p->poa_m = 1; p->poa_n = 4; p->poa_g = 6; p->poa_e = 2; p->poa_q = 26; p->poa_c = 1;  // src/main.cpp:322-327
     p->local_alignment = 1;                                                              // src/main.cpp:487
     p->poa_padding_fraction = 0.001f; p->max_block_depth_for_padding_more = 1000;         // src/main.cpp:293-295
@@ -1905,6 +1987,7 @@ int64_t sxg_blockset_size(const sxg_blockset* b) { return b ? (int64_t)b->blocks
 
 int sxg_block_collect_text(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, const sxg_smooth_params* p, char** out_text) {
     if (!g || !b || !p || !out_text || block_id < 0 || block_id >= (int64_t)b->blocks.size()) return fail(SXG_E_INVALID, "bad argument");
+    if (int prc = check_params(p)) return prc;
     const collected_t c = collect(*g, b->blocks[block_id], *p);
     std::string o = "padding\t" + std::to_string(c.poa_padding) + "\n";
     for (size_t i = 0; i < c.seqs.size(); ++i) o += "seq\t" + std::to_string(i) + "\t" + std::to_string(c.weights[i]) + "\t" + c.seqs[i] + "\n";
@@ -1919,6 +2002,7 @@ int sxg_block_collect_text(const sxg_graph* g, const sxg_blockset* b, int64_t bl
 int sxg_block_graph_gfa(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, const sxg_smooth_params* p, sxg_poa_run_fn run,
                         sxg_poa_free_fn fre, void* ctx, char** out_gfa) {
     if (!g || !b || !p || !run || !out_gfa || block_id < 0 || block_id >= (int64_t)b->blocks.size()) return fail(SXG_E_INVALID, "bad argument");
+    if (int prc = check_params(p)) return prc;
     const collected_t c = collect(*g, b->blocks[block_id], *p);
     batch_t B;
     add_to_batch(B, c);
@@ -1940,6 +2024,7 @@ int sxg_block_graph_gfa(const sxg_graph* g, const sxg_blockset* b, int64_t block
 static int block_maf_rows(const sxg_graph* g, const sxg_blockset* b, int64_t block_id, const sxg_smooth_params* p, sxg_poa_run_fn run,
                           sxg_poa_free_fn fre, void* ctx, std::vector<maf_row_t>& rows) {
     if (!g || !b || !p || !run || block_id < 0 || block_id >= (int64_t)b->blocks.size()) return fail(SXG_E_INVALID, "bad argument");
+    if (int prc = check_params(p)) return prc;
     const collected_t c = collect(*g, b->blocks[block_id], *p);
     rows.clear();
     if (c.seqs.empty()) return SXG_OK;
@@ -2031,6 +2116,7 @@ static void reap(std::function<void()> fn) { g_reaper.run(std::move(fn)); }
 static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, const sxg_merge_params* mp,
                             sxg_poa_run_fn run, sxg_poa_free_fn fre, void* ctx, char** out_gfa, char** out_maf, int64_t* n_flipped) {
     if (!g || !b || !p || !run || !out_gfa) return fail(SXG_E_INVALID, "NULL argument");
+    if (int prc = check_params(p)) return prc;
     if (out_maf) *out_maf = nullptr;
     if (n_flipped) *n_flipped = 0;
     const OmpTeamGuard team(host_threads());
@@ -2048,7 +2134,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
     // reference's default -l 700...1100: thousands of ~1 kbp blocks, where the host phases outweigh the kernels) the GPU and
     // the host cores are busy at the same time.  Blocks are independent (src/smooth.cpp:1931) and their results do not
     // depend on what else is in a batch, so the output is the same for every chunking.  A batch below 2 x
-    // SXG_SMOOTH_CHUNK_BLOCKS blocks (default 2048; the headline's 1000 x 64 x 5 kbp) is ONE chunk: one provider call, as before.
+    // SXG_SMOOTH_CHUNK_BLOCKS blocks (default 8192; the headline's 1000 x 64 x 5 kbp) is ONE chunk: one provider call, as before.
     struct frag_t { uint64_t path, start, end; int64_t target, block; };
     // Without the MAF consumer (no flips, no merged consensus paths) the iteration works on compact block graphs -- asked of
     // the provider (the GPU engine builds them on the device), built here from raw results otherwise -- and laces them
@@ -2066,13 +2152,14 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         batch_t B;
         std::vector<sxg_poa_params> pps;
         std::vector<int32_t> trims;
+        uvec<uint32_t> soff, eoff;   // sequence / edge offsets of the chunk's block graphs, block after block (n + 1 entries each)
         bool keep_out = false;   // block graphs of this chunk are views of `out`: released when the text is written
         sxg_poa_batch_in in;
         sxg_poa_batch_out out;
         uint8_t dummy = 0;
         int rc = SXG_OK;
     };
-    int64_t chunk_blocks = 2048;
+    int64_t chunk_blocks = 8192;   // (round 4: the host phases of a chunk now cost less than what smaller launches lose on the GPU)
     if (const char* e = getenv("SXG_SMOOTH_CHUNK_BLOCKS")) chunk_blocks = std::max<int64_t>(1, atoll(e));
     const int64_t nc = std::max<int64_t>(1, nb / chunk_blocks);
     std::vector<chunk_t> chunks((size_t)nc);
@@ -2137,7 +2224,11 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         const int64_t k0 = C.k0;
         const bool have_bg = fast && out.bg_node_off && out.bg_node_len && out.bg_node_outdeg && out.bg_node_indeg && out.bg_seq_off &&
                              out.bg_edge_off && out.bg_step_off && (out.bg_seq || out.bg_seq_off[C.k1 - C.k0] == 0);
-        if (have_bg) C.keep_out = true;
+        if (have_bg) {
+            C.keep_out = true;
+            const size_t room = (size_t)out.bg_node_off[C.k1 - C.k0] + (size_t)(C.k1 - C.k0);
+            C.soff.resize(room); C.eoff.resize(room);
+        }
 #pragma omp parallel for schedule(dynamic, 1)
         for (int64_t k = C.k0; k < C.k1; ++k) {
             if (col[(size_t)k].seqs.empty()) continue;
@@ -2145,7 +2236,8 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
             if (fast) {
                 const collected_t& c = col[(size_t)k];
                 cblock_t& Bk = cblocks[(size_t)k];
-                if (have_bg) cblock_from_out(Bk, c, b->blocks[(size_t)k].size(), C.B, out, slot, p->add_consensus != 0);
+                if (have_bg) cblock_from_out(Bk, c, b->blocks[(size_t)k].size(), C.B, out, slot, p->add_consensus != 0,
+                                             C.soff.data() + out.bg_node_off[slot] + slot, C.eoff.data() + out.bg_node_off[slot] + slot);
                 else {
                     std::vector<const int32_t*> sp;
                     for (int32_t sq = C.B.blk_off[(size_t)slot]; sq < C.B.blk_off[(size_t)slot + 1]; ++sq) sp.push_back(out.seq_path_nodes + C.B.seq_off[(size_t)sq]);
@@ -2154,8 +2246,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
                     cblock_from_raw(Bk, c, b->blocks[(size_t)k].size(), out.node_code + n0, nn, sp, hc ? out.cons_nodes + out.cons_off[slot] : nullptr,
                                     hc ? out.cons_off[slot + 1] - out.cons_off[slot] : 0, p->add_consensus != 0, p->use_abpoa != 0);
                 }
-                collected_t().seqs.swap(col[(size_t)k].seqs);
-                continue;
+                continue;   // (the padded sequences go with everything else when the iteration is over)
             }
             graphs[(size_t)k] = block_graph_from_out(col[(size_t)k], C.B, out, slot, cons_name(*p, k), p->use_abpoa != 0);
             if (mp) {   // MSA -> MAF rows of the block (src/smooth.cpp:782-905), and its grooming orientation (:1826-1842)
@@ -2176,6 +2267,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         int fail_rc = SXG_OK;
         std::string fail_msg;
         std::thread worker;
+        struct joiner_t { std::thread& t; ~joiner_t() { if (t.joinable()) t.join(); } } joiner{worker};   // (also when an exception unwinds: see guarded())
         prepare(chunks[0]);
         if (nc > 1) worker = std::thread(call, &chunks[0]); else call(&chunks[0]);
         for (int64_t c = 0; c < nc; ++c) {
@@ -2212,11 +2304,13 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         // caller's back: unmapping them is not on anybody's critical path.  The reaper is joined by the next iteration
         // (and when the library is unloaded).
         {
-            auto* graveyard = new std::pair<std::vector<cblock_t>, std::vector<chunk_t>>();
-            graveyard->first.swap(cblocks);
-            graveyard->second.swap(chunks);
+            struct grave_t { std::vector<cblock_t> cb; std::vector<chunk_t> ch; std::vector<collected_t> col; };
+            auto* graveyard = new grave_t();
+            graveyard->cb.swap(cblocks);
+            graveyard->ch.swap(chunks);
+            graveyard->col.swap(col);
             reap([graveyard, fre]() {
-                for (auto& C : graveyard->second) if (C.keep_out && fre) fre(&C.out);
+                for (auto& C : graveyard->ch) if (C.keep_out && fre) fre(&C.out);
                 delete graveyard;
             });
         }
@@ -2536,23 +2630,82 @@ int sxg_blockset_smoothable(const sxg_graph* g, uint64_t max_block_weight, uint6
     return SXG_OK;
 }
 
-// The cutting half of break_blocks (src/breaks.cpp:210-330): a block with more than one range and a range
-// longer than max_poa_length has every such range cut into pieces of just over max_poa_length bases
-// (a piece is closed by the step that takes it past the limit), then re-ordered by length.  The
-// repeat-aware cut length (:226-262) needs sautocorr, an absent dependency: by decree it is off (cut
-// blindly, the reference's own fallback when no repeat is found); splitting by identity (:335+) stays off
-// as in the defaults (block_group_identity = 0, src/main.cpp:316-320).
-int sxg_blockset_break(const sxg_graph* g, const sxg_blockset* in, uint64_t max_poa_length, int order_paths_from_longest, sxg_blockset** out) {
+// sautocorr::repeat(vec, min_copy, max_copy, min_copy, min_z, stride) as src/breaks.cpp:236-245 calls it -- BY DECREE
+// (ekg/sautocorr is an un-vendored dependency, absent from the reference snapshot; DESIGN.md section 9, mirrored by
+// oracle/smooth_oracle.py::repeat_length): for every lag L in [min_copy, min(max_copy, n - min_copy)] the autocorrelation
+// is the fraction of the sampled positions i = 0, stride, 2 stride, ... < n - L whose letter comes back L bases later; a
+// lag whose z-score over all lags is at least min_z is a repeat, the repeat's length is the FIRST lag of greatest z.
+// Returns 0 when there is none.  Sums run in lag order in double precision, as in the Python restatement.
+static double repeat_length(const std::string& seq, uint64_t min_copy, uint64_t max_copy, double min_z, uint64_t stride) {
+    const uint64_t n = seq.size();
+    if (min_copy == 0 || stride == 0 || n < 2 * min_copy) return 0.0;
+    const uint64_t hi = std::min<uint64_t>(max_copy, n - min_copy);
+    if (hi < min_copy) return 0.0;
+    std::vector<double> r;
+    r.reserve((size_t)(hi - min_copy + 1));
+    for (uint64_t L = min_copy; L <= hi; ++L) {
+        uint64_t match = 0, cnt = 0;
+        for (uint64_t i = 0; i < n - L; i += stride) { match += seq[(size_t)i] == seq[(size_t)(i + L)] ? 1 : 0; ++cnt; }
+        r.push_back((double)match / (double)cnt);
+    }
+    double mean = 0.0;
+    for (double v : r) mean += v;
+    mean /= (double)r.size();
+    double var = 0.0;
+    for (double v : r) var += (v - mean) * (v - mean);
+    const double sd = std::sqrt(var / (double)r.size());
+    if (sd == 0.0) return 0.0;
+    int64_t best = -1;
+    double best_z = 0.0;
+    for (size_t k = 0; k < r.size(); ++k) {
+        const double z = (r[k] - mean) / sd;
+        if (best < 0 || z > best_z) { best = (int64_t)k; best_z = z; }
+    }
+    return best_z >= min_z ? (double)(min_copy + (uint64_t)best) : 0.0;
+}
+
+}  // extern "C"
+// The cutting half of break_blocks (src/breaks.cpp:210-330): a block with more than one range and a range longer than
+// max_poa_length is cut -- at half the mean length of the repeats its ranges hold when there are any (:224-272: the
+// reference always asks for this, break_repeats = true at src/main.cpp:476), every range of it; otherwise blindly, the
+// ranges of at least max_poa_length bases into pieces of just over that (a piece is closed by the step that takes it past
+// the limit) -- and re-ordered by length.  Splitting by identity (:335+) stays off as in the defaults
+// (block_group_identity = 0, src/main.cpp:316-320).
+static int blockset_break(const sxg_graph* g, const sxg_blockset* in, uint64_t max_poa_length, bool break_repeats, uint64_t min_copy_length,
+                          uint64_t max_copy_length, double min_autocorr_z, uint64_t autocorr_stride, int order_paths_from_longest, sxg_blockset** out) {
     if (!g || !in || !out) return fail(SXG_E_INVALID, "NULL argument");
+    if (break_repeats && (min_copy_length == 0 || autocorr_stride == 0 || max_copy_length < min_copy_length)) return fail(SXG_E_INVALID, "bad repeat parameters");
     sxg_blockset* bs = new sxg_blockset();
-    for (auto& blk : in->blocks) {
+    const int64_t nb = (int64_t)in->blocks.size();
+    bs->blocks.resize((size_t)nb);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t k = 0; k < nb; ++k) {
+        const auto& blk = in->blocks[(size_t)k];
         bool to_break = false;
         for (auto& r : blk) if (r.length > max_poa_length) { to_break = true; break; }
-        if (!(blk.size() > 1 && to_break)) { bs->blocks.push_back(blk); continue; }
-        const uint64_t cut_length = max_poa_length;
+        if (!(blk.size() > 1 && to_break)) { bs->blocks[(size_t)k] = blk; continue; }
+        uint64_t cut_length = max_poa_length;
+        bool found_repeat = false;
+        if (break_repeats) {
+            std::vector<double> lengths;
+            for (auto& r : blk) {
+                std::string seq;
+                for (uint64_t st = r.begin; st != r.end; ++st) seq += g->sequence(g->steps[r.path][st]);
+                if (seq.size() >= 2 * min_copy_length) {
+                    const double rl = repeat_length(seq, min_copy_length, max_copy_length, min_autocorr_z, autocorr_stride);
+                    if (rl > 0) lengths.push_back(rl);
+                }
+            }
+            if (!lengths.empty()) {
+                double total = 0.0;
+                for (double v : lengths) total += v;
+                found_repeat = true;
+                cut_length = (uint64_t)std::round(total / (double)lengths.size() / 2.0);
+            }
+        }
         std::vector<path_range_t> chopped;
         for (auto& r : blk) {
-            if (r.length < cut_length) { chopped.push_back(r); continue; }
+            if (!found_repeat && r.length < cut_length) { chopped.push_back(r); continue; }
             uint64_t last_cut = 0, last_end = r.begin, pos = 0, st;
             for (st = r.begin; st != r.end; ++st) {
                 pos += g->seq[nid(g->steps[r.path][st])].size();
@@ -2566,15 +2719,36 @@ int sxg_blockset_break(const sxg_graph* g, const sxg_blockset* in, uint64_t max_
         }
         if (order_paths_from_longest) std::stable_sort(chopped.begin(), chopped.end(), [](const path_range_t& a, const path_range_t& b) { return a.length > b.length; });
         else std::stable_sort(chopped.begin(), chopped.end(), [](const path_range_t& a, const path_range_t& b) { return a.length < b.length; });
-        bs->blocks.push_back(chopped);
+        bs->blocks[(size_t)k] = chopped;
     }
     *out = bs;
     return SXG_OK;
 }
+extern "C" {
+
+// ... with the reference's own repeat parameters (min_copy_length 1000, max_copy_length 20000: src/main.cpp:285-286;
+// min_autocorr_z 5, autocorr_stride 50: :457-458)
+int sxg_blockset_break(const sxg_graph* g, const sxg_blockset* in, uint64_t max_poa_length, int order_paths_from_longest, sxg_blockset** out) {
+    return blockset_break(g, in, max_poa_length, true, 1000, 20000, 5.0, 50, order_paths_from_longest, out);
+}
+int sxg_blockset_break_ex(const sxg_graph* g, const sxg_blockset* in, uint64_t max_poa_length, int break_repeats, uint64_t min_copy_length,
+                          uint64_t max_copy_length, double min_autocorr_z, uint64_t autocorr_stride, int order_paths_from_longest, sxg_blockset** out) {
+    return blockset_break(g, in, max_poa_length, break_repeats != 0, min_copy_length, max_copy_length, min_autocorr_z, autocorr_stride, order_paths_from_longest, out);
+}
+
+}  // extern "C"
+// no exception crosses the C ABI: an allocation that fails anywhere in the iteration becomes SXG_E_NOMEM (the pipeline's
+// worker thread is joined while the stack unwinds)
+template <class F> static int guarded(F f) {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(SXG_E_NOMEM, "out of host memory in the smoothing iteration"); }
+    catch (const std::exception& e) { return fail(SXG_E_INVALID, std::string("internal error: ") + e.what()); }
+}
+extern "C" {
 
 int sxg_smooth_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, sxg_poa_run_fn run, sxg_poa_free_fn fre, void* ctx,
                    char** out_gfa) {
-    return smooth_iteration(g, b, p, nullptr, run, fre, ctx, out_gfa, nullptr, nullptr);
+    return guarded([&] { return smooth_iteration(g, b, p, nullptr, run, fre, ctx, out_gfa, nullptr, nullptr); });
 }
 
 void sxg_merge_default_params(sxg_merge_params* mp) {
@@ -2586,7 +2760,7 @@ void sxg_merge_default_params(sxg_merge_params* mp) {
 int sxg_smooth_maf_gfa(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, const sxg_merge_params* mp, sxg_poa_run_fn run,
                        sxg_poa_free_fn fre, void* ctx, char** out_gfa, char** out_maf, int64_t* n_flipped) {
     if (!mp || !out_maf) return fail(SXG_E_INVALID, "NULL argument");
-    return smooth_iteration(g, b, p, mp, run, fre, ctx, out_gfa, out_maf, n_flipped);
+    return guarded([&] { return smooth_iteration(g, b, p, mp, run, fre, ctx, out_gfa, out_maf, n_flipped); });
 }
 
 // blockset_t from the caller's own blocks (src/blocks.hpp:29-43,70-120): block k owns ranges

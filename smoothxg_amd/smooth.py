@@ -16,19 +16,20 @@ FREE_FN = C.CFUNCTYPE(None, C.POINTER(_poa.BatchOut))
 
 
 class SmoothParams(C.Structure):
-    _fields_ = [("poa_m", C.c_int32), ("poa_n", C.c_int32), ("poa_g", C.c_int32), ("poa_e", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("poa_m", C.c_int32), ("poa_n", C.c_int32), ("poa_g", C.c_int32), ("poa_e", C.c_int32),
                 ("poa_q", C.c_int32), ("poa_c", C.c_int32), ("local_alignment", C.c_int32),
                 ("poa_padding_fraction", C.c_float), ("max_block_depth_for_padding_more", C.c_uint64),
                 ("add_consensus", C.c_int32), ("consensus_base_name", C.c_char_p),
-                ("adaptive_poa_params", C.c_int32), ("kmer_size", C.c_int32), ("use_abpoa", C.c_int32)]
+                ("adaptive_poa_params", C.c_int32), ("kmer_size", C.c_int32), ("use_abpoa", C.c_int32),
+                ("abpoa_band_local", C.c_int32)]
 
 
-EXPORTS = ["sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_free", "sxg_graph_from_gfa",
+EXPORTS = ["sxg_smooth_abi_version", "sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_free", "sxg_graph_from_gfa",
            "sxg_graph_free", "sxg_graph_node_count", "sxg_graph_path_count", "sxg_blockset_by_path_windows",
            "sxg_blockset_free", "sxg_blockset_size", "sxg_block_collect_text", "sxg_block_graph_gfa",
            "sxg_smooth_gfa", "sxg_adaptive_poa_scores", "sxg_block_identity_threshold",
            "sxg_block_maf_rows", "sxg_block_maf", "sxg_blockset_from_ranges", "sxg_blockset_block_size",
-           "sxg_blockset_block_ranges", "sxg_blockset_smoothable", "sxg_blockset_break", "sxg_merge_default_params", "sxg_smooth_maf_gfa"]
+           "sxg_blockset_block_ranges", "sxg_blockset_smoothable", "sxg_blockset_break", "sxg_blockset_break_ex", "sxg_merge_default_params", "sxg_smooth_maf_gfa"]
 
 
 class MergeParams(C.Structure):
@@ -67,6 +68,7 @@ def load_library():
     L.sxg_blockset_block_ranges.argtypes = [vp, C.c_int64, C.POINTER(PathRange)]
     L.sxg_blockset_smoothable.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]
     L.sxg_blockset_break.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.sxg_blockset_break_ex.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64, C.c_int, C.POINTER(vp)]
     L.sxg_blockset_free.argtypes = [vp]
     L.sxg_blockset_size.restype = C.c_int64
     L.sxg_blockset_size.argtypes = [vp]
@@ -118,7 +120,8 @@ class Smoother:
 
     def __init__(self, gfa_text, target_bp=None, blocks=None, discover=None):
         """discover: block discovery as smoothxg does it -- a dict with target_poa_length and n_haps (and optionally
-        max_path_jump, max_edge_jump, max_poa_length): smoothable_blocks then the length cut of break_blocks.
+        max_path_jump, max_edge_jump, max_poa_length, repeats): smoothable_blocks then the cutting half of break_blocks
+        (repeat-aware cut lengths with the reference's defaults unless repeats=None).
         blocks: the caller's own blockset -- a list of blocks, each a list of (path, step_begin, step_end)
         or (path, step_begin, step_end, length) in alignment order (sxg_blockset_from_ranges); otherwise the
         demo partition into path windows of target_bp."""
@@ -136,7 +139,12 @@ class Smoother:
                                                 int(discover.get("max_path_jump", 100)), int(discover.get("max_edge_jump", 0)), 1,
                                                 C.byref(raw))
             if not rc:
-                rc = self.L.sxg_blockset_break(g, raw, int(discover.get("max_poa_length", 2 * tl)), 1, C.byref(b))
+                rep = discover.get("repeats", (1000, 20000, 5, 50))   # (min_copy_length, max_copy_length, min_autocorr_z, autocorr_stride) or None
+                if rep is None:
+                    rc = self.L.sxg_blockset_break_ex(g, raw, int(discover.get("max_poa_length", 2 * tl)), 0, 1000, 20000, 5.0, 50, 1, C.byref(b))
+                else:
+                    rc = self.L.sxg_blockset_break_ex(g, raw, int(discover.get("max_poa_length", 2 * tl)), 1, int(rep[0]), int(rep[1]),
+                                                      float(rep[2]), int(rep[3]), 1, C.byref(b))
                 self.L.sxg_blockset_free(raw)
         elif blocks is not None:
             flat = [r for blk in blocks for r in blk]

@@ -677,3 +677,97 @@ def test_flat_lacing_equals_the_laced_graph_path(case, monkeypatch):
         monkeypatch.delenv("SXG_SMOOTH_LEGACY", raising=False)
         sm.close()
         assert fast == legacy
+
+
+def test_parameter_struct_is_checked():
+    """sxg_smooth_params carries its size (a caller built against another header is refused instead of having fields read from
+    whatever follows its struct), and scores whose engine form does not fit int8 are refused instead of wrapping."""
+    L = S.load_library()
+    assert L.sxg_smooth_abi_version() == 2
+    sm = S.Smoother(synthetic_gfa(0), target_bp=200)
+    prov = OracleProvider()
+    p = S.default_params()
+    assert p.struct_size == C.sizeof(S.SmoothParams) and p.abpoa_band_local == 1
+    p.struct_size -= 4
+    with pytest.raises(S.SmoothError, match="struct_size"):
+        sm.smooth_gfa(p, prov.provider())
+    with pytest.raises(S.SmoothError, match="int8"):
+        sm.smooth_gfa(S.default_params(poa_q=200), prov.provider())
+    with pytest.raises(S.SmoothError, match="int8"):
+        sm.smooth_gfa(S.default_params(use_abpoa=1, poa_q=100, poa_c=30), prov.provider())
+    with pytest.raises(S.SmoothError):
+        sm.collect_text(0, S.default_params(poa_n=-4))
+    sm.close()
+
+
+def tandem_repeat_gfa(seed, n_paths=4, unit=1300, copies=(3, 4, 3, 5), flank=400, node_bp=70, sub=0.01):
+    """Haplotypes that carry a tandem repeat: `copies[p]` copies of a `unit`-base motif between unique flanks, every path
+    on its own chain of nodes (so the block spans the whole locus and its ranges are several kbp long)."""
+    rng = np.random.default_rng(seed)
+    motif = rng.integers(0, 4, unit)
+    left, right = rng.integers(0, 4, flank), rng.integers(0, 4, flank)
+    lines, plines, nid = ["H\tVN:Z:1.0"], [], 1
+    for p in range(n_paths):
+        hap = np.concatenate([left] + [motif] * copies[p % len(copies)] + [right])
+        mut = rng.random(len(hap)) < sub
+        hap[mut] = (hap[mut] + rng.integers(1, 4, int(mut.sum()))) % 4
+        text = "".join("ACGT"[c] for c in hap)
+        steps = []
+        for a in range(0, len(text), node_bp):
+            lines.append("S\t%d\t%s" % (nid, text[a:a + node_bp]))
+            steps.append("%d+" % nid)
+            nid += 1
+        plines.append("P\thap%d\t%s\t*" % (p, ",".join(steps)))
+    return "\n".join(lines + plines) + "\n"
+
+
+def test_repeat_aware_cut_length_of_break_blocks():
+    """src/breaks.cpp:224-272 (break_repeats = true is what src/main.cpp:476 always passes): a block that has to be cut and
+    whose ranges hold a tandem repeat is cut at half the mean repeat length, every range of it.  The detector is a decree
+    (sautocorr is absent): C++ == Python restatement, the repeat is found at its true period, the cut differs from the blind
+    one, and the iteration on the repeat-cut blocks still preserves every path."""
+    text = tandem_repeat_gfa(11)
+    g = SO.Graph(text)
+    # one block per... the locus: every path one range of ~5-7 kbp
+    blocks = [[(p, 0, len(g.steps[p]), len(g.path_sequence(p))) for p in range(len(g.pname))]]
+    blocks[0].sort(key=lambda r: -r[3])
+    seq = g.path_sequence(blocks[0][0][0])
+    rl = SO.repeat_length(seq, 1000, 20000, 5.0, 50)
+    assert rl == 1300.0                                    # the motif's period (first lag of greatest z: not 2600, 3900)
+    assert SO.repeat_length(seq[:1900], 1000, 20000, 5.0, 50) == 0.0   # shorter than two minimal copies
+    rng = np.random.default_rng(3)
+    assert SO.repeat_length("".join("ACGT"[c] for c in rng.integers(0, 4, 6000)), 1000, 20000, 5.0, 50) == 0.0
+    want = SO.break_blocks(g, blocks, 2000)
+    blind = SO.break_blocks(g, blocks, 2000, repeats=None)
+    assert want != blind
+    assert max(r[3] for r in want[0]) <= 650 + 70          # pieces of just over 1300 / 2 bases (closed by a node of 70)
+    sm = S.Smoother(text, blocks=blocks)
+    L = sm.L
+    for rep, ref in (((1000, 20000, 5.0, 50), want), (None, blind), ((500, 3000, 4.0, 25), SO.break_blocks(g, blocks, 2000, repeats=(500, 3000, 4, 25)))):
+        out = C.c_void_p()
+        if rep is None:
+            assert L.sxg_blockset_break_ex(sm.g, sm.b, 2000, 0, 1000, 20000, 5.0, 50, 1, C.byref(out)) == 0
+        else:
+            assert L.sxg_blockset_break_ex(sm.g, sm.b, 2000, 1, rep[0], rep[1], rep[2], rep[3], 1, C.byref(out)) == 0
+        keep, sm.b = sm.b, out
+        got = [sm.block_ranges(k) for k in range(sm.n_blocks)]
+        sm.b = keep
+        L.sxg_blockset_free(out)
+        assert got == [[tuple(r) for r in blk] for blk in ref]
+    out = C.c_void_p()
+    assert L.sxg_blockset_break(sm.g, sm.b, 2000, 1, C.byref(out)) == 0   # the reference's defaults
+    keep, sm.b = sm.b, out
+    assert [sm.block_ranges(k) for k in range(sm.n_blocks)] == [[tuple(r) for r in blk] for blk in want]
+    sm.b = keep
+    L.sxg_blockset_free(out)
+    sm.close()
+    # discovery with the defaults takes the repeat-aware cut, end to end
+    sm = S.Smoother(text, discover=dict(target_poa_length=4000, n_haps=4, max_poa_length=2000))
+    prov = OracleProvider()
+    got = sm.smooth_gfa(S.default_params(), prov.provider())
+    o = SO.Graph(got)
+    for q, nm in enumerate(g.pname):
+        assert o.path_sequence(o.pname.index(nm)) == g.path_sequence(q)
+    blocks2 = SO.break_blocks(g, SO.smoothable_blocks(g, 4000 * 4, 4000, 100, 0), 2000)
+    assert got == SO.smooth(g, blocks2)
+    sm.close()
