@@ -1821,7 +1821,7 @@ RcclApi& rccl_api() {
         if (_r != ncclSuccess) return fail(SXG_E_NODEVICE, std::string(#x) + ": " + ncclGetErrorString(_r)); \
     } while (0)
 
-constexpr int BC_N_WORDS = 8;   // words per rank in the count exchange (BC_N below)
+constexpr int BC_N_WORDS = 16;   // words per rank in the count exchange (BC_N below)
 extern "C" int sxg_poa_comm_unique_id(uint8_t* id) {
     if (!id) return fail(SXG_E_INVALID, "NULL argument");
     static_assert(sizeof(ncclUniqueId) == SXG_POA_COMM_ID_BYTES, "ncclUniqueId size");
@@ -1890,6 +1890,7 @@ struct LocalBatch {
     std::vector<uint8_t> bases;
     std::vector<uint32_t> weights;
     std::vector<sxg_poa_params> params;
+    std::vector<int32_t> trims;
     sxg_poa_batch_in in;
 };
 void build_local(const sxg_poa_batch_in* in, const std::vector<int32_t>& part, LocalBatch& L) {
@@ -1909,11 +1910,24 @@ void build_local(const sxg_poa_batch_in* in, const std::vector<int32_t>& part, L
     L.in.n_blocks = (int32_t)part.size(); L.in.blk_off = L.blk_off.data(); L.in.seq_off = L.seq_off.data();
     L.in.bases = L.bases.data(); L.in.weights = L.weights.data(); L.in.params = L.params.data();
     L.in.per_block_params = in->per_block_params; L.in.want_consensus = in->want_consensus; L.in.want_msa = 0;
+    // the owning rank builds the block graphs of its blocks (the root only laces); the MSA is formatted on the root from
+    // the per-base paths, which then travel as well
+    L.in.want_block_graph = in->want_block_graph == 2 && in->want_msa ? 1 : in->want_block_graph;
+    L.in.bg_consensus_visited_only = in->bg_consensus_visited_only;
+    if (in->want_block_graph) {
+        for (int b : part) L.trims.push_back(in->bg_trim ? in->bg_trim[b] : 0);
+        if (L.trims.empty()) L.trims.push_back(0);
+        L.in.bg_trim = L.trims.data();
+    }
 }
 // blob of one rank: eight counts, then the arrays, every section 16-byte aligned
-enum { BC_NB = 0, BC_NS, BC_NBASES, BC_NODES, BC_EDGES, BC_CONS, BC_BYTES, BC_PAD /* error code of the rank (0 = fine) */, BC_N };
+enum { BC_NB = 0, BC_NS, BC_NBASES, BC_NODES, BC_EDGES, BC_CONS, BC_BYTES, BC_PAD /* error code of the rank (0 = fine) */,
+       // block graphs of the rank's blocks (want_block_graph): the owning rank builds them, the root only laces
+       BC_BG /* 0 = none, 1 = with, 2 = instead of the per-base paths */, BC_BG_NODES, BC_BG_EDGES, BC_BG_SEQ, BC_BG_STEPS, BC_BG_CONS,
+       BC_RES0, BC_RES1, BC_N };
 static_assert(BC_N == BC_N_WORDS, "count words");
-struct BlobLayout { size_t status, nn, ne, nc, score, cells, code, rank, group, et, eh, ew, paths, cons, total; };
+struct BlobLayout { size_t status, nn, ne, nc, score, cells, code, rank, group, et, eh, ew, paths, cons,
+                    bg_counts, bg_nsteps, bg_len, bg_od, bg_id, bg_seq, bg_eto, bg_steps, bg_cons, total; };
 BlobLayout blob_layout(const int64_t* c) {
     BlobLayout B;
     size_t cur = 0;
@@ -1922,7 +1936,12 @@ BlobLayout blob_layout(const int64_t* c) {
     B.score = sec(4 * (size_t)c[BC_NS]); B.cells = sec(8 * (size_t)c[BC_NS]);
     B.code = sec((size_t)c[BC_NODES]); B.rank = sec(4 * (size_t)c[BC_NODES]); B.group = sec(4 * (size_t)c[BC_NODES]);
     B.et = sec(4 * (size_t)c[BC_EDGES]); B.eh = sec(4 * (size_t)c[BC_EDGES]); B.ew = sec(4 * (size_t)c[BC_EDGES]);
-    B.paths = sec(4 * (size_t)c[BC_NBASES]); B.cons = sec(4 * (size_t)c[BC_CONS]);
+    B.paths = sec(c[BC_BG] == 2 ? 0 : 4 * (size_t)c[BC_NBASES]); B.cons = sec(4 * (size_t)c[BC_CONS]);
+    const bool bg = c[BC_BG] != 0;
+    B.bg_counts = sec(bg ? 4 * (size_t)BGC_N * (size_t)c[BC_NB] : 0); B.bg_nsteps = sec(bg ? 4 * (size_t)c[BC_NS] : 0);
+    B.bg_len = sec(bg ? 4 * (size_t)c[BC_BG_NODES] : 0); B.bg_od = sec(bg ? 4 * (size_t)c[BC_BG_NODES] : 0); B.bg_id = sec(bg ? (size_t)c[BC_BG_NODES] : 0);
+    B.bg_seq = sec(bg ? (size_t)c[BC_BG_SEQ] : 0); B.bg_eto = sec(bg ? 4 * (size_t)c[BC_BG_EDGES] : 0);
+    B.bg_steps = sec(bg ? 4 * (size_t)c[BC_BG_STEPS] : 0); B.bg_cons = sec(bg ? 4 * (size_t)c[BC_BG_CONS] : 0);
     B.total = cur;
     return B;
 }
@@ -1943,6 +1962,26 @@ int pack_blob(sxg_poa_handle* h, int64_t* counts) {
     memset(counts, 0, sizeof(int64_t) * BC_N);
     counts[BC_NB] = nb; counts[BC_NS] = h->n_seqs; counts[BC_NBASES] = h->n_bases;
     counts[BC_NODES] = noff[nb]; counts[BC_EDGES] = eoff[nb]; counts[BC_CONS] = coff[nb];
+    // block graphs: dense offsets from the block-graph kernel's counts (as sxg_poa_batch_download computes them)
+    const bool bg = h->want_block_graph && h->bg_done;
+    std::vector<int64_t> gno(nb + 1, 0), gso(nb + 1, 0), geo(nb + 1, 0), gco(nb + 1, 0), gpo(nb + 1, 0), src_no(nb + 1, 0), src_eo(nb + 1, 0);
+    if (bg) {
+        std::vector<int32_t> st(std::max(nb, 1)), nsteps((size_t)std::max<int64_t>(h->n_seqs, 1), 0);
+        if (nb) HIPCHK(hipMemcpy(st.data(), h->d_status.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        if (h->n_seqs) HIPCHK(hipMemcpy(nsteps.data(), h->d_bg_nsteps.p, 4 * (size_t)h->n_seqs, hipMemcpyDeviceToHost));
+        for (int b = 0; b < nb; ++b) {
+            const int32_t* c = h->bg_counts.data() + (size_t)BGC_N * b;
+            const bool ok = st[b] == ST_OK;
+            gno[b + 1] = gno[b] + (ok ? c[BGC_NODES] : 0); gso[b + 1] = gso[b] + (ok ? c[BGC_SEQ] : 0);
+            geo[b + 1] = geo[b] + (ok ? c[BGC_EDGES] : 0); gco[b + 1] = gco[b] + (ok && h->want_consensus ? c[BGC_CONS] : 0);
+            int64_t stp = 0;
+            for (int sq = h->h_blk_off[b]; sq < h->h_blk_off[b + 1]; ++sq) stp += nsteps[(size_t)sq];
+            gpo[b + 1] = gpo[b] + (ok ? stp : 0);
+            src_no[b] = h->bg_node_o[(size_t)b]; src_eo[b] = h->bg_edge_o[(size_t)b];
+        }
+        counts[BC_BG] = h->want_block_graph; counts[BC_BG_NODES] = gno[nb]; counts[BC_BG_EDGES] = geo[nb]; counts[BC_BG_SEQ] = gso[nb];
+        counts[BC_BG_STEPS] = gpo[nb]; counts[BC_BG_CONS] = gco[nb];
+    }
     const BlobLayout B = blob_layout(counts);
     counts[BC_BYTES] = (int64_t)B.total;
     int rc;
@@ -1959,11 +1998,14 @@ int pack_blob(sxg_poa_handle* h, int64_t* counts) {
         HIPCHK(hipMemcpyAsync(blob + B.score, h->d_score.p, 4 * (size_t)h->n_seqs, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(blob + B.cells, h->d_cells.p, 8 * (size_t)h->n_seqs, hipMemcpyDeviceToDevice, h->stream));
     }
-    if (h->n_bases) HIPCHK(hipMemcpyAsync(blob + B.paths, h->d_paths.p, 4 * (size_t)h->n_bases, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_tmp_a.p, soff.data(), 8 * (size_t)(nb + 1), hipMemcpyHostToDevice, h->stream));
+    if (h->n_bases && counts[BC_BG] != 2) HIPCHK(hipMemcpyAsync(blob + B.paths, h->d_paths.p, 4 * (size_t)h->n_bases, hipMemcpyDeviceToDevice, h->stream));
+    if (bg && nb) HIPCHK(hipMemcpyAsync(blob + B.bg_counts, h->d_bg_counts.p, 4 * (size_t)BGC_N * (size_t)nb, hipMemcpyDeviceToDevice, h->stream));
+    if (bg && h->n_seqs) HIPCHK(hipMemcpyAsync(blob + B.bg_nsteps, h->d_bg_nsteps.p, 4 * (size_t)h->n_seqs, hipMemcpyDeviceToDevice, h->stream));
+    const std::vector<int64_t>* cur_src = &soff;
     auto gather = [&](auto tag, const DevBuf& src, const std::vector<int64_t>& off, size_t at) -> int {
         typedef decltype(tag) Tv;
         if (off[nb] == 0) return SXG_OK;
+        HIPCHK(hipMemcpyAsync(h->d_tmp_a.p, cur_src->data(), 8 * (size_t)(nb + 1), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_tmp_b.p, off.data(), 8 * (size_t)(nb + 1), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL((gather_kernel<Tv>), dim3((unsigned)std::min(nb, 4096)), dim3(256), 0, h->stream, src.as<Tv>(), (Tv*)(blob + at),
                            h->d_tmp_a.as<int64_t>(), h->d_tmp_b.as<int64_t>(), nb);
@@ -1976,6 +2018,17 @@ int pack_blob(sxg_poa_handle* h, int64_t* counts) {
         (rc = gather(int32_t(), h->d_edge_head, eoff, B.eh)) || (rc = gather(uint32_t(), h->d_edge_w, eoff, B.ew)))
         return rc;
     if (h->want_consensus && (rc = gather(int32_t(), h->d_cons, coff, B.cons))) return rc;
+    if (bg) {
+        cur_src = &src_no;
+        if ((rc = gather(int32_t(), h->d_bg_len, gno, B.bg_len)) || (rc = gather(int32_t(), h->d_bg_od, gno, B.bg_od)) ||
+            (rc = gather(uint8_t(), h->d_bg_id, gno, B.bg_id)) || (rc = gather(uint8_t(), h->d_bg_seq, gso, B.bg_seq)))
+            return rc;
+        if (h->want_consensus && (rc = gather(int32_t(), h->d_bg_cons, gco, B.bg_cons))) return rc;
+        cur_src = &src_eo;
+        if ((rc = gather(int32_t(), h->d_bg_eto, geo, B.bg_eto))) return rc;
+        cur_src = &soff;
+        if ((rc = gather(int32_t(), h->d_bg_steps, gpo, B.bg_steps))) return rc;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     return SXG_OK;
 }
@@ -1990,20 +2043,33 @@ int assemble(const sxg_poa_batch_in* in, const std::vector<std::vector<int32_t>>
     out->n_blocks = nb; out->n_seqs = ns;
     o->status.assign(std::max(nb, 1), 0); o->score.assign((size_t)std::max<int64_t>(ns, 1), 0); o->cells.assign((size_t)std::max<int64_t>(ns, 1), 0);
     o->node_off.assign(nb + 1, 0); o->edge_off.assign(nb + 1, 0); o->cons_off.assign(nb + 1, 0);
-    o->seq_path_nodes = (int32_t*)host_big_alloc(4 * (size_t)std::max<int64_t>(nbases, 1));
-    if (!o->seq_path_nodes) return fail(SXG_E_NOMEM, "host allocation of the path array failed");
+    int bg_mode = 0;   // what the ranks sent (the same on all of them: every rank was handed the same request)
+    for (int r = 0; r < nranks; ++r) if (counts[(size_t)r * BC_N + BC_NB] > 0) bg_mode = std::max(bg_mode, (int)counts[(size_t)r * BC_N + BC_BG]);
+    const bool with_paths = bg_mode != 2;
+    if (with_paths) {
+        o->seq_path_nodes = (int32_t*)host_big_alloc(4 * (size_t)std::max<int64_t>(nbases, 1));
+        if (!o->seq_path_nodes) return fail(SXG_E_NOMEM, "host allocation of the path array failed");
+    }
     // where every block sits: (rank, index in the rank's shard, offsets inside that rank's arrays)
-    struct Where { int rank, idx; int64_t n0, e0, c0, s0, b0; };
+    struct Where { int rank, idx; int64_t n0, e0, c0, s0, b0, gn0, gs0, ge0, gc0, gp0; };
     std::vector<Where> where(std::max(nb, 1));
     for (int r = 0; r < nranks; ++r) {
         const int64_t* c = counts.data() + (size_t)r * BC_N;
         const BlobLayout B = blob_layout(c);
         const uint8_t* blob = blobs[r].data();
         const int32_t *nn = (const int32_t*)(blob + B.nn), *ne = (const int32_t*)(blob + B.ne), *nc = (const int32_t*)(blob + B.nc);
-        int64_t n0 = 0, e0 = 0, c0 = 0, s0 = 0, b0 = 0;
+        int64_t n0 = 0, e0 = 0, c0 = 0, s0 = 0, b0 = 0, gn0 = 0, gs0 = 0, ge0 = 0, gc0 = 0, gp0 = 0;
+        const int32_t* gcnt = (const int32_t*)(blob + B.bg_counts);
+        const int32_t* gnst = (const int32_t*)(blob + B.bg_nsteps);
+        const int32_t* rst = (const int32_t*)(blob + B.status);
         for (size_t k = 0; k < parts[r].size(); ++k) {
             const int b = parts[r][k];
-            where[b] = Where{r, (int)k, n0, e0, c0, s0, b0};
+            where[b] = Where{r, (int)k, n0, e0, c0, s0, b0, gn0, gs0, ge0, gc0, gp0};
+            if (c[BC_BG] && rst[k] == ST_OK) {
+                const int32_t* q = gcnt + (size_t)BGC_N * k;
+                gn0 += q[BGC_NODES]; gs0 += q[BGC_SEQ]; ge0 += q[BGC_EDGES]; gc0 += in->want_consensus ? q[BGC_CONS] : 0;
+                for (int64_t sq = s0; sq < s0 + (in->blk_off[b + 1] - in->blk_off[b]); ++sq) gp0 += gnst[sq];
+            }
             o->node_off[b + 1] = nn[k]; o->edge_off[b + 1] = ne[k]; o->cons_off[b + 1] = in->want_consensus ? nc[k] : 0;
             n0 += nn[k]; e0 += ne[k]; c0 += in->want_consensus ? nc[k] : 0;
             s0 += in->blk_off[b + 1] - in->blk_off[b];
@@ -2030,7 +2096,53 @@ int assemble(const sxg_poa_batch_in* in, const std::vector<std::vector<int32_t>>
         const int64_t nsq = in->blk_off[b + 1] - in->blk_off[b], nbs = in->seq_off[in->blk_off[b + 1]] - in->seq_off[in->blk_off[b]];
         memcpy(o->score.data() + in->blk_off[b], blob + B.score + 4 * wv.s0, 4 * (size_t)nsq);
         memcpy(o->cells.data() + in->blk_off[b], blob + B.cells + 8 * wv.s0, 8 * (size_t)nsq);
-        memcpy(o->seq_path_nodes + in->seq_off[in->blk_off[b]], blob + B.paths + 4 * wv.b0, 4 * (size_t)nbs);
+        if (with_paths) memcpy(o->seq_path_nodes + in->seq_off[in->blk_off[b]], blob + B.paths + 4 * wv.b0, 4 * (size_t)nbs);
+    }
+    if (bg_mode) {
+        // block graphs in the batch's block order: offsets first, then every block's pieces from its rank's blob
+        o->bg_node_off.assign(nb + 1, 0); o->bg_seq_off.assign(nb + 1, 0); o->bg_edge_off.assign(nb + 1, 0); o->bg_cons_off.assign(nb + 1, 0);
+        o->bg_step_off.assign((size_t)ns + 1, 0);
+        for (int b = 0; b < nb; ++b) {
+            const Where& wv = where[b];
+            const int64_t* c = counts.data() + (size_t)wv.rank * BC_N;
+            const BlobLayout B = blob_layout(c);
+            const uint8_t* blob = blobs[wv.rank].data();
+            const bool ok = c[BC_BG] && o->status[b] == ST_OK;
+            const int32_t* q = (const int32_t*)(blob + B.bg_counts) + (size_t)BGC_N * wv.idx;
+            o->bg_node_off[b + 1] = o->bg_node_off[b] + (ok ? q[BGC_NODES] : 0);
+            o->bg_seq_off[b + 1] = o->bg_seq_off[b] + (ok ? q[BGC_SEQ] : 0);
+            o->bg_edge_off[b + 1] = o->bg_edge_off[b] + (ok ? q[BGC_EDGES] : 0);
+            o->bg_cons_off[b + 1] = o->bg_cons_off[b] + (ok && in->want_consensus ? q[BGC_CONS] : 0);
+            const int32_t* gnst = (const int32_t*)(blob + B.bg_nsteps) + wv.s0;
+            for (int sq = in->blk_off[b]; sq < in->blk_off[b + 1]; ++sq)
+                o->bg_step_off[(size_t)sq + 1] = o->bg_step_off[(size_t)sq] + (ok ? gnst[sq - in->blk_off[b]] : 0);
+        }
+        o->bg_node_len.resize((size_t)std::max<int64_t>(o->bg_node_off[nb], 1)); o->bg_node_outdeg.resize(o->bg_node_len.size());
+        o->bg_node_indeg.resize(o->bg_node_len.size()); o->bg_seq.resize((size_t)std::max<int64_t>(o->bg_seq_off[nb], 1));
+        o->bg_edge_to.resize((size_t)std::max<int64_t>(o->bg_edge_off[nb], 1)); o->bg_steps.resize((size_t)std::max<int64_t>(o->bg_step_off[(size_t)ns], 1));
+        o->bg_cons_steps.resize((size_t)std::max<int64_t>(o->bg_cons_off[nb], 1));
+        for (int b = 0; b < nb; ++b) {
+            const Where& wv = where[b];
+            const BlobLayout B = blob_layout(counts.data() + (size_t)wv.rank * BC_N);
+            const uint8_t* blob = blobs[wv.rank].data();
+            const int64_t n = o->bg_node_off[b + 1] - o->bg_node_off[b], sb = o->bg_seq_off[b + 1] - o->bg_seq_off[b], ne = o->bg_edge_off[b + 1] - o->bg_edge_off[b];
+            const int64_t nc = o->bg_cons_off[b + 1] - o->bg_cons_off[b];
+            const int64_t p0 = o->bg_step_off[(size_t)in->blk_off[b]], np = o->bg_step_off[(size_t)in->blk_off[b + 1]] - p0;
+            if (n) {
+                memcpy(o->bg_node_len.data() + o->bg_node_off[b], blob + B.bg_len + 4 * wv.gn0, 4 * (size_t)n);
+                memcpy(o->bg_node_outdeg.data() + o->bg_node_off[b], blob + B.bg_od + 4 * wv.gn0, 4 * (size_t)n);
+                memcpy(o->bg_node_indeg.data() + o->bg_node_off[b], blob + B.bg_id + wv.gn0, (size_t)n);
+            }
+            if (sb) memcpy(o->bg_seq.data() + o->bg_seq_off[b], blob + B.bg_seq + wv.gs0, (size_t)sb);
+            if (ne) memcpy(o->bg_edge_to.data() + o->bg_edge_off[b], blob + B.bg_eto + 4 * wv.ge0, 4 * (size_t)ne);
+            if (nc) memcpy(o->bg_cons_steps.data() + o->bg_cons_off[b], blob + B.bg_cons + 4 * wv.gc0, 4 * (size_t)nc);
+            if (np) memcpy(o->bg_steps.data() + p0, blob + B.bg_steps + 4 * wv.gp0, 4 * (size_t)np);
+        }
+        out->bg_node_off = o->bg_node_off.data(); out->bg_node_len = o->bg_node_len.data(); out->bg_node_outdeg = o->bg_node_outdeg.data();
+        out->bg_node_indeg = o->bg_node_indeg.data(); out->bg_seq_off = o->bg_seq_off.data(); out->bg_seq = (char*)o->bg_seq.data();
+        out->bg_edge_off = o->bg_edge_off.data(); out->bg_edge_to = o->bg_edge_to.data(); out->bg_step_off = o->bg_step_off.data();
+        out->bg_steps = o->bg_steps.data();
+        if (in->want_consensus) { out->bg_cons_off = o->bg_cons_off.data(); out->bg_cons_steps = o->bg_cons_steps.data(); }
     }
     out->status = o->status.data();
     out->node_off = o->node_off.data(); out->node_code = o->node_code.data(); out->node_rank = o->node_rank.data();
@@ -2038,7 +2150,7 @@ int assemble(const sxg_poa_batch_in* in, const std::vector<std::vector<int32_t>>
     out->edge_head = o->edge_head.data(); out->edge_weight = o->edge_weight.data();
     out->seq_path_nodes = o->seq_path_nodes; out->score = o->score.data(); out->cells = o->cells.data();
     if (in->want_consensus) { out->cons_off = o->cons_off.data(); out->cons_nodes = o->cons_nodes.data(); }
-    if (in->want_msa) {
+    if (in->want_msa && o->seq_path_nodes) {
         format_msa(o, in, in->want_consensus != 0);
         out->msa_off = o->msa_off.data(); out->msa_cols = o->msa_cols.data(); out->msa = o->msa.data();
     }

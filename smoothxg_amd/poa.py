@@ -354,10 +354,10 @@ class PoaEngine:
             raise self._err("sxg_poa_comm_init")
 
     def run_flat_sharded(self, bases, seq_off, blk_off, weights, params, want_consensus=False, want_msa=False, check=True,
-                         simulate_ranks=0):
+                         simulate_ranks=0, block_graph=0, bg_trim=None, bg_cons_visited_only=False):
         """sxg_poa_batch_run_sharded: every rank passes the SAME batch; rank 0 gets all results (list), the others None.
         simulate_ranks > 0: the test entry that plays that many ranks on this one GPU."""
-        bi = self._mk_in(bases, seq_off, blk_off, weights, params, want_consensus, want_msa)
+        bi = self._mk_in(bases, seq_off, blk_off, weights, params, want_consensus, want_msa, block_graph, bg_trim, bg_cons_visited_only)
         self._shape = (np.asarray(blk_off).copy(), np.asarray(seq_off).copy())
         out = BatchOut()
         if simulate_ranks:

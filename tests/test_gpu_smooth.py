@@ -230,3 +230,48 @@ def test_device_block_graphs_feed_the_same_gfa_as_host_built_ones(engine, monkey
         monkeypatch.delenv("SXG_SMOOTH_LEGACY", raising=False)
         sm.close()
         assert fast == legacy
+
+
+def test_sharded_runs_carry_block_graphs_built_by_the_owning_rank(engine):
+    """Multi-GPU: every rank builds the block graphs of ITS blocks on its device and sends compact graphs (not one node id
+    per base) to the rank that laces.  Played with simulated ranks on the one GPU (partition, per-rank blobs with the bg
+    sections, the root's assembly in batch order) and through a real one-rank communicator: the block graphs equal the
+    single-GPU ones, mode 2 leaves the per-base paths out of the blobs, and sxg_smooth_gfa over the sharded entry gives the
+    single-GPU bytes."""
+    import numpy as np
+    import smoothxg_amd as SX
+    from helpers import random_block
+    rng = np.random.default_rng(311)
+    blocks = [random_block(rng, int(rng.integers(1, 10)), int(rng.choice([40, 300, 900])), div=0.06) if b != 4 else [] for b in range(13)]
+    trims = [int(rng.integers(0, 12)) for _ in blocks]
+    flat = [s for blk in blocks for s in blk]
+    bases = np.concatenate(flat).astype(np.uint8)
+    seq_off = np.zeros(len(flat) + 1, np.int64)
+    seq_off[1:] = np.cumsum([len(s) for s in flat])
+    blk_off = np.zeros(len(blocks) + 1, np.int32)
+    blk_off[1:] = np.cumsum([len(b) for b in blocks])
+    prm = SX.Params(1, -4, -6, -2, -26, -1, 0, 0)
+    ref = engine.run_flat(bases, seq_off, blk_off, None, prm, want_consensus=True, block_graph=1, bg_trim=trims)
+    names = lambda b: [["s%d" % i] for i in range(len(blocks[b]))]
+
+    def same(res, mode):
+        for b, (a, r) in enumerate(zip(res, ref)):
+            assert a.status == r.status == 0
+            assert (a.paths is None) == (mode == 2)
+            if blocks[b]:
+                assert a.bg.gfa(names(b), None, "c") == r.bg.gfa(names(b), None, "c")
+                assert (a.bg.node_indeg == r.bg.node_indeg).all()
+    for nranks in (1, 2, 3):
+        for mode in (1, 2):
+            same(engine.run_flat_sharded(bases, seq_off, blk_off, None, prm, want_consensus=True, simulate_ranks=nranks, block_graph=mode,
+                                         bg_trim=trims), mode)
+    engine.comm_init(engine.comm_unique_id(), 1, 0)
+    try:
+        same(engine.run_flat_sharded(bases, seq_off, blk_off, None, prm, want_consensus=True, block_graph=2, bg_trim=trims), 2)
+        text = open(DRB1).read()
+        sm = S.Smoother(text, 900)
+        p = S.default_params(add_consensus=1)
+        assert sm.smooth_gfa(p, S.gpu_provider(engine, sharded=True)) == sm.smooth_gfa(p, S.gpu_provider(engine))
+        sm.close()
+    finally:
+        engine.lib.sxg_poa_comm_destroy(engine.h)

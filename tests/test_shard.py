@@ -177,3 +177,127 @@ def test_shard_gather_lace_equals_single_rank_gloo_world2():
     for p in procs:
         p.join(60)
     assert got == [(0, True), (1, True)]
+
+
+def _bg_lace_worker(rank, world, port, q):
+    """Every rank builds the COMPACT block graphs of its LPT share (the product's block-graph code through the CPU
+    emulation harness, on the oracle's POA), the graphs meet on rank 0 over gloo, and rank 0 laces graphs it did not build
+    (sxg_poa_batch_out::bg_*: what sxg_poa_batch_run_sharded hands it when block graphs are asked for)."""
+    import ctypes as C
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import test_graph_emul as GE
+    import test_smooth_host as H
+    from oracle import oracle_py as O
+    from smoothxg_amd import smooth as S
+    emul = C.CDLL(os.path.join(here, "csrc", "libgraph_emul.so"))
+    stats = {"built": 0, "asked": 0}
+
+    class ShardedBgProvider(H.OracleProvider):
+        def _run(self, ctx, pin, pout):
+            i, o = pin.contents, pout.contents
+            nb = i.n_blocks
+            blk = np.ctypeslib.as_array(i.blk_off, (nb + 1,)).copy()
+            ns = int(blk[-1])
+            so = np.ctypeslib.as_array(i.seq_off, (ns + 1,)).copy()
+            bases = np.ctypeslib.as_array(i.bases, (max(int(so[-1]), 1),)).copy()
+            w = np.ctypeslib.as_array(i.weights, (max(ns, 1),)).copy()
+            trim = np.ctypeslib.as_array(i.bg_trim, (max(nb, 1),)).copy() if i.bg_trim else np.zeros(max(nb, 1), np.int32)
+            stats["asked"] = i.want_block_graph
+            costs = [shard.block_cost(np.diff(so[blk[b]:blk[b + 1] + 1])) for b in range(nb)]
+            mine = shard.partition_blocks(costs, world)[rank]
+            pr = i.params[0]
+            par = O.mkparams(pr.m, pr.n, pr.g, pr.e, pr.q, pr.c, pr.mode)
+            local = {}
+            for b in mine:
+                seqs = [bases[so[s]:so[s + 1]] for s in range(blk[b], blk[b + 1])]
+                if seqs:
+                    g, _, _ = O.block_run(seqs, w[blk[b]:blk[b + 1]], par)
+                    B = GE.run_block_graph_emul(emul, g, seqs, int(trim[b]), (2 if i.bg_consensus_visited_only else 1) if i.want_consensus else 0)
+                    local[b] = (B.node_seq, B.node_indeg, B.edges, [np.asarray(p) for p in B.paths], np.asarray(B.consensus))
+                    stats["built"] += 1
+            parts = [None] * world
+            dist.all_gather_object(parts, local)
+            if rank != 0:
+                return 1   # SXG_NOT_ROOT
+            merged = {}
+            for part in parts:
+                merged.update(part)
+            node_off, seq_off, edge_off, cons_off, step_off = [0], [0], [0], [0], [0]
+            nlen, nod, nid_, seq, eto, steps, cons = [], [], [], b"", [], [], []
+            for b in range(nb):
+                if b in merged:
+                    ns_, idg, edges, paths, cn = merged[b]
+                    od = np.zeros(len(ns_), np.int32)
+                    for a, _ in edges:
+                        od[a] += 1
+                    nlen += [len(x) for x in ns_]; nod += od.tolist(); nid_ += list(idg)
+                    seq += "".join(ns_).encode(); eto += [h for _, h in edges]; cons += cn.tolist()
+                    for p in paths:
+                        steps += p.tolist()
+                        step_off.append(len(steps))
+                else:
+                    step_off += [step_off[-1]] * int(blk[b + 1] - blk[b])
+                node_off.append(len(nlen)); seq_off.append(len(seq)); edge_off.append(len(eto)); cons_off.append(len(cons))
+            arr = lambda x, dt: np.ascontiguousarray(np.asarray(x if len(x) else [0], dt))
+            A = dict(node_off=arr(node_off, np.int64), seq_off=arr(seq_off, np.int64), edge_off=arr(edge_off, np.int64), cons_off=arr(cons_off, np.int64),
+                     step_off=arr(step_off, np.int64), nlen=arr(nlen, np.int32), nod=arr(nod, np.int32), nid=arr(nid_, np.uint8),
+                     seq=np.frombuffer(seq + b"\0", np.uint8).copy(), eto=arr(eto, np.int32), steps=arr(steps, np.int32), cons=arr(cons, np.int32),
+                     status=np.zeros(max(nb, 1), np.int32))
+            self.keep.append(A)
+            P32, P64, P8 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+            o.n_blocks, o.n_seqs = nb, ns
+            o.status = A["status"].ctypes.data_as(P32)
+            o.bg_node_off = A["node_off"].ctypes.data_as(P64); o.bg_node_len = A["nlen"].ctypes.data_as(P32)
+            o.bg_node_outdeg = A["nod"].ctypes.data_as(P32); o.bg_node_indeg = A["nid"].ctypes.data_as(P8)
+            o.bg_seq_off = A["seq_off"].ctypes.data_as(P64); o.bg_seq = A["seq"].ctypes.data
+            o.bg_edge_off = A["edge_off"].ctypes.data_as(P64); o.bg_edge_to = A["eto"].ctypes.data_as(P32)
+            o.bg_step_off = A["step_off"].ctypes.data_as(P64); o.bg_steps = A["steps"].ctypes.data_as(P32)
+            if i.want_consensus:
+                o.bg_cons_off = A["cons_off"].ctypes.data_as(P64); o.bg_cons_steps = A["cons"].ctypes.data_as(P32)
+            return 0
+
+    ok = True
+    for text, tb, kw in ((H.haplotype_gfa(5, n_paths=5, length=900), 250, dict(add_consensus=1)),
+                         (H.synthetic_gfa(2), 120, dict()),
+                         (H.haplotype_gfa(7, n_paths=4, length=700), 200, dict(add_consensus=1, use_abpoa=1, poa_padding_fraction=0.0))):
+        prov = ShardedBgProvider()
+        stats["built"] = 0
+        sm = S.Smoother(text, tb)
+        got = sm.smooth_gfa(S.default_params(**kw), prov.provider())
+        if rank == 0:
+            single = S.Smoother(text, tb).smooth_gfa(S.default_params(**kw), H.OracleProvider().provider())
+            if not (got is not None and got == single and stats["asked"] == 2 and 0 < stats["built"] < sm.n_blocks):
+                print("MISMATCH", tb, kw, got == single, stats, sm.n_blocks, flush=True)
+            ok = ok and got is not None and got == single and stats["asked"] == 2 and 0 < stats["built"] < sm.n_blocks
+        else:
+            ok = ok and got is None
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_root_laces_compact_block_graphs_built_on_other_ranks_gloo_world2():
+    """Verdict item: in the sharded run the block graphs are built on the owning rank; rank 0 receives compact graphs and
+    only laces.  Two gloo ranks, the product's block-graph code (emulated on the CPU) as every rank's builder: rank 0's GFA
+    equals the single-rank GFA built from per-base paths on the host."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call(["make", "-C", os.path.join(here, "csrc"), "-s"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bg_lace_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert got == [(0, True), (1, True)]
