@@ -92,8 +92,11 @@ typedef struct sxg_poa_params {
                            snapshot); whole 6-, 8- or 11-column strips, at most 128 strips.
                        1 = STATIC band: w columns either side of the node's backbone coordinate (decrees B1-B3), known
                            before the sweep starts; same kernel, no per-row search of the best cell.
-                       Local mode only (a global alignment asked to be banded runs the full matrix); out->cells
-                       then counts band cells.  sxg_poa_align_batch ignores it.                                   */
+                       The adaptive band serves local AND global alignments (smooth_abpoa sets wb / wf for both modes,
+                       src/smooth.cpp:259-271); the static band is for local mode only (a global alignment that asks for
+                       it runs the full matrix, and so does a global alignment whose scores leave the packed sweep's
+                       int16 range: affine defaults beyond ~3.9 kbp).  out->cells then counts band cells.
+                       sxg_poa_align_batch ignores it.                                                            */
 } sxg_poa_params;
 
 typedef struct sxg_poa_handle sxg_poa_handle;

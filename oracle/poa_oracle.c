@@ -61,7 +61,9 @@
  *     rows; a band known before the row is computed is what lets the MI355X sweep slide a one-wave window
  *     along the diagonal.)  The virtual source row is not banded.
  *  B3 a cell outside its row's band does not exist: H and both outgoing gap candidates are -inf for every
- *     reader, in-row gaps start at the band's first column.  Local mode only; cells = sum of band widths.
+ *     reader, in-row gaps start at the band's first column.  cells = sum of band widths.  The backbone band (banded = 1)
+ *     is for local mode only (a global alignment ends in column L of a sink row, which a band around backbone
+ *     coordinates need not hold); the adaptive band B4 serves both modes, as smooth_abpoa sets it (src/smooth.cpp:259-271).
  *  B4 ADAPTIVE band (banded = 2; abPOA's published rule -- Gao et al. 2021, "adaptive banding": the band of a node
  *     follows the best-scoring cells of its predecessors and the node's position in the graph).  For the row of node v:
  *       remain(v) = number of edges of the walk that leaves v by its heaviest out-edge (the first of greatest weight in
@@ -489,7 +491,7 @@ int poa_align_ws(poa_ws_t *ws, const poa_graph_t *g, const uint8_t *seq, int len
     int32_t *row_node = (int32_t *)ws_get(ws, WS_ROWNODE, sizeof(int32_t) * (size_t)N);
     poa_graph_rows(g, codes, off, pred, sink, row_node);
     int n = -1;
-    const int banded = p->banded && p->mode == POA_MODE_SW;
+    const int banded = p->banded && (p->mode == POA_MODE_SW || band_is_adaptive(p->banded));   /* global: the adaptive band only */
     if (ws->impl == POA_IMPL_AVX2 && !banded) {   /* (-1: no AVX2 on this host, or the scores leave int16: scalar path) */
         if (!ws->simd) ws->simd = poa_simd_ws_new();
         n = poa_align_rows_simd(ws->simd, N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score);
@@ -752,7 +754,7 @@ poa_graph_t *poa_block_run_ws(poa_ws_t *ws, const uint8_t *bases, const int32_t 
     int32_t *an = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
     int32_t *ap = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
     poa_params_t pb = *p;   /* B2: one strip width for all alignments of the block, from its longest sequence */
-    if (pb.banded && pb.mode == POA_MODE_SW)
+    if (pb.banded && (pb.mode == POA_MODE_SW || band_is_adaptive(pb.banded)))
         pb.banded = (uint8_t)((band_is_adaptive(pb.banded) ? 0x80 : 0) | poa_band_strip_width((long)maxlen));
     for (int s = 0; s < n_seqs; ++s) {
         const uint8_t *seq = bases + seq_off[s];

@@ -20,7 +20,12 @@
 //   * lanes outside the band compute values nobody reads; they are forced to -inf only where the band is about
 //     to change (their strips may enter the next row's band) and kept out of the gap scan, the hand-over, the
 //     end-cell search and the stores.
-// Local alignment only (decree B3); a global alignment asked to be banded runs the full sweep.
+// SW = false: GLOBAL alignment (smooth_abpoa sets its band for both modes, src/smooth.cpp:259-271), adaptive band only.
+// Nothing is clamped at 0 then; a cell none of whose sources exists holds "minus infinity give or take a few penalties"
+// (NEGP +- ...), which no real score -- all within +-15 800, checked per alignment -- ever equals or falls below, and
+// such cells only occur in the strip by which a band moved LEFT (to the right of it the row's own gaps reach every cell
+// from a real one), so the drift stays a few steps.  The virtual row is not banded: a row whose predecessor it is takes
+// the gap costs of its columns.  End cell: column L of the sink rows (its strip is in their band: remain() = 0).
 //
 // ADAPTIVE band (params.banded = 2, decree B4 -- abPOA's rule): the band of a row follows the columns of the greatest H of
 // its predecessor rows and the node's distance to the end of the graph.  Everything it depends on belongs to EARLIER rows,
@@ -56,7 +61,7 @@ __device__ __forceinline__ void band_strips_of(const int hint, const int w, cons
     bh = min((hint + w) / W, last_strip);
 }
 
-template <bool CVX, int W>
+template <bool CVX, int W, bool SW = true>
 __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView R, const int N_, const uint8_t* seq, const int L_,
                                                const DpBuffers B, char* smem, unsigned long long* cells_out) {
     DpResult res;
@@ -106,6 +111,13 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         bl_ = sb; bh_ = se;
     };
 
+    // H of the virtual row (global mode): the cost of the gap that precedes column j
+    auto row0_h = [&](const int j) -> int {
+        if (j < 0 || j > L) return NEGP;
+        if (j == 0) return 0;
+        const int a_ = g + (j - 1) * e, b_ = q + (j - 1) * c;
+        return max(a_ > b_ ? a_ : b_, NEGP);
+    };
     int s0 = -1000000;          // window origin (strip); far away: the first row re-centres
     unsigned let[NL];           // letters of my two strips, one byte per (strip, column): (lo_k+1, lo_k, hi_k+1, hi_k)
     unsigned so_lo = 0, so_hi = 0;   // byte offsets of my strips' slots in a plane row
@@ -115,7 +127,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
     int pbl = 0, pbh = -1;      // band strips of the row held in Hp/Fp/Op (row i-1); empty: nothing valid in registers
     bool regs_ok = false;       // Hp/Fp/Op hold row i-1 aligned to the current window
     bool next_sib = false;
-    int best_lo = 0, best_hi = 0, bi_lo = -1, bi_hi = -1, bj_lo = 0, bj_hi = 0;   // (bj: ABSOLUTE column -- the window moves)
+    int best_lo = SW ? 0 : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bj_lo = 0, bj_hi = 0;   // (bj: ABSOLUTE column -- the window moves)
     unsigned long long cells = 0;
 
 #ifdef SXG_ROW_PROF
@@ -150,7 +162,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         const int p1 = __builtin_amdgcn_readfirstlane(m1.x);
         const int h1 = __builtin_amdgcn_readfirstlane(m1.y);    // hint of predecessor #1
         const int hint = __builtin_amdgcn_readfirstlane(m1.w);
-        const int np = info & 0xffff, code = (info >> 16) & 0xff;
+        const int np = info & 0xffff, code = (info >> 16) & 0xff, flags = (info >> 24) & 0xff;
         const unsigned SC_T0 = SC_N4 ^ (code < 4 ? SC_MX << (8 * code) : 0u), SC_T1 = SC_N4 ^ (code == 4 ? SC_MX : 0u);
 
         int bl, bh;
@@ -211,9 +223,17 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
 #define BAND_FETCH(p_, hp_, wr_, hl_)                                                                       \
     do {                                                                                                    \
         if ((p_) == 0) {                                                                                    \
-            const int z_ = pk2(st_lo * W <= L ? 0 : NEGP, st_hi * W <= L ? 0 : NEGP);                        \
-            _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = p16_pack_row<CVX>(z_, pk_add(z_, G2), CVX ? pk_add(z_, Q2) : NEG2); \
-            hl_ = pk2(st_lo == 0 ? NEGP : 0, 0);                                                            \
+            if (SW) {                                                                                       \
+                const int z_ = pk2(st_lo * W <= L ? 0 : NEGP, st_hi * W <= L ? 0 : NEGP);                    \
+                _Pragma("unroll") for (int k = 0; k < W; ++k) wr_[k] = p16_pack_row<CVX>(z_, pk_add(z_, G2), CVX ? pk_add(z_, Q2) : NEG2); \
+                hl_ = pk2(st_lo == 0 ? NEGP : 0, 0);                                                        \
+            } else {                                                                                        \
+                _Pragma("unroll") for (int k = 0; k < W; ++k) {                                             \
+                    const int z_ = pk2(row0_h(st_lo * W + k), row0_h(st_hi * W + k));                       \
+                    wr_[k] = p16_pack_row<CVX>(z_, pk_add(z_, G2), CVX ? pk_add(z_, Q2) : NEG2);            \
+                }                                                                                           \
+                hl_ = pk2(row0_h(st_lo * W - 1), row0_h(st_hi * W - 1));                                    \
+            }                                                                                               \
         } else {                                                                                            \
             int fl_, fh_;                                                                                   \
             if (ada) { fl_ = (hp_) & 0xffff; fh_ = (int)((unsigned)(hp_) >> 16); }                          \
@@ -313,7 +333,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             if (CVX) b = pk_max(pk_add(b, C2), h);
             SXG_PIN("+v"(Hc[k]), "+v"(a), "+v"(b));
         }
-        a = pk_max(a, 0); if (CVX) b = pk_max(b, 0);
+        if (SW) { a = pk_max(a, 0); if (CVX) b = pk_max(b, 0); }
         a = pk_add(a, G2);
         if (CVX) b = pk_add(b, Q2);
         // ---- carries: strips outside the band contribute nothing; lo strips precede hi strips
@@ -335,12 +355,12 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         int E = pk2(Ein_lo, Ein_hi), Q = pk2(Qin_lo, Qin_hi);
 
         // ---- pass 2: final H
-        int rowmax = 0;
+        int rowmax = SW ? 0 : NEG2;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             int h = pk_max(Hc[k], E);
             if (CVX) h = pk_max(h, Q);
-            h = pk_max(h, 0);
+            if (SW) h = pk_max(h, 0);
             Hc[k] = h;
             rowmax = pk_max(rowmax, h);
             E = pk_max(pk_add(h, G2), pk_add(E, E2));
@@ -358,9 +378,19 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         }
 
         BP_MARK(2);   // pass 1, scan, pass 2
-        // ---- end cell (local): only cells of the band count
-        rowmax &= m2;
-        {
+        // ---- end cell: only cells of the band count
+        rowmax = SW ? (rowmax & m2) : ((rowmax & m2) | (NEG2 & ~m2));
+        if (!SW) {
+            // global: column L of a row without successors (first strictly greatest); the strip of column L is in a sink's band
+            if (flags & ROW_SINK) {
+                const int kL = L - last_strip * W;
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    if (k == kL && in_lo && st_lo == last_strip && (bi_lo < 0 || pk_lo(Hc[k]) > best_lo)) { best_lo = pk_lo(Hc[k]); bi_lo = i; bj_lo = L; }
+                    if (k == kL && in_hi && st_hi == last_strip && (bi_hi < 0 || pk_hi(Hc[k]) > best_hi)) { best_hi = pk_hi(Hc[k]); bi_hi = i; bj_hi = L; }
+                }
+            }
+        } else {
             const bool il = pk_lo(rowmax) > best_lo, ih = pk_hi(rowmax) > best_hi;
             if (__any(il || ih)) {
                 if (il) { best_lo = pk_lo(rowmax); bi_lo = i; }
@@ -381,10 +411,10 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             int rmx = rowmax;
             if (bh == last_strip) {   // the strip of column L also has columns beyond L: not cells, and they may hold more than any cell
                 const int kL = L - last_strip * W;
-                int rv = 0;
+                int rv = SW ? 0 : NEG2;
 #pragma unroll
                 for (int k = 0; k < W; ++k) if (k <= kL) rv = pk_max(rv, Hc[k]);
-                rv &= m2;
+                rv = SW ? (rv & m2) : ((rv & m2) | (NEG2 & ~m2));
                 if (st_lo == last_strip) rmx = (int)(((unsigned)rmx & 0xffff0000u) | ((unsigned)rv & 0x0000ffffu));
                 if (st_hi == last_strip) rmx = (int)(((unsigned)rmx & 0x0000ffffu) | ((unsigned)rv & 0xffff0000u));
             }

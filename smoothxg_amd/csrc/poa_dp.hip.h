@@ -204,16 +204,16 @@ __device__ __forceinline__ void sxg_balance_prio(const DpBuffers& B, const unsig
     if (threadIdx.x == 0) __hip_atomic_store(B.prio_board + B.prio_rank, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the eight ranks come through the scalar data path (s_load, glc: past the constant cache): a
     // vector load here would be waited for with vmcnt, in order behind every store still in flight
-    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
-    u32x8 bw;
+    typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 bw;
     const unsigned long long bp = (unsigned long long)B.prio_board;
     const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bp >> 32));  // (the builtin returns int:
     const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)bp);          //  no sign extension, please)
     const unsigned long long bps = ((unsigned long long)bhi << 32) | blo;
-    asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bw) : "s"(bps) : "memory");
+    asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(bw) : "s"(bps) : "memory");
     unsigned behind = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)  // launch ranks 0..7 (occupancy never exceeds 8 workgroups per CU here)
+    for (int k = 0; k < PRIO_BOARD_SLOTS; ++k)  // every rank of the board: the launches of one round share it (ranks offset per launch)
         behind += (k != B.prio_rank && bw[k] != 0u && bw[k] < mine) ? 1u : 0u;
     sxg_set_prio(min(__builtin_amdgcn_readfirstlane(behind), 3u));
 }

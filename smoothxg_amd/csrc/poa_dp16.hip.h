@@ -102,7 +102,11 @@ __device__ __forceinline__ int band_first_strip(const int hint_col, const int W,
 // (out of line, views by value: inlined into the persistent kernel the sweep shared ~100 SGPRs with the
 // kernel's own state and reloaded its loop-invariant scalars from VGPR lanes -- v_readlane + hazard nops --
 // all over the row loop)
-template <int W, bool CVX, bool SW>
+// EXP (development, profiles/tools/cost_map.sh): bits switch parts of the row OFF in a sweep whose results are thrown away
+// (the kernel runs it in front of the real one), so that the difference between two builds prices a part of the row:
+// 1 = no band stores, 2 = no ring stores, 4 = no end-cell bookkeeping, 8 = no carry scans, 16 = no mailbox exchange,
+// 32 = every row takes the register-predecessor path (no fetch, no fold), 64 = no pass 2, 128 = no pass 1.
+template <int W, bool CVX, bool SW, int EXP = 0>
 __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R, const int N_,
                                              const uint8_t* seq, const int L_, const DpBuffers B,
                                              char* smem) {
@@ -327,7 +331,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         // Hleft the column left of the strip -- and pass 1 walks the strip right to left, so that column k's new value
         // can take the register of Hp[k] (dead once column k+1 has used it): the shifted copy Hc[k] = Hp[k-1] that an
         // ascending pass needs cost 11-23 v_mov per row.
-        if (np <= 1 && p0 == i - 1) {
+        if ((EXP & 32) || (np <= 1 && p0 == i - 1)) {
             // register predecessor: its outgoing candidates ARE this row's F and O
         } else if (sib) {
             u32x2 wr[W];
@@ -400,6 +404,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         unsigned sc4 = 0;
 #pragma unroll
         for (int k = W - 1; k >= 0; --k) {
+            if (EXP & 128) { Hc[k] = Fp[k]; continue; }
             // four scores per letter register in one table look-up; the odd bytes -- column k's pair, after a byte shift
             // column k+1's -- are sign-extended into a packed pair by a second permute.  (2 + 1/2 instructions and an
             // add per column; the compare-free form before -- xor, extract, min with 1, multiply-add, add m -- took 4 1/2)
@@ -431,12 +436,14 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         const int tWe = __mul24(tt, We), tWc = __mul24(tt, Wc);
         int ya_lo = pk_lo(a) - tWe, ya_hi = pk_hi(a) - tWe - 64 * We;
         int yb_lo = CVX ? pk_lo(b) - tWc : NEG, yb_hi = CVX ? pk_hi(b) - tWc - 64 * Wc : NEG;
+        if (!(EXP & 8)) {
         ya_lo = sxg_wave_incl_max(ya_lo); ya_hi = sxg_wave_incl_max(ya_hi);
         if (CVX) { yb_lo = sxg_wave_incl_max(yb_lo); yb_hi = sxg_wave_incl_max(yb_hi); }
+        }
         RP_MARK(1);  // pass 1 + in-wave scan
         // what crosses my left edge in this row: {E, Q entering my first column, H of the column left of it, row}
         int in_e = NEG * 2, in_q = NEG * 2, in_h = FLOORV;
-        if (wv > 0) {
+        if (wv > 0 && !(EXP & 16)) {
             i32x4 m = mb_in[i & (P16_MBOX - 1)];
             while (__builtin_amdgcn_readfirstlane(m.w) != i) { __builtin_amdgcn_s_sleep(2); m = mb_in[i & (P16_MBOX - 1)]; }
             in_e = __builtin_amdgcn_readfirstlane(m.x) + We;   // (as y of strip u = -1)
@@ -460,6 +467,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         int rowmax = SW ? 0 : NEG2;
 #pragma unroll
         for (int k = 0; k < W; ++k) {
+            if (EXP & 64) { rowmax = pk_max(rowmax, Hc[k] ^ E ^ Q); continue; }
             int h = pk_max(Hc[k], E);
             if (CVX) h = pk_max(h, Q);
             if (SW) h = pk_max(h, B2);
@@ -479,7 +487,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             if (lane == 0) lh = pk2(in_h, pk_lo(x63));
         }
         RP_MARK(3);  // carry combine + pass 2
-        if (wv + 1 < NW) {
+        if (wv + 1 < NW && !(EXP & 16)) {
             if ((i & (P16_MBOX / 2 - 1)) == 0)   // the slots of the next P16_MBOX / 2 rows: has my reader freed them?
                 while (__builtin_amdgcn_readfirstlane(prog[wv + 1]) < i - P16_MBOX / 2) __builtin_amdgcn_s_sleep(2);
             if (lane == 63) mb_out[i & (P16_MBOX - 1)] = i32x4{pk_hi(E), pk_hi(Q), pk_hi(xh), i};
@@ -487,7 +495,8 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         RP_MARK(4);  // waiting for the right neighbour's progress
 
         // ---- end cell bookkeeping
-        if (SW) {
+        if (EXP & 4) { best_lo ^= rowmax & 1; }
+        else if (SW) {
             const bool il = pk_lo(rowmax) > best_lo, ih = pk_hi(rowmax) > best_hi;
             if (__any(il || ih)) {  // wave-uniform: only the waves the best diagonal runs through
                 if (il) { best_lo = pk_lo(rowmax); bi_lo = i; }
@@ -518,9 +527,9 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         // hi strips 64 further on.  (wave-uniform tests; the lane test is ONE exec mask around all W stores)
         const int bs0 = band_first_strip(hint, W, BS, T);
         const int w0 = wv << 7;
-        const bool band_lo = (w0 + 63 >= bs0) && (w0 < bs0 + BS);
-        const bool band_hi = (w0 + 127 >= bs0) && (w0 + 64 < bs0 + BS);
-        const bool ring = (flags & ROW_STORE) != 0;
+        const bool band_lo = !(EXP & 1) && (w0 + 63 >= bs0) && (w0 < bs0 + BS);
+        const bool band_hi = !(EXP & 1) && (w0 + 127 >= bs0) && (w0 + 64 < bs0 + BS);
+        const bool ring = !(EXP & 2) && (flags & ROW_STORE) != 0;
         const __amdgpu_buffer_rsrc_t rs_ring = p16_rsrc((const void*)((SXG_GLOBAL const char*)g_pool + (size_t)(ring && myslot >= 0 ? myslot : 0) * (size_t)RB), RB);
         const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
         const bool in_lo = (unsigned)(w0 + tt - bs0) < (unsigned)BS, in_hi = (unsigned)(w0 + 64 + tt - bs0) < (unsigned)BS;

@@ -151,7 +151,8 @@ struct BlockArgs {
     int park_in_lds;
     int pf_off;  // byte offset of the LDS prefetch area, -1 = off
     int num_cu;  // compute units of the device (co-residency of workgroups, sxg_rotate_prio)
-    uint32_t* prio_board;              // [PRIO_BOARD_CUS][PRIO_BOARD_SLOTS] progress board, zeroed per launch
+    uint32_t* prio_board;              // [PRIO_BOARD_CUS][PRIO_BOARD_SLOTS] progress board, shared by the launches of a round
+    int prio_base;                     // first board rank of this launch (the launches before it took the ranks below)
     const unsigned long long* est;     // [n_work] estimated cells of work item wi (host cost model)
 };
 
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
     WgCtx ctx{(sxg_lds_int*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() + 128u * 4u)};
     const int t = threadIdx.x;
     SlotViews V = slot_views(A.arena + (size_t)blockIdx.x * A.lay.total, A.lay);
-    V.B.prio_rank = (int)(blockIdx.x / (unsigned)A.num_cu) & (PRIO_BOARD_SLOTS - 1);
+    V.B.prio_rank = (int)(blockIdx.x / (unsigned)A.num_cu + (unsigned)A.prio_base) & (PRIO_BOARD_SLOTS - 1);
     V.B.prio_board = A.prio_board ? A.prio_board + (size_t)(__smid() & (PRIO_BOARD_CUS - 1)) * PRIO_BOARD_SLOTS : nullptr;
     const RowCaps caps{A.lay.rows_cap, A.lay.pool_slots, A.lay.step_cap, A.lay.lds_rows};
     // the first item of a slot is fixed (work[blockIdx]: the host orders the list by where the slot will
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     // exist, so the traceback cannot leave the kept cells
                     V.B.band_w = band_half_width(len);
                     V.B.band_mode = band_mode;
-                    res = dp_fill_band16<CVX, W>(S, V.R, N, seq, len, V.B, smem, A.cells + s);
+                    res = dp_fill_band16<CVX, W, SW>(S, V.R, N, seq, len, V.B, smem, A.cells + s);
                     __syncthreads();
                     PROF(2);
                     if (t == 0) lds[TBM_FLAG] = 0;
@@ -258,6 +259,10 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     // more than half a band away from the backbone coordinates), the hints of the rows not yet
                     // walked are shifted onto the walk and this sequence's sweep is repeated.
                     for (int att = 0;; ++att) {
+#ifdef SXG_EXP
+                        // (development: a sweep with parts switched off in front of the real one -- see dp_fill_p16's EXP)
+                        if (att == 0) { res = dp_fill_p16<W, CVX, SW, SXG_EXP>(S, V.R, N, seq, len, V.B, smem); __syncthreads(); if (res.best == 0x7fffffff) break; }
+#endif
                         res = dp_fill_p16<W, CVX, SW>(S, V.R, N, seq, len, V.B, smem);
                         __syncthreads();
                         PROF(2);
@@ -603,9 +608,9 @@ template <int TMAX, int W, int RM> static KernelFn<AlignArgs> pick_align(bool cv
 // SXG_DEV_ONLY_W=<w>: development builds instantiate a single packed class (seconds instead of minutes)
 static KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
     if (v.RM == 3) {   // banded: the strip width is part of the semantics (decree B2), never merged or widened
-        if (v.W == 6) return cvx ? poa_block_kernel<64, 6, true, 3, true> : poa_block_kernel<64, 6, false, 3, true>;
-        if (v.W == 8) return cvx ? poa_block_kernel<64, 8, true, 3, true> : poa_block_kernel<64, 8, false, 3, true>;
-        return cvx ? poa_block_kernel<64, 11, true, 3, true> : poa_block_kernel<64, 11, false, 3, true>;
+        if (v.W == 6) return pick_block<64, 6, 3>(cvx, sw);
+        if (v.W == 8) return pick_block<64, 8, 3>(cvx, sw);
+        return pick_block<64, 11, 3>(cvx, sw);
     }
 #ifdef SXG_DEV_ONLY_W
     SXG_PICK16(pick_block, SXG_DEV_ONLY_TMAX, SXG_DEV_ONLY_W);
@@ -741,6 +746,7 @@ struct sxg_poa_handle {
     DevBuf d_status, d_nn, d_ne, d_nc, d_node_code, d_node_rank, d_node_group, d_edge_tail, d_edge_head, d_edge_w,
         d_paths, d_score, d_cells, d_cons, d_work, d_queue, d_arena;
     DevBuf d_tmp_a, d_tmp_b, d_tmp_c, d_tmp_d;
+    DevBuf d_board;   // the per-CU progress board (sxg_balance_prio) the launches of a round share
     // block graphs (want_block_graph): inputs, outputs in per-block layouts, the per-block counts of the last execute
     int want_block_graph = 0, bg_cons_visited_only = 0;
     bool bg_done = false;
@@ -805,7 +811,7 @@ static void release_all(sxg_poa_handle* h) {
     DevBuf* bufs[] = {&h->d_blk_off, &h->d_seq_off, &h->d_bases, &h->d_weights, &h->d_params, &h->d_status, &h->d_nn,
                       &h->d_ne, &h->d_nc, &h->d_node_code, &h->d_node_rank, &h->d_node_group, &h->d_edge_tail,
                       &h->d_edge_head, &h->d_edge_w, &h->d_paths, &h->d_score, &h->d_cells, &h->d_cons, &h->d_work,
-                      &h->d_queue, &h->d_arena, &h->d_tmp_a, &h->d_tmp_b, &h->d_tmp_c, &h->d_tmp_d, &h->d_trim, &h->d_bg_no, &h->d_bg_eo,
+                      &h->d_queue, &h->d_arena, &h->d_tmp_a, &h->d_tmp_b, &h->d_tmp_c, &h->d_tmp_d, &h->d_board, &h->d_trim, &h->d_bg_no, &h->d_bg_eo,
                       &h->d_bg_len, &h->d_bg_od, &h->d_bg_id, &h->d_bg_seq, &h->d_bg_eto, &h->d_bg_steps, &h->d_bg_nsteps, &h->d_bg_cons,
                       &h->d_bg_counts, &h->d_bg_work, &h->d_bg_queue, &h->d_bg_arena};
     for (DevBuf* b : bufs) b->release();
@@ -907,7 +913,10 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
         m.fits = variant_for_len(m.maxlen, m.rm, &m.variant, m.S.sw);
         // A11: the reference's abPOA path is banded (wb=311, wf=0.03); local alignments whose scores fit the packed
         // sweep run the one-wave banded kernel, everything else asked to be banded runs the full matrix
-        if (h->h_params[in->per_block_params ? b : 0].banded && m.S.sw && m.rm == 2 && m.maxlen <= SXG_POA_MAX_SEQ_LEN) {
+        // (global alignment: the adaptive band only -- the band of a row without successors holds the end column by
+        //  construction, a band around backbone coordinates need not)
+        const int bnd = h->h_params[in->per_block_params ? b : 0].banded;
+        if (bnd && (m.S.sw || bnd == 2) && m.rm == 2 && m.maxlen <= SXG_POA_MAX_SEQ_LEN) {
             m.rm = 3;
             m.variant = Variant{band_strip_width(m.maxlen), 1, 64, 3};   // decree B2: strip width from the block's longest sequence
             m.fits = true;
@@ -1062,7 +1071,7 @@ static int sample_clock(const LaunchPlan& P, const PlanRes& R) {
     return ticks ? (int)((double)cyc / (double)ticks * 100.0 + 0.5) : 0;
 }
 
-static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
+static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, const int prio_base) {
     const Variant V = P.variant;
     int rc;
     if (!P.kern) return fail(SXG_E_INVALID, "no kernel class built for this geometry");
@@ -1088,13 +1097,12 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
             std::copy(first.begin(), first.end(), P.work.begin());
         }
     }
-    const size_t board_bytes = (size_t)PRIO_BOARD_CUS * PRIO_BOARD_SLOTS * 4;
-    if ((rc = R.work.ensure(4 * P.work.size())) || (rc = R.queue.ensure(256 + board_bytes)) || (rc = R.est.ensure(8 * P.work.size()))) return rc;
+    if ((rc = R.work.ensure(4 * P.work.size())) || (rc = R.queue.ensure(256)) || (rc = R.est.ensure(8 * P.work.size()))) return rc;
     HIPCHK(hipMemcpyAsync(R.work.p, P.work.data(), 4 * P.work.size(), hipMemcpyHostToDevice, R.stream));
     P.est.resize(P.work.size());
     for (size_t k = 0; k < P.work.size(); ++k) P.est[k] = (unsigned long long)std::max(h->meta[P.work[k]].cost, 1.0);
     HIPCHK(hipMemcpyAsync(R.est.p, P.est.data(), 8 * P.est.size(), hipMemcpyHostToDevice, R.stream));
-    HIPCHK(hipMemsetAsync(R.queue.p, 0, 256 + board_bytes, R.stream));
+    HIPCHK(hipMemsetAsync(R.queue.p, 0, 256, R.stream));
     BlockArgs A;
     A.blk_off = h->d_blk_off.as<int32_t>(); A.seq_off = h->d_seq_off.as<int64_t>(); A.bases = h->d_bases.as<uint8_t>();
     A.weights = h->has_weights ? h->d_weights.as<uint32_t>() : nullptr;
@@ -1111,7 +1119,11 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R) {
     A.park_in_lds = P.park_lds ? 1 : 0;
     A.pf_off = P.pf_off;
     A.num_cu = std::max(h->num_cu, 1);
-    A.prio_board = getenv("SXG_POA_NO_BALANCE") ? nullptr : (uint32_t*)(R.queue.as<uint8_t>() + 256);
+    // One board for all launches of the round: workgroups of different geometries share CUs, and each takes as priority
+    // the number of co-residents -- of ANY launch -- with less work left.  (Round 3 kept a board per launch: two launches
+    // side by side were balanced pair by pair and lost more than their narrower geometry saved.)
+    A.prio_board = getenv("SXG_POA_NO_BALANCE") ? nullptr : h->d_board.as<uint32_t>();
+    A.prio_base = prio_base;
     A.est = R.est.as<unsigned long long>();
     // every slot's header (counters, phase times, clock readings) starts a launch at zero: one strided memset
     HIPCHK(hipMemset2DAsync(R.arena.as<uint8_t>() + P.lay.hdr, P.lay.total, 0, 512, (size_t)P.n_slots, R.stream));
@@ -1308,7 +1320,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         // a geometry with at least 75 % of the columns of a wider one of the same kind joins it: fewer,
         // fuller launches beat many partial ones, but every joined block sweeps the wider geometry's columns
         // (measured on the mixed batch, round 2 with over-subscribed launches: 0.60 39.6 s, 0.75 33.8 s, 0.90 34.3 s)
-        const double merge_ratio = getenv("SXG_POA_MERGE") ? atof(getenv("SXG_POA_MERGE")) : 0.75;
+        const double merge_ratio = getenv("SXG_POA_MERGE") ? atof(getenv("SXG_POA_MERGE")) : 0.92;
         for (size_t i = 0; i < plans.size(); ++i)
             for (size_t j = i + 1; j < plans.size();) {
                 const LaunchPlan &a = plans[i], &b = plans[j];
@@ -1403,10 +1415,18 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         }
         for (size_t i = 0; i < plans.size(); ++i) plans[i].n_slots = slots_at(i, lambda);
         lap("plan");
+        {
+            const size_t board_bytes = (size_t)PRIO_BOARD_CUS * PRIO_BOARD_SLOTS * 4;
+            int rcb = h->d_board.ensure(board_bytes);
+            if (rcb) return rcb;
+            HIPCHK(hipMemsetAsync(h->d_board.p, 0, board_bytes, h->stream));
+        }
         HIPCHK(hipEventRecord(h->ev0, h->stream));
+        int prio_base = 0;
         for (size_t i = 0; i < plans.size(); ++i) {
-            int rc = launch_plan(h, plans[i], *h->planres[i]);
+            int rc = launch_plan(h, plans[i], *h->planres[i], prio_base);
             if (rc) return rc;
+            prio_base += (int)((plans[i].n_slots + h->num_cu - 1) / std::max(h->num_cu, 1));
         }
         HIPCHK(hipEventRecord(h->ev1, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));

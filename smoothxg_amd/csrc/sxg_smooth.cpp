@@ -691,7 +691,9 @@ sxg_poa_params poa_params(const sxg_smooth_params& p) {  // src/smooth.cpp:2098-
         q.g = (int8_t)-(o1 + e1); q.e = (int8_t)-e1;
         if (o2 == 0) { q.q = q.g; q.c = q.e; } else { q.q = (int8_t)-(o2 + e2); q.c = (int8_t)-e2; }
     }
-    q.banded = 2;
+    // the band: always for global alignment; for local alignment unless the caller says that upstream abPOA runs its
+    // local mode without one (sxg_smooth_params::abpoa_band_local, include/sxg_smooth.h)
+    q.banded = (p.local_alignment && !p.abpoa_band_local) ? 0 : 2;
     return q;
 }
 // ---------------------------------------------------------------------------------------------

@@ -74,14 +74,56 @@ def test_config3_shape_banded_full_block(engine):
     assert w == 461
 
 
-def test_global_alignment_ignores_the_band_flag(engine):
+def test_global_alignment_static_band_flag_runs_the_full_matrix(engine):
+    """The STATIC band is for local mode only (its band need not hold the end column of a global alignment): global +
+    banded = 1 runs the full matrix, in the oracle and on the device."""
     rng = np.random.default_rng(63)
     seqs = random_block(rng, 4, 800, div=0.03)
     m, n, g, e, q, c = PARAM_SETS["convex_default"]
     res = engine.run_blocks([seqs], Params(m, n, g, e, q, c, 1, 1))[0]
     gg, sc, cells = O.block_run(seqs, None, O.mkparams(m, n, g, e, q, c, mode=1, banded=1))
-    assert_block_equal(res, gg, sc, cells, label="global+band flag")
+    assert_block_equal(res, gg, sc, cells, label="global+static band flag")
     assert engine.stats()["dom_row_mode"] != 3
+
+
+@pytest.mark.parametrize("pname", ["convex_default", "affine_4param", "linear"])
+def test_global_alignment_with_the_adaptive_band(engine, pname):
+    """smooth_abpoa sets abPOA's band for BOTH alignment modes (src/smooth.cpp:259-271): global alignment (-Z) with the
+    adaptive band (banded = 2, decree B4) on the one-wave kernel -- nothing clamped at 0, the virtual row's gap costs,
+    end cell = column L of a sink row -- against the oracle: scores, graphs, paths, consensus, band cells.  Blocks of
+    several shapes incl. structural variants and deep bubbles; all inside the packed range (a global alignment whose
+    scores leave int16 runs the full matrix, see the last assertion)."""
+    rng = np.random.default_rng(64)
+    # (linear gaps cost 5 per base here: the int16 range ends near 1.4 kbp)
+    lens, alen = ((40, 300, 900, 1500, 2400), 2200) if pname != "linear" else ((40, 300, 700, 1100), 1100)
+    blocks = [random_block(rng, int(rng.integers(3, 9)), L, div=0.04) for L in lens]
+    blocks.append(random_block(rng, 20, 400, div=0.12))
+    anc = rng.integers(0, 4, alen, dtype=np.uint8)
+    ins = rng.integers(0, 4, 280, dtype=np.uint8)
+    a3 = alen // 3
+    blocks.append([np.concatenate([anc[:a3], ins, anc[a3:]]), anc.copy(), np.concatenate([anc[:a3 - 200], anc[a3 + 50:]]),
+                   np.concatenate([anc[:2 * a3], ins[:150], anc[2 * a3:]])])
+    if pname != "linear":
+        big_ins = rng.integers(0, 4, 600, dtype=np.uint8)   # an insertion beyond the band's half-width, shared by two sequences
+        blocks.append([np.concatenate([anc[:900], big_ins, anc[900:]]), anc.copy(), np.concatenate([anc[:900], big_ins, anc[900:]]), anc.copy()])
+    m, n, g, e, q, c = PARAM_SETS[pname]
+    gp, op = Params(m, n, g, e, q, c, 1, 2), O.mkparams(m, n, g, e, q, c, mode=1, banded=2)
+    res = engine.run_blocks(blocks, gp, want_consensus=True)
+    st = engine.stats()
+    assert st["dom_row_mode"] == 3 and st["dom_threads"] == 64
+    for b, seqs in enumerate(blocks):
+        gg, sc, cells = O.block_run(seqs, None, op)
+        assert_block_equal(res[b], gg, sc, cells, label=f"global-adaptive/{pname}/block{b}")
+        assert (res[b].consensus == gg.consensus()).all()
+        if len(seqs[0]) > 2000:
+            full = O.block_run(seqs, None, O.mkparams(m, n, g, e, q, c, mode=1, banded=0))
+            assert int(res[b].cells.sum()) < 0.8 * int(full[2].sum())
+    # beyond the packed range (affine global at 6 kbp): the block takes the widening ladder and runs the full matrix
+    long_seqs = random_block(rng, 3, 6000, div=0.02)
+    r = engine.run_blocks([long_seqs], Params(1, -4, -8, -2, -8, -2, 1, 2))[0]
+    assert r.status == 0 and engine.stats()["dom_row_mode"] != 3
+    gf, sf, cf = O.block_run(long_seqs, None, O.mkparams(1, -4, -8, -2, -8, -2, mode=1, banded=0))
+    assert (r.scores == sf).all()
 
 
 def test_banded_beyond_12_kbp(engine):

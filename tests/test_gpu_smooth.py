@@ -141,6 +141,26 @@ def test_drb1_abpoa_path_on_gpu(engine, cons):
         assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
 
 
+def test_drb1_abpoa_path_global_and_unbanded_local_on_gpu(engine):
+    """-A -Z: the smooth_abpoa path with GLOBAL alignment runs the adaptive band too (src/smooth.cpp:259-271 sets wb / wf for
+    both modes).  -A with abpoa_band_local = 0: the reading in which upstream abPOA switches its band off in local mode --
+    abPOA's scores on the full matrix.  Both equal the oracle stack byte for byte."""
+    text = open(DRB1).read()
+    g = SO.Graph(text)
+    blocks = SO.break_blocks(g, SO.smoothable_blocks(g, 900 * 12, 900, 5000, 5000), 1800)
+    sm = S.Smoother(text, discover=dict(target_poa_length=900, n_haps=12, max_path_jump=5000, max_edge_jump=5000))
+    got = sm.smooth_gfa(S.default_params(use_abpoa=1, local_alignment=0), S.gpu_provider(engine))
+    assert engine.stats()["dom_row_mode"] == 3
+    assert got == SO.smooth(g, blocks, abpoa=True, local=False)
+    out = SO.Graph(got)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+    got = sm.smooth_gfa(S.default_params(use_abpoa=1, abpoa_band_local=0), S.gpu_provider(engine))
+    assert engine.stats()["dom_row_mode"] != 3
+    assert got == SO.smooth(g, blocks, abpoa=True, band_local=False)
+    sm.close()
+
+
 def test_drb1_three_chained_iterations_as_the_reference_ctest_runs_them(engine):
     """The reference's own test configuration (CMakeLists.txt:565: -l 700,900,1100 -j 5k -e 5k -r 12) is THREE smoothing
     iterations, each on the graph the one before wrote (src/main.cpp:374-1065); consensus paths only in the last

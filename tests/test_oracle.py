@@ -343,7 +343,7 @@ def test_banded_decrees_static_and_adaptive(oracle):
     and graph at a fraction of its cells.  (b) A 700-base insertion shared by two of four sequences (beyond
     w = 311 + 0.03 L) carries the alignment off the backbone: the STATIC band (B2) loses it, the ADAPTIVE band (B4, abPOA's
     rule: the band follows the best cells of the predecessor rows) keeps the full matrix's scores.  (c) remain() -- the
-    walk along heaviest out-edges -- of a chain graph counts down to 0; global mode ignores the flag."""
+    walk along heaviest out-edges -- of a chain graph counts down to 0."""
     from helpers import random_block
     rng = np.random.default_rng(81)
     calm = random_block(rng, 5, 1500, div=0.02)
@@ -362,5 +362,11 @@ def test_banded_decrees_static_and_adaptive(oracle):
     assert int(adaptive[2].sum()) < 0.5 * sum(len(s) for s in wild[1:]) * adaptive[0].n_nodes
     chain = oracle.block_run([anc[:50]], None, oracle.mkparams())[0]
     assert (chain.row_remain() == np.arange(49, -1, -1)).all()
-    gl = [oracle.block_run(calm[:3], None, oracle.mkparams(mode=1, banded=b))[1] for b in (0, 1, 2)]
-    assert (gl[0] == gl[1]).all() and (gl[0] == gl[2]).all()
+    # (d) global mode: the static band is not applied (its band need not hold the end column); the adaptive band is (round 4,
+    # smooth_abpoa sets its band for both modes): full-matrix scores at a fraction of the cells on the calm block AND on the
+    # block with the 700-base insertion
+    glc = [oracle.block_run(calm[:3], None, oracle.mkparams(mode=1, banded=b)) for b in (0, 1, 2)]
+    assert (glc[0][1] == glc[1][1]).all() and int(glc[1][2].sum()) == int(glc[0][2].sum())
+    assert (glc[0][1] == glc[2][1]).all() and int(glc[2][2].sum()) < 0.6 * int(glc[0][2].sum())
+    glw = [oracle.block_run(wild, None, oracle.mkparams(mode=1, banded=b)) for b in (0, 2)]
+    assert (glw[0][1] == glw[1][1]).all() and int(glw[1][2].sum()) < 0.6 * int(glw[0][2].sum())

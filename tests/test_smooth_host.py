@@ -240,6 +240,27 @@ def test_abpoa_path_iteration_matches_restatement(prov, cons, scores):
         assert (e.g, e.e, e.q, e.c) == (-8, -2, -8, -2)
 
 
+def test_abpoa_band_in_global_mode_and_the_local_mode_switch(prov):
+    """smooth_abpoa sets its band for both alignment modes (src/smooth.cpp:259-271): -A -Z hands the provider banded = 2 with
+    mode = 1, and the oracle honours the adaptive band in global mode.  abpoa_band_local = 0 (upstream abPOA may run local
+    mode unbanded): abPOA's scores, banded = 0.  C++ == Python restatement in both."""
+    text = haplotype_gfa(21, n_paths=5, length=1000)
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 350)
+    blocks = SO.blockset_by_path_windows(g, 350)
+    got = sm.smooth_gfa(S.default_params(use_abpoa=1, local_alignment=0, add_consensus=1), prov.provider())
+    assert got == SO.smooth(g, blocks, add_consensus=True, abpoa=True, local=False)
+    e = SO.engine_params(1, 4, 6, 2, 26, 1, False, True)
+    assert e.banded == 2 and e.mode == 1
+    got = sm.smooth_gfa(S.default_params(use_abpoa=1, abpoa_band_local=0), prov.provider())
+    assert got == SO.smooth(g, blocks, abpoa=True, band_local=False)
+    e = SO.engine_params(1, 4, 6, 2, 26, 1, True, True, band_local=False)
+    assert e.banded == 0 and (e.g, e.q) == (-8, -27)
+    e = SO.engine_params(1, 4, 6, 2, 26, 1, False, True, band_local=False)
+    assert e.banded == 2                              # global alignment is banded either way
+    sm.close()
+
+
 def test_drb1_fixture_round_trip(prov):
     """The reference's own test input (CMakeLists.txt:562-567 runs the CLI on it and checks the exit
     code): one smoothing iteration must preserve all 12 paths and agree with the oracle."""
