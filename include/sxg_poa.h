@@ -52,6 +52,12 @@ extern "C" {
 
 #define SXG_MODE_LOCAL 0  /* spoa::AlignmentType::kSW */
 #define SXG_MODE_GLOBAL 1 /* spoa::AlignmentType::kNW */
+/* OR-ed into sxg_poa_params::mode: after every AddAlignment the block's graph is re-sorted depth-first the way spoa's
+ * Graph::TopologicalSort is BELIEVED to do it (node-id order, in-edge tails first, aligned nodes together; restated from
+ * memory -- the library is absent from the reference snapshot -- as decree S7' of oracle/poa_oracle.c) instead of being kept
+ * in order incrementally (decree S7, the default).  Both are valid POA orders; they differ in how ties between equally good
+ * alignments fall.  One lane per block walks the graph: measured cost in DESIGN.md section 5. */
+#define SXG_ORDER_SPOA 0x10
 
 /* return codes */
 #define SXG_OK 0

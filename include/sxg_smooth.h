@@ -66,6 +66,11 @@ typedef struct sxg_smooth_params {
                                                          off in local mode (abpoa_post_set_para; unverifiable here, the library is
                                                          absent from the snapshot), in which case this is what -A without -Z runs.
                                                          Global alignment (-Z) is banded either way. */
+    int32_t poa_spoa_order;                           /* 1 = the engine re-sorts a block's graph after every alignment the way
+                                                         spoa's TopologicalSort is believed to (SXG_ORDER_SPOA, include/sxg_poa.h:
+                                                         decree S7', restated from memory, unverified) instead of keeping it in
+                                                         order incrementally (decree S7); one lane per block does it, see
+                                                         DESIGN.md for the price.  Default 0. */
 } sxg_smooth_params;
 
 void sxg_smooth_default_params(sxg_smooth_params *p);

@@ -99,6 +99,7 @@ struct poa_graph {
     int32_t *order;  /* rank -> node */
     int32_t *leader; /* node -> first node of its aligned group */
     int32_t *xpos;   /* node -> backbone coordinate (B2) */
+    int32_t *via;    /* node -> the node it was created aligned to (-1: created unaligned): fixes spoa's aligned-node list order (S7') */
     int32_t *gmem;   /* [leader*5 + code] -> node | -1 (valid at leader rows) */
     int32_t *in_head, *in_tail, *out_head, *out_tail, *in_deg, *out_deg;
     int n_edges, cap_edges;
@@ -123,7 +124,7 @@ poa_graph_t *poa_graph_new(void) {
 }
 void poa_graph_free(poa_graph_t *g) {
     if (!g) return;
-    free(g->code); free(g->rank); free(g->order); free(g->leader); free(g->gmem); free(g->xpos);
+    free(g->code); free(g->rank); free(g->order); free(g->leader); free(g->gmem); free(g->xpos); free(g->via);
     free(g->in_head); free(g->in_tail); free(g->out_head); free(g->out_tail);
     free(g->in_deg); free(g->out_deg);
     free(g->e_tail); free(g->e_head); free(g->e_next_in); free(g->e_next_out); free(g->e_w);
@@ -140,7 +141,7 @@ static void reserve_nodes(poa_graph_t *g, int n) {
     while (c < n) c *= 2;
     g->code = (uint8_t *)xrealloc(g->code, c);
 #define RS(f) g->f = (int32_t *)xrealloc(g->f, sizeof(int32_t) * (size_t)c)
-    RS(rank); RS(order); RS(leader); RS(xpos); RS(in_head); RS(in_tail); RS(out_head); RS(out_tail);
+    RS(rank); RS(order); RS(leader); RS(xpos); RS(via); RS(in_head); RS(in_tail); RS(out_head); RS(out_tail);
     RS(in_deg); RS(out_deg);
 #undef RS
     g->gmem = (int32_t *)xrealloc(g->gmem, sizeof(int32_t) * 5 * (size_t)c);
@@ -163,6 +164,7 @@ static int new_node(poa_graph_t *g, uint8_t code) {
     g->code[v] = code;
     g->rank[v] = -1;
     g->xpos[v] = 0;
+    g->via[v] = -1;
     g->leader[v] = v;
     for (int c = 0; c < 5; ++c) g->gmem[5 * v + c] = -1;
     g->gmem[5 * v + code] = v;
@@ -195,7 +197,7 @@ typedef struct {
 static norm_params_t normalise(const poa_params_t *p) {
     norm_params_t r;
     r.m = p->m; r.n = p->n; r.g = p->g; r.e = p->e; r.q = p->q; r.c = p->c;
-    r.sw = (p->mode == POA_MODE_SW);
+    r.sw = ((p->mode & 1) == POA_MODE_SW);
     if (r.g >= r.e) { r.e = r.g; r.q = r.g; r.c = r.g; }            /* linear  */
     else if (r.g <= r.q || r.e >= r.c) { r.q = r.g; r.c = r.e; }    /* affine  */
     return r;                                                        /* convex  */
@@ -491,7 +493,7 @@ int poa_align_ws(poa_ws_t *ws, const poa_graph_t *g, const uint8_t *seq, int len
     int32_t *row_node = (int32_t *)ws_get(ws, WS_ROWNODE, sizeof(int32_t) * (size_t)N);
     poa_graph_rows(g, codes, off, pred, sink, row_node);
     int n = -1;
-    const int banded = p->banded && (p->mode == POA_MODE_SW || band_is_adaptive(p->banded));   /* global: the adaptive band only */
+    const int banded = p->banded && ((p->mode & 1) == POA_MODE_SW || band_is_adaptive(p->banded));   /* global: the adaptive band only */
     if (ws->impl == POA_IMPL_AVX2 && !banded) {   /* (-1: no AVX2 on this host, or the scores leave int16: scalar path) */
         if (!ws->simd) ws->simd = poa_simd_ws_new();
         n = poa_align_rows_simd(ws->simd, N, codes, off, pred, sink, row_node, seq, len, p, out_node, out_pos, score);
@@ -557,6 +559,7 @@ void poa_add_alignment(poa_graph_t *g, const int32_t *aln_node, const int32_t *a
                 g->leader[v] = ld;
                 g->gmem[5 * ld + c] = v;
                 g->xpos[v] = g->xpos[a];
+                g->via[v] = a;
                 target[i] = v; kind[i] = 1;
             }
         } else { target[i] = new_node(g, c); kind[i] = 2; }
@@ -613,6 +616,69 @@ void poa_add_alignment(poa_graph_t *g, const int32_t *aln_node, const int32_t *a
     g->seq_off[++g->n_seqs] = base + len;
     free(posnode); free(target); free(kind);
 }
+
+/* S7' -- spoa's topological order, AS RECOLLECTED (rvaser/spoa Graph::TopologicalSort is absent from the reference snapshot:
+ * UNVERIFIED, offered as an option so that the one known divergence of S7 can be switched off and priced):
+ *   for every node in id order, depth-first with an explicit stack: a node on top of the stack pushes the tails of its
+ *   in-edges that are not done (in-edge insertion order) and -- unless it was itself pushed as somebody's aligned node
+ *   ("ignored") -- its aligned nodes that are not done (marking them ignored); when nothing had to be pushed it is done,
+ *   and unless ignored it is emitted, followed by its aligned nodes in the order of ITS aligned-node list.
+ * A node's aligned-node list follows spoa's AddAlignment: a node created aligned to x starts with x's list followed by x,
+ * and is appended to the list of every member the group already had.  Groups stay contiguous, so S8 applies unchanged. */
+static int aligned_list(const poa_graph_t *g, int v, int *out) {
+    int mem[5], nm = 0;
+    const int ld = g->leader[v];
+    for (int c = 0; c < 5; ++c) if (g->gmem[5 * ld + c] >= 0) mem[nm++] = g->gmem[5 * ld + c];
+    for (int a = 1; a < nm; ++a) { int x = mem[a], b = a; while (b > 0 && mem[b - 1] > x) { mem[b] = mem[b - 1]; --b; } mem[b] = x; }   /* creation order */
+    int list[5][5], ln[5];
+    for (int k = 0; k < nm; ++k) {
+        ln[k] = 0;
+        int xi = -1;
+        for (int j = 0; j < k; ++j) if (mem[j] == g->via[mem[k]]) xi = j;
+        if (k > 0 && xi < 0) xi = 0;   /* (cannot happen: a member is created aligned to an earlier member) */
+        if (xi >= 0) { for (int q = 0; q < ln[xi]; ++q) list[k][ln[k]++] = list[xi][q]; list[k][ln[k]++] = mem[xi]; }
+        for (int j = 0; j < k; ++j) list[j][ln[j]++] = mem[k];
+    }
+    for (int k = 0; k < nm; ++k) if (mem[k] == v) { for (int q = 0; q < ln[k]; ++q) out[q] = list[k][q]; return ln[k]; }
+    return 0;
+}
+static void spoa_resort(poa_graph_t *g) {
+    const int n = g->n_nodes;
+    uint8_t *marks = (uint8_t *)calloc((size_t)n + 1, 1), *ignored = (uint8_t *)calloc((size_t)n + 1, 1);
+    int32_t *stack = (int32_t *)malloc(sizeof(int32_t) * ((size_t)g->n_edges + 6 * (size_t)n + 8));
+    int w = 0;
+    for (int s0 = 0; s0 < n; ++s0) {
+        if (marks[s0] != 0) continue;
+        int sp = 0;
+        stack[sp++] = s0;
+        while (sp > 0) {
+            const int curr = stack[sp - 1];
+            int valid = 1;
+            if (marks[curr] != 2) {
+                for (int e = g->in_head[curr]; e >= 0; e = g->e_next_in[e])
+                    if (marks[g->e_tail[e]] != 2) { stack[sp++] = g->e_tail[e]; valid = 0; }
+                int al[5], na = 0;
+                if (!ignored[curr]) {
+                    na = aligned_list(g, curr, al);
+                    for (int q = 0; q < na; ++q)
+                        if (marks[al[q]] != 2) { stack[sp++] = al[q]; ignored[al[q]] = 1; valid = 0; }
+                }
+                if (valid) {
+                    marks[curr] = 2;
+                    if (!ignored[curr]) {
+                        g->order[w++] = curr;
+                        for (int q = 0; q < na; ++q) g->order[w++] = al[q];
+                    }
+                } else marks[curr] = 1;
+            }
+            if (valid) --sp;
+        }
+    }
+    if (w != n) { fprintf(stderr, "poa_oracle: spoa_resort emitted %d of %d nodes\n", w, n); abort(); }
+    for (int r = 0; r < n; ++r) g->rank[g->order[r]] = r;
+    free(marks); free(ignored); free(stack);
+}
+void poa_graph_spoa_resort(poa_graph_t *g) { spoa_resort(g); }
 
 void poa_graph_nodes(const poa_graph_t *g, uint8_t *code, int32_t *rank, int32_t *group) {
     for (int v = 0; v < g->n_nodes; ++v) {
@@ -754,7 +820,7 @@ poa_graph_t *poa_block_run_ws(poa_ws_t *ws, const uint8_t *bases, const int32_t 
     int32_t *an = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
     int32_t *ap = (int32_t *)malloc(sizeof(int32_t) * (size_t)maxpairs);
     poa_params_t pb = *p;   /* B2: one strip width for all alignments of the block, from its longest sequence */
-    if (pb.banded && (pb.mode == POA_MODE_SW || band_is_adaptive(pb.banded)))
+    if (pb.banded && ((pb.mode & 1) == POA_MODE_SW || band_is_adaptive(pb.banded)))
         pb.banded = (uint8_t)((band_is_adaptive(pb.banded) ? 0x80 : 0) | poa_band_strip_width((long)maxlen));
     for (int s = 0; s < n_seqs; ++s) {
         const uint8_t *seq = bases + seq_off[s];
@@ -765,6 +831,7 @@ poa_graph_t *poa_block_run_ws(poa_ws_t *ws, const uint8_t *bases, const int32_t 
         if (scores) scores[s] = sc;
         if (cells) cells[s] = cl;
         poa_add_alignment(g, an, ap, n, seq, len, weights ? weights[s] : 1);
+        if (pb.mode & POA_ORDER_SPOA) spoa_resort(g);   /* S7' */
     }
     free(an); free(ap);
     return g;

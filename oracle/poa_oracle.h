@@ -33,6 +33,8 @@ extern "C" {
 
 #define POA_MODE_SW 0 /* local; smoothxg default (src/main.cpp:487) */
 #define POA_MODE_NW 1 /* global; smoothxg -Z */
+#define POA_ORDER_SPOA 0x10 /* OR-ed into mode: after every AddAlignment the graph is re-sorted depth-first the way spoa is
+                               BELIEVED to do it (decree S7', poa_oracle.c) instead of being kept in order incrementally (S7) */
 
 typedef struct {
     int8_t m, n, g, e, q, c; /* spoa sign convention: m>0 match, n<=0 mismatch, gaps <=0
@@ -104,6 +106,7 @@ int poa_align_csr_vtb(int n_rows, const uint8_t *codes, const int32_t *off, cons
                       int32_t *out_node, int32_t *out_pos, int32_t *score);
 
 /* Fuse an alignment into the graph (spoa Graph::AddAlignment semantics, see .c).       */
+void poa_graph_spoa_resort(poa_graph_t *g); /* S7': spoa's depth-first re-sort (as recollected, unverified) */
 void poa_add_alignment(poa_graph_t *g, const int32_t *aln_node, const int32_t *aln_pos,
                        int n_pairs, const uint8_t *seq, int len, uint32_t weight);
 

@@ -48,7 +48,7 @@ typedef struct { int m, n, g, e, q, c, sw, convex; } sp_t;
 static sp_t snormalise(const poa_params_t *p) {
     sp_t r;
     r.m = p->m; r.n = p->n; r.g = p->g; r.e = p->e; r.q = p->q; r.c = p->c;
-    r.sw = (p->mode == POA_MODE_SW); r.convex = 0;
+    r.sw = ((p->mode & 1) == POA_MODE_SW); r.convex = 0;
     if (r.g >= r.e) { r.e = r.g; r.q = r.g; r.c = r.g; }
     else if (r.g <= r.q || r.e >= r.c) { r.q = r.g; r.c = r.e; }
     else r.convex = 1;

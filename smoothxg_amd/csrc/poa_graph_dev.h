@@ -161,6 +161,7 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq_,
         G.in_deg[v] = G.out_deg[v] = 0;
         for (int x = 0; x < 5; ++x) G.gmem[5 * v + x] = -1;
         int slot;
+        G.via[v] = kind == 1 ? G.posnode[i] : -1;
         if (kind == 1) {
             const int ld = G.leader[G.posnode[i]];
             G.leader[v] = ld;
@@ -270,6 +271,73 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq_,
     c.sync();
     if (t == 0) { *G.n_nodes = n_old + n_new; *G.n_edges = e_old + n_newe; }
     c.sync();
+}
+
+// S7' -- spoa's topological order AS RECOLLECTED (rvaser/spoa Graph::TopologicalSort is absent from the reference snapshot:
+// unverified; an option -- sxg_poa_params::mode | SXG_ORDER_SPOA -- that switches the one known divergence of decree S7 off
+// so that it can be priced; restated in oracle/poa_oracle.c::spoa_resort, same text): for every node in id order, depth-first
+// with an explicit stack -- a node on top of the stack pushes the tails of its in-edges that are not done (insertion order)
+// and, unless it was itself pushed as somebody's aligned node ("ignored"), its aligned nodes that are not done (marking them
+// ignored); when nothing had to be pushed it is done and, unless ignored, emitted, followed by its aligned nodes in the
+// order of ITS aligned-node list.  That list follows spoa's AddAlignment: a node created aligned to x starts with x's list
+// followed by x, and is appended to the list of every member the group already had.
+// A chain of dependent loads over the whole graph: ONE lane runs it (the caller's thread 0), after add_alignment.
+SXG_HD int spoa_aligned_list(const GraphView& G, int v, int* out) {
+    int mem[5], nm = 0;
+    const int ld = G.leader[v];
+    for (int c = 0; c < 5; ++c) { const int x = G.gmem[5 * ld + c]; if (x >= 0) mem[nm++] = x; }
+    for (int a = 1; a < nm; ++a) { const int x = mem[a]; int b = a; while (b > 0 && mem[b - 1] > x) { mem[b] = mem[b - 1]; --b; } mem[b] = x; }   // creation order
+    int list[5][5], ln[5];
+    for (int k = 0; k < nm; ++k) {
+        ln[k] = 0;
+        int xi = -1;
+        const int via = G.via[mem[k]];
+        for (int j = 0; j < k; ++j) if (mem[j] == via) xi = j;
+        if (k > 0 && xi < 0) xi = 0;
+        if (xi >= 0) { for (int q = 0; q < ln[xi]; ++q) list[k][ln[k]++] = list[xi][q]; list[k][ln[k]++] = mem[xi]; }
+        for (int j = 0; j < k; ++j) list[j][ln[j]++] = mem[k];
+    }
+    for (int k = 0; k < nm; ++k)
+        if (mem[k] == v) { for (int q = 0; q < ln[k]; ++q) out[q] = list[k][q]; return ln[k]; }
+    return 0;
+}
+SXG_HD_PHASE void spoa_resort(const GraphView& G) {
+    const int n = *G.n_nodes;
+    SXG_GP uint8_t* const marks = G.dfs_marks;
+    SXG_GP uint8_t* const ignored = G.dfs_marks + (n + 1);
+    SXG_GP int32_t* const stack = G.dfs_stack;
+    for (int v = 0; v < 2 * (n + 1); ++v) marks[v] = 0;
+    int w = 0;
+    for (int s0 = 0; s0 < n; ++s0) {
+        if (marks[s0] != 0) continue;
+        int sp = 0;
+        stack[sp++] = s0;
+        while (sp > 0) {
+            const int curr = stack[sp - 1];
+            bool valid = true;
+            if (marks[curr] != 2) {
+                for (int e = G.in_head[curr]; e >= 0; e = G.e_next_in[e]) {
+                    const int tl = G.e_tail[e];
+                    if (marks[tl] != 2) { stack[sp++] = tl; valid = false; }
+                }
+                int al[5], na = 0;
+                if (!ignored[curr]) {
+                    na = spoa_aligned_list(G, curr, al);
+                    for (int q = 0; q < na; ++q)
+                        if (marks[al[q]] != 2) { stack[sp++] = al[q]; ignored[al[q]] = 1; valid = false; }
+                }
+                if (valid) {
+                    marks[curr] = 2;
+                    if (!ignored[curr]) {
+                        G.order[w++] = curr;
+                        for (int q = 0; q < na; ++q) G.order[w++] = al[q];
+                    }
+                } else marks[curr] = 1;
+            }
+            if (valid) --sp;
+        }
+    }
+    for (int r = 0; r < n; ++r) G.rank[G.order[r]] = r;
 }
 
 struct RowCaps {

@@ -80,6 +80,11 @@ struct GraphView {
     // sequence: its own position; later nodes inherit / interpolate from the nodes they were aligned
     // next to).  Centres the band of cells the packed sweep keeps for the traceback; never affects results.
     SXG_GP int32_t *xpos;
+    // S7' (spoa's depth-first re-sort, sxg_poa_params::mode | SXG_ORDER_SPOA): the node a node was created aligned to (-1:
+    // created unaligned) -- it fixes the order of spoa's aligned-node lists --, and the scratch of the re-sort
+    SXG_GP int32_t *via;
+    SXG_GP int32_t *dfs_stack;   // [n_edges + 6 n_nodes + 8]
+    SXG_GP uint8_t *dfs_marks;   // [2 (n_nodes + 1)]: marks, ignored
 };
 
 // Row structures of the current graph in rank space, rebuilt before every alignment.

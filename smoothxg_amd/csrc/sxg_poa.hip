@@ -36,7 +36,7 @@ using namespace sxg;
 struct SlotLayout {  // byte offsets inside one slot arena (all 16-byte aligned)
     size_t hdr, code, rank, order, order_tmp, leader, gmem, in_head, in_tail, out_head, out_tail, in_deg,
         out_deg, e_tail, e_head, e_next_in, e_next_out, e_w, posnode, target, newidx, nexta, preva, slotadd,
-        kind, xpos, r_code, r_flags, r_pred_off, r_preds, r_slot, r_tbx, r_sseq, r_row_node, r_meta, tb, steps, pool,
+        kind, xpos, via, dfs_stack, dfs_marks, r_code, r_flags, r_pred_off, r_preds, r_slot, r_tbx, r_sseq, r_row_node, r_meta, tb, steps, pool,
         row0, park, cons_sc, cons_pr, pair_row, pair_pos, total;
     int nodes_cap, rows_cap, pool_slots, step_cap, scratch_len, Lpad, word_bytes, threads;
     int band_strips;  // packed sweep: strips per row in the traceback plane (0 = not the packed sweep)
@@ -72,6 +72,7 @@ static SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int s
     L.posnode = lay(cur, 4 * S); L.target = lay(cur, 4 * S); L.newidx = lay(cur, 4 * S);
     L.nexta = lay(cur, 4 * S); L.preva = lay(cur, 4 * S); L.slotadd = lay(cur, 4 * S); L.kind = lay(cur, S);
     L.xpos = lay(cur, 4 * C);
+    L.via = lay(cur, 4 * C); L.dfs_stack = lay(cur, 4 * (7 * C + 8)); L.dfs_marks = lay(cur, 2 * C + 8);
     L.r_code = lay(cur, Rr); L.r_flags = lay(cur, Rr); L.r_pred_off = lay(cur, 4 * Rr);
     L.r_preds = lay(cur, 4 * C); L.r_slot = lay(cur, 4 * Rr); L.r_tbx = lay(cur, 4 * Rr);
     L.r_sseq = lay(cur, 4 * Rr); L.r_row_node = lay(cur, 4 * Rr); L.r_meta = lay(cur, 32 * Rr);
@@ -110,7 +111,7 @@ __device__ static SlotViews slot_views(uint8_t* base, const SlotLayout& L) {
     V.G.e_next_out = P32(e_next_out); V.G.e_w = (SXG_GP uint32_t*)(base + L.e_w);
     V.G.posnode = P32(posnode); V.G.target = P32(target); V.G.newidx = P32(newidx); V.G.nexta = P32(nexta);
     V.G.preva = P32(preva); V.G.slotadd = P32(slotadd); V.G.kind = (SXG_GP int8_t*)(base + L.kind);
-    V.G.xpos = P32(xpos);
+    V.G.xpos = P32(xpos); V.G.via = P32(via); V.G.dfs_stack = P32(dfs_stack); V.G.dfs_marks = (SXG_GP uint8_t*)(base + L.dfs_marks);
     V.R.code = (SXG_GP uint8_t*)(base + L.r_code); V.R.flags = (SXG_GP uint8_t*)(base + L.r_flags); V.R.pred_off = P32(r_pred_off);
     V.R.preds = P32(r_preds); V.R.slot = P32(r_slot); V.R.tbx = P32(r_tbx); V.R.sseq = P32(r_sseq);
     V.R.row_node = P32(r_row_node); V.R.meta = P32(r_meta);
@@ -126,7 +127,7 @@ __device__ static SlotViews slot_views(uint8_t* base, const SlotLayout& L) {
 __host__ __device__ static inline Scoring normalise(const sxg_poa_params& p) {
     Scoring S;
     S.m = p.m; S.n = p.n; S.g = p.g; S.e = p.e; S.q = p.q; S.c = p.c;
-    S.sw = p.mode == SXG_MODE_LOCAL;
+    S.sw = (p.mode & 1) == SXG_MODE_LOCAL;
     S.convex = 0;
     if (S.g >= S.e) { S.e = S.g; S.q = S.g; S.c = S.g; }
     else if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
@@ -296,6 +297,10 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             if (t == 0) { A.score[s] = score; if (RM != 3 || N == 0 || len == 0) A.cells[s] = RM == 3 ? 0ull : (unsigned long long)N * (unsigned long long)len; }
             done_cells += (unsigned long long)N * (unsigned long long)len;
             add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
+            if (A.params[A.per_block_params ? b : 0].mode & SXG_ORDER_SPOA) {   // S7': spoa's depth-first re-sort (one lane)
+                if (t == 0) spoa_resort(V.G);
+                __syncthreads();
+            }
             PROF(4);
         }
         PROF(0);
@@ -577,6 +582,8 @@ template <class Args> using KernelFn = void (*)(const Args);
 
 // On-chip copies of stored rows a packed-sweep workgroup gets (SlotLayout::lds_rows): what is left of its share of the CU's
 // 160 KB of LDS when as many workgroups share the CU as its registers allow (128 VGPRs: 16 waves per CU).
+// (Round 4: giving the workgroups of a launch that does not fill the chip -- 1000 two-wave blocks: four per CU where eight
+//  fit -- the LDS the absent ones leave, i.e. 8 on-chip rows instead of 2-3, was measured on c2: 59.6 ms against 57.4 ms.  Dropped.)
 static int p16_lds_rows(const int T, const int W) {
     if (const char* e = getenv("SXG_POA_LDS_ROWS")) return std::max(0, std::min(8, atoi(e)));
     const int wg_per_cu = std::max(1, 16 / std::max(T / 64, 1));
@@ -880,7 +887,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     const int np = in->per_block_params ? nb : 1;
     for (int k = 0; k < np && nb > 0; ++k) {
         const sxg_poa_params& p = in->params[k];
-        if (p.m < 0 || p.n > 0 || p.g > 0 || p.e > 0 || p.q > 0 || p.c > 0 || p.mode > 1 || p.banded > 2)
+        if (p.m < 0 || p.n > 0 || p.g > 0 || p.e > 0 || p.q > 0 || p.c > 0 || (p.mode & ~(1 | SXG_ORDER_SPOA)) != 0 || p.banded > 2)
             return fail(SXG_E_INVALID, "scores must follow spoa's sign convention (m>=0, others <=0), mode 0|1");
     }
     h->n_blocks = nb; h->n_seqs = ns; h->n_bases = nbases;
@@ -1320,12 +1327,16 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         // a geometry with at least 75 % of the columns of a wider one of the same kind joins it: fewer,
         // fuller launches beat many partial ones, but every joined block sweeps the wider geometry's columns
         // (measured on the mixed batch, round 2 with over-subscribed launches: 0.60 39.6 s, 0.75 33.8 s, 0.90 34.3 s)
-        const double merge_ratio = getenv("SXG_POA_MERGE") ? atof(getenv("SXG_POA_MERGE")) : 0.92;
+        // Round 4, with ONE priority board for all launches of a round: the headline's two geometries (5 120 and 5 632 columns)
+        // run 2.4 % faster apart than merged (2 137 -> 2 088 ms, same box) and the mixed batch 1.8 %; the small geometries of
+        // config 2 (three launches of 1-2 waves per block) still lose 15 % apart.  So: wide geometries merge only within 8 %,
+        // the others within 25 % as before.
+        const double merge_env = getenv("SXG_POA_MERGE") ? atof(getenv("SXG_POA_MERGE")) : 0.0;
         for (size_t i = 0; i < plans.size(); ++i)
             for (size_t j = i + 1; j < plans.size();) {
                 const LaunchPlan &a = plans[i], &b = plans[j];
                 if (a.variant.RM == b.variant.RM && a.variant.RM != 3 && a.cvx == b.cvx && a.sw == b.sw && a.tier == b.tier && a.wide_band == b.wide_band &&
-                    (double)b.variant.Lpad() >= merge_ratio * (double)a.variant.Lpad()) {
+                    (double)b.variant.Lpad() >= (merge_env > 0 ? merge_env : (a.variant.Lpad() >= 4096 ? 0.92 : 0.75)) * (double)a.variant.Lpad()) {
                     plans[i].work.insert(plans[i].work.end(), b.work.begin(), b.work.end());
                     plans.erase(plans.begin() + (long)j);
                 } else ++j;

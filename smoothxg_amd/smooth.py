@@ -21,7 +21,7 @@ class SmoothParams(C.Structure):
                 ("poa_padding_fraction", C.c_float), ("max_block_depth_for_padding_more", C.c_uint64),
                 ("add_consensus", C.c_int32), ("consensus_base_name", C.c_char_p),
                 ("adaptive_poa_params", C.c_int32), ("kmer_size", C.c_int32), ("use_abpoa", C.c_int32),
-                ("abpoa_band_local", C.c_int32)]
+                ("abpoa_band_local", C.c_int32), ("poa_spoa_order", C.c_int32)]
 
 
 EXPORTS = ["sxg_smooth_abi_version", "sxg_smooth_default_params", "sxg_smooth_last_error", "sxg_smooth_free", "sxg_graph_from_gfa",

@@ -437,3 +437,23 @@ def test_packed_sweep_handles_the_block_itself(engine, oracle, n_seqs, length):
         seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[b], blk_off[b + 1])]
         g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
         assert_block_equal(res[b], g, sc, cells, f"block {b}")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_spoa_order_option_on_the_device(engine, oracle, mode):
+    """sxg_poa_params::mode | SXG_ORDER_SPOA (decree S7': the depth-first re-sort after every AddAlignment that spoa is
+    believed to do; restated from memory, unverified): one lane per block re-sorts the graph on the device; scores,
+    graphs, ranks, paths, consensus and MSA equal the oracle run with the same option, on blocks of several shapes
+    (packed sweep, banded sweep, deep bubbles), and mixed with default-order blocks in one batch."""
+    import smoothxg_amd as S
+    rng = np.random.default_rng(900 + mode)
+    blocks = [random_block(rng, int(rng.integers(2, 12)), L, div=0.07) for L in (30, 200, 700, 1600)]
+    blocks.append(random_block(rng, 24, 300, div=0.12))
+    m, n, g, e, q, c = PARAM_SETS["convex_default"]
+    prm = [S.Params(m, n, g, e, q, c, mode | (0x10 if b != 1 else 0), 2 if (b == 3 and mode == 0) else 0) for b in range(len(blocks))]
+    res = engine.run_blocks(blocks, prm, want_consensus=True, want_msa=True)
+    for b, seqs in enumerate(blocks):
+        op = oracle.mkparams(m, n, g, e, q, c, mode=mode | (0x10 if b != 1 else 0), banded=2 if (b == 3 and mode == 0) else 0)
+        gg, sc, cells = oracle.block_run(seqs, None, op)
+        assert_block_equal(res[b], gg, sc, cells, f"spoa order, block {b}")
+        assert (res[b].consensus == gg.consensus()).all() and res[b].msa == gg.msa(True)

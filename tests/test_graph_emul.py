@@ -22,7 +22,7 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def run_emul(L, seqs, weights, params, pool=4096):
+def run_emul(L, seqs, weights, params, pool=4096, spoa_order=0):
     bases = np.concatenate(seqs).astype(np.uint8)
     off = np.zeros(len(seqs) + 1, np.int32)
     off[1:] = np.cumsum([len(s) for s in seqs])
@@ -39,7 +39,7 @@ def run_emul(L, seqs, weights, params, pool=4096):
     st = L.emul_block_run(_p(bases, C.c_uint8), _p(off, C.c_int32), len(seqs), _p(w, C.c_uint32), C.byref(params),
                           pool, _p(cnt, C.c_int32), _p(code, C.c_uint8), _p(rank, C.c_int32), _p(ld, C.c_int32),
                           _p(et, C.c_int32), _p(eh, C.c_int32), _p(ew, C.c_uint32), _p(paths, C.c_int32),
-                          _p(sc, C.c_int32), _p(cons, C.c_int32), _p(hints, C.c_int32), _p(remain, C.c_int32))
+                          _p(sc, C.c_int32), _p(cons, C.c_int32), _p(hints, C.c_int32), _p(remain, C.c_int32), spoa_order)
     n, e, nc = cnt
     return st, (code[:n], rank[:n], ld[:n], et[:e], eh[:e], ew[:e], paths[:off[-1]], sc, cons[:nc], hints[:n], remain[:n])
 
@@ -156,3 +156,38 @@ def test_block_graph_phase_matches_the_restatement(emul, oracle, cons_mode):
         for a, b in B.edges:
             ind[b] += 1
         assert (np.minimum(ind, 255) == B.node_indeg).all()
+
+
+def test_spoa_order_option_matches_its_restatement(emul, oracle):
+    """Decree S7' (sxg_poa_params::mode | SXG_ORDER_SPOA): the depth-first re-sort after every AddAlignment, restated from
+    memory of spoa's Graph::TopologicalSort (unverified: the library is absent) -- the product's one-lane walk
+    (poa_graph_dev.h::spoa_resort) against the oracle's (poa_oracle.c::spoa_resort): same ranks, hence same alignments,
+    graphs, paths, consensus.  Both give valid topological orders with contiguous aligned groups, and on divergent blocks
+    the order DIFFERS from the incremental one (S7)."""
+    rng = np.random.default_rng(77)
+    differs = 0
+    for mode in (0, 1):
+        p = oparams("convex_default", mode)
+        p.mode = mode | 0x10
+        for trial in range(20):
+            S = int(rng.integers(2, 14))
+            seqs = random_block(rng, S, int(rng.integers(5, 300)), div=0.09) if trial % 4 else \
+                [rng.integers(0, 5, int(rng.integers(1, 30)), dtype=np.uint8) for _ in range(S)]
+            w = rng.integers(1, 4, len(seqs))
+            g, sc, _ = oracle.block_run(seqs, w, p)
+            st, r = run_emul(emul, seqs, w, p, spoa_order=1)
+            assert st == 0
+            code, rank, grp = g.nodes()
+            t, h, ww = g.edges()
+            assert (r[0] == code).all() and (r[1] == rank).all() and (r[2] == grp).all()
+            assert (r[3] == t).all() and (r[4] == h).all() and (r[5] == ww).all()
+            assert (r[6] == np.concatenate([g.seq_path(s) for s in range(g.n_seqs)])).all()
+            assert (r[7] == sc).all() and (r[8] == g.consensus()).all()
+            assert (rank[t] < rank[h]).all()
+            by_rank = grp[np.argsort(rank)]
+            starts = np.flatnonzero(np.r_[True, by_rank[1:] != by_rank[:-1]])
+            assert len(set(by_rank[starts].tolist())) == len(starts)          # aligned groups are contiguous
+            g0 = oracle.block_run(seqs, w, oparams("convex_default", mode))[0]
+            if g0.n_nodes != g.n_nodes or not (g0.nodes()[1] == rank).all():
+                differs += 1
+    assert differs > 5

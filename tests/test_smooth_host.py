@@ -261,6 +261,22 @@ def test_abpoa_band_in_global_mode_and_the_local_mode_switch(prov):
     sm.close()
 
 
+def test_spoa_order_switch_reaches_the_engine(prov):
+    """poa_spoa_order = 1: the provider is handed mode | SXG_ORDER_SPOA (decree S7'); the iteration equals the restatement run
+    with the same switch, still preserves every path, and differs from the default order's output on a divergent graph."""
+    text = synthetic_gfa(5, n_paths=6, n_nodes=80)
+    g = SO.Graph(text)
+    sm = S.Smoother(text, 250)
+    blocks = SO.blockset_by_path_windows(g, 250)
+    got = sm.smooth_gfa(S.default_params(poa_spoa_order=1, add_consensus=1), prov.provider())
+    assert got == SO.smooth(g, blocks, add_consensus=True, spoa_order=True)
+    out = SO.Graph(got)
+    for q, nm in enumerate(g.pname):
+        assert out.path_sequence(out.pname.index(nm)) == g.path_sequence(q)
+    assert SO.engine_params(1, 4, 6, 2, 26, 1, True, False, spoa_order=True).mode == 0x10
+    sm.close()
+
+
 def test_drb1_fixture_round_trip(prov):
     """The reference's own test input (CMakeLists.txt:562-567 runs the CLI on it and checks the exit
     code): one smoothing iteration must preserve all 12 paths and agree with the oracle."""
