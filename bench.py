@@ -416,7 +416,11 @@ def main():
         k_s = kernel_ms / 1e3
         algo_gbs = (algo_bytes / 1e9) / k_s if k_s > 0 else 0.0
         pc = profile_counters("%s_%s" % (a.workload, a.mode))
-        launch_cells = cells / max(launches, 1)
+        # Round 4: a step may be SEVERAL launches side by side (the headline's two geometries are no longer merged into
+        # the wider one; the mixed batch always was several).  Everything "per launch" below is per STEP: all dispatches of
+        # one pass over the batch, timed by the HIP events around them (kernel_ms) -- the counters are collected the same way.
+        launch_cells = cells / max(a.steps, 1)
+        launches_per_step = launches / max(a.steps, 1)
         # the shader clock the dominant launch actually ran at (sampled by the engine from its slots: core-clock cycles per
         # 100 MHz wall tick); the boxes of the pool sustain 2.1-2.4 GHz under this kernel, the nominal value is the fallback
         clock_ghz = st["dom_clock_mhz"] / 1000.0 if st.get("dom_clock_mhz", 0) > 0 else VALU_CLOCK_GHZ
@@ -457,6 +461,18 @@ def main():
                 hbm.update({"counter_bytes_per_cell": bpc, "counter_GBps": bpc * cells / k_s / 1e9,
                             "counter_frac_of_peak": bpc * cells / k_s / 1e9 / HBM_PEAK_GBS,
                             "counter_correction": pc.get("correction")})
+        # The recurrence's own instruction count: convex local alignment, two-pass in-row scan, per
+        # packed column of a lane -- pass 1 8.5 (score look-up 1.5, diagonal add, max with F and O, two carry steps of add +
+        # max), pass 2 9 (max with E, Q and 0; E and Q updates of two adds + max), outgoing candidates 6, the wave scans
+        # 40 per row / W columns -- against the wave instructions executed per cell (a packed wave instruction touches
+        # 128 cells, so "instructions per cell" = wave instructions x 128 / cells, the unit of the counters above).
+        if pc and st["dom_row_mode"] == 2:
+            wl_w = max(st["dom_cols_per_lane"] // 2, 1)
+            min_ipc = 23.5 + 40.0 / wl_w
+            exe_ipc = valu["wave_insts_per_cell"] * 128.0
+            valu.update({"min_insts_per_cell": min_ipc, "executed_insts_per_cell": exe_ipc,
+                         "algorithmic_frac": (min_ipc / exe_ipc) * valu_frac if exe_ipc else None,
+                         "insts_per_cell_unit": "wave instructions x 128 cells / cells of the step"})
         valu_peak = simd_cycles_per_s
         out = {
             "metric": "POA blocks/sec (+ DP cells/sec) on 1000-block synthetic",
@@ -480,8 +496,10 @@ def main():
                          "kernel": "poa_block_kernel<T=%d, cols/lane=%d, %s>" % (
                              st["dom_threads"], st["dom_cols_per_lane"],
                              {2: "packed int16 sweep", 3: "banded packed int16 sweep (one wave, sliding window)"}.get(st["dom_row_mode"], "32-bit sweep")),
-                         "kernel_ms_per_launch": kernel_ms / max(launches, 1), "kernel_ms_total": kernel_ms,
-                         "algo_bytes_per_launch": algo_bytes / max(launches, 1),
+                         "kernel_ms_per_launch": kernel_ms / max(a.steps, 1), "kernel_ms_total": kernel_ms,
+                         "launches_per_step": launches_per_step,
+                         "per_launch_means": "per step: every dispatch of one pass over the batch (launches of different geometries run side by side)",
+                         "algo_bytes_per_launch": algo_bytes / max(a.steps, 1),
                          "bytes_per_cell": algo_bytes / max(cells, 1),
                          "valu": valu, "hbm": hbm},
             "engine": {"slots": st["n_slots"], "retries": st["retries"], "arena_bytes": st["device_bytes"]},

@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "gpurun_out")
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-rnd = args[0] if args else "r03"
+rnd = args[0] if args else "r04"
 counters_only = "--counters-only" in sys.argv
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -45,13 +45,25 @@ def counter_sum(path, name):
     return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "poa_block" in r["Kernel_Name"] and r["Counter_Name"] == name)
 
 
+def per_step(path, name):
+    """Counter `name` summed over EVERY poa_block dispatch of the run, per step.  Round 4: a step of the headline workload is two
+    launches side by side (strips of 10 and of 11 columns: the geometries are no longer merged), so 'per launch' means per
+    step -- all dispatches of one pass over the batch; steps = dispatches / distinct kernels."""
+    rows = [(r["Kernel_Name"], float(r["Counter_Value"])) for r in csv.DictReader(open(path)) if "poa_block" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    if not rows:
+        return None, 0
+    kernels = len(set(k for k, _ in rows))
+    steps = max(1, len(rows) // max(kernels, 1))
+    return sum(v for _, v in rows) / steps, steps
+
+
 stats = glob.glob(os.path.join(OUT, "prof_stats", "*kernel_stats.csv"))[0]
-row = [r for r in csv.DictReader(open(stats)) if "poa_block" in r["Name"]][0]
+stat_rows = [r for r in csv.DictReader(open(stats)) if "poa_block" in r["Name"]]
+row = max(stat_rows, key=lambda r: float(r["TotalDurationNs"]))   # the launch that runs longest (the others run beside it)
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.path.join(OUT, "prof_pmc_" + c, "*counter_collection.csv"))[0]
-    rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "poa_block" in r["Kernel_Name"] and r["Counter_Name"] == c]
-    vals[c] = sum(rows) / len(rows)   # per launch: mean over the run's launches (warm-up + timed)
+    vals[c], _ = per_step(f, c)
     shutil.copy(f, os.path.join(dst, "ns_sw_pmc_%s.csv" % c))
 shutil.copy(stats, os.path.join(dst, "ns_sw_kernel_stats.csv"))
 # every launch of the dominant kernel in the stats run (the first one is the warm-up: it first-touches the arenas)
@@ -63,6 +75,7 @@ traffic = {"ns_sw": {
     "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python bench.py --workload ns "
                "--steps 1 --warmup 1 --no-cpu-baseline --no-e2e (profiles/run_pmc.sh)",
     "kernel": row["Name"], "kernel_ms_avg_rocprof": float(row["AverageNs"]) / 1e6,
+    "kernels_of_a_step": {r["Name"]: float(r["AverageNs"]) / 1e6 for r in stat_rows},
     "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W, "correction": CORRECTION,
     "hbm_bytes_per_launch": (2 * F + W) * 1024, "hbm_bytes_per_launch_uncorrected": (F + W) * 1024}}
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
@@ -70,13 +83,10 @@ json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), in
 agg, cnt = {}, {}
 for d in sorted(glob.glob(os.path.join(OUT, "pmc16_*/"))):
     for f in glob.glob(d + "*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            if "poa_block" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]] = agg.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-                cnt[r["Counter_Name"]] = cnt.get(r["Counter_Name"], 0) + 1
-agg = {k: v / cnt[k] for k, v in agg.items()}   # per launch: mean over the run's launches
+        for name in sorted(set(r["Counter_Name"] for r in csv.DictReader(open(f)) if "poa_block" in r["Kernel_Name"])):
+            agg[name], cnt[name] = per_step(f, name)   # per step: every dispatch of one pass over the batch
 if agg:
-    json.dump({"command": "profiles/run_sq_pmc.sh (ns workload, mean over %d launches, kernel %s)" % (max(cnt.values()), row["Name"]), "counters": agg},
+    json.dump({"command": "profiles/run_sq_pmc.sh (ns workload, per step = all launches of one pass, mean over %d steps, longest kernel %s)" % (max(cnt.values()), row["Name"]), "counters": agg},
               open(os.path.join(dst, "ns_sw_sq_counters.json"), "w"), indent=1)
 
 # cells per launch of the headline workload: from the bench line of the stats run itself
@@ -85,7 +95,8 @@ counters = {"source_sha256": bench.source_hash(),
             "collected_with": "profiles/run_evidence.sh: run_pmc.sh + run_sq_pmc.sh + run_wl_pmc.sh (rocprofv3 --kernel-trace --pmc, one "
                               "counter group per run; per-launch means over the warm-up and the timed launch)",
             "workloads": {"ns_sw": {
-                "kernel": row["Name"], "cells_per_launch": d_stats["config"]["cells_per_step_per_gpu"],
+                "kernel": row["Name"], "kernels_of_a_step": {r["Name"]: float(r["AverageNs"]) / 1e6 for r in stat_rows},
+                "cells_per_launch": d_stats["config"]["cells_per_step_per_gpu"],
                 "kernel_ms_avg_rocprof": float(row["AverageNs"]) / 1e6, "kernel_ms_per_launch_rocprof": launch_ms,
                 "SQ_INSTS_VALU": agg.get("SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU2": agg.get("SQ_ACTIVE_INST_VALU2"),
                 "SQ_WAIT_ANY": agg.get("SQ_WAIT_ANY"), "SQ_INSTS_SALU": agg.get("SQ_INSTS_SALU"),
