@@ -51,7 +51,7 @@ __host__ __device__ inline int band_strip_width(int maxlen) {
 }
 __host__ __device__ inline int band_half_width(int L) { const int w = BAND_WB + (int)(BAND_WF * L); return w < BAND_WMAX ? w : BAND_WMAX; }
 // strips the plane keeps per row: the widest band of a block whose longest sequence has maxlen letters
-__host__ __device__ inline int band_plane_strips(int maxlen, int W) { return 2 * band_half_width(maxlen) / W + 2; }
+__host__ __device__ inline int band_plane_strips(int maxlen, int W) { return plane_round4(2 * band_half_width(maxlen) / W + 2); }
 __host__ __device__ constexpr int band_lds_bytes(int W) { return LDS_CTL_BYTES + LDS_META_BYTES / 2 + 64 * W * 8; }
 
 constexpr unsigned NEGCELL = 0x0000C000u;   // plane cell of a cell that does not exist: H = NEGP, distances 0
@@ -120,7 +120,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
     };
     int s0 = -1000000;          // window origin (strip); far away: the first row re-centres
     unsigned let[NL];           // letters of my two strips, one byte per (strip, column): (lo_k+1, lo_k, hi_k+1, hi_k)
-    unsigned so_lo = 0, so_hi = 0;   // byte offsets of my strips' slots in a plane row
+    unsigned so_lo = 0, so_hi = 0;   // slots of my strips in a plane row
     int Hp[W], Fp[W], Op[W], Hleft = NEG2;
 #pragma unroll
     for (int k = 0; k < W; ++k) { Hp[k] = NEG2; Fp[k] = NEG2; Op[k] = NEG2; }
@@ -211,8 +211,8 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
                 }
                 let[k2] = v;
             }
-            so_lo = (unsigned)((s0 + lane) % BS) << 2;
-            so_hi = (unsigned)((s0 + 64 + lane) % BS) << 2;
+            so_lo = (unsigned)((s0 + lane) % BS);
+            so_hi = (unsigned)((s0 + 64 + lane) % BS);
         }
         const int st_lo = s0 + lane, st_hi = s0 + 64 + lane;   // my strips
         const bool in_lo = st_lo >= bl && st_lo <= bh, in_hi = st_hi >= bl && st_hi <= bh;
@@ -242,12 +242,10 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             const bool a_ = st_lo >= fl_ && st_lo <= fh_, b_ = st_hi >= fl_ && st_hi <= fh_;                 \
             const bool la_ = st_lo - 1 >= fl_ && st_lo - 1 <= fh_, lb_ = st_hi - 1 >= fl_ && st_hi - 1 <= fh_; \
             unsigned cl_[W], chh_[W];                                                                       \
-            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
-                cl_[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_, so_lo, k * BS * 4, 0);                   \
-                chh_[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_, so_hi, k * BS * 4, 0);                  \
-            }                                                                                               \
-            const unsigned ll_ = __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)((st_lo + BS - 1) % BS) << 2, (W - 1) * BS * 4, 0); \
-            const unsigned lh_ = __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)((st_hi + BS - 1) % BS) << 2, (W - 1) * BS * 4, 0); \
+            plane_load_strip<W>(rs_, so_lo, BS, cl_);                                                       \
+            plane_load_strip<W>(rs_, so_hi, BS, chh_);                                                      \
+            const unsigned ll_ = __builtin_amdgcn_raw_buffer_load_b32(rs_, plane_cell_byte<W>(BS, (unsigned)((st_lo + BS - 1) % BS), W - 1), 0, 0); \
+            const unsigned lh_ = __builtin_amdgcn_raw_buffer_load_b32(rs_, plane_cell_byte<W>(BS, (unsigned)((st_hi + BS - 1) % BS), W - 1), 0, 0); \
             _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
                 const unsigned x_ = a_ ? cl_[k] : NEGCELL, y_ = b_ ? chh_[k] : NEGCELL;                     \
                 wr_[k] = u32x2{__builtin_amdgcn_perm(y_, x_, 0x05040100u), __builtin_amdgcn_perm(y_, x_, 0x07060302u)}; \
@@ -464,18 +462,14 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
 #define BAND_STORE(CF, CO)                                                                                  \
     do {                                                                                                    \
-        if (in_lo) {                                                                                        \
-            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
+        if (in_lo)                                                                                          \
+            plane_store_strip<W>(rs_plane, so_lo, BS, [&](const int k) -> unsigned {                        \
                 const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                           \
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), rs_plane, so_lo, k * BS * 4, 0); \
-            }                                                                                               \
-        }                                                                                                   \
-        if (in_hi) {                                                                                        \
-            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
+                return __builtin_amdgcn_perm(w.y, w.x, 0x05040100u); });                                    \
+        if (in_hi)                                                                                          \
+            plane_store_strip<W>(rs_plane, so_hi, BS, [&](const int k) -> unsigned {                        \
                 const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                           \
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), rs_plane, so_hi, k * BS * 4, 0); \
-            }                                                                                               \
-        }                                                                                                   \
+                return __builtin_amdgcn_perm(w.y, w.x, 0x07060302u); });                                    \
     } while (0)
         if (!next_sib) {
 #pragma unroll

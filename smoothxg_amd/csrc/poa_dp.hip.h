@@ -19,6 +19,7 @@
 namespace sxg {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 
 // ---------------------------------------------------------------------------------------
 // workgroup context for poa_graph_dev.h

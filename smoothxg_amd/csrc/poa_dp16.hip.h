@@ -30,6 +30,7 @@
 // 32-bit sweep runs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
 #include "poa_dp.hip.h"
 
 namespace sxg {
@@ -86,10 +87,81 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t p16_rsrc(const void* base, con
 
 // ---- the traceback plane of the packed sweep: a band of strips per row -------------------------
 // Strip s = columns [s*W, (s+1)*W) (s < T: lo strips, s >= T: hi strips).  Row r keeps the BS strips
-// starting at band_first_strip(hint of r), strip s in slot s mod BS; cell (r, column j) is the dword
-//     plane[(r * W + j % W) * BS + (j / W) % BS]  =  H int16 | (H - oF) << 16 | (H - oO) << 24.
+// starting at band_first_strip(hint of r), strip s in slot s mod BS.  A row's cells are laid out in GROUPS of four
+// columns-in-strip: [group][slot][column of the group], i.e. cell (r, column j), k = j % W, slot = (j / W) % BS is the dword
+//     plane[(r * W + 4 * (k / 4)) * BS + slot * gw(k / 4) + k % 4]  =  H int16 | (H - oF) << 16 | (H - oO) << 24,
+// gw(group) = min(4, W - 4 * group).  A lane then writes (reads) its strip with ceil(W / 4) 16-byte instructions, each of
+// which covers 1 KB of consecutive memory per wave (round 4; rounds 1-3 had [column][slot]: W four-byte instructions of
+// 256 B each -- the packed sweep's band stores were 24 % of its launch, most of it instruction issue and the vmcnt they hold).
+// BS is a multiple of 4: rows and groups start on 16-byte boundaries.
+__host__ __device__ constexpr int plane_round4(int bs) { return (bs + 3) & ~3; }
 __host__ __device__ constexpr int p16_band_strips(int T, int W) {
-    return (1100 + W - 1) / W < 2 * T ? (1100 + W - 1) / W : 2 * T;
+    return plane_round4((1100 + W - 1) / W) < 2 * T ? plane_round4((1100 + W - 1) / W) : 2 * T;
+}
+template <int W>
+__device__ __forceinline__ size_t plane_cell(const size_t row, const int BS, const int slot, const int k) {
+    const int gi = k >> 2, gw = W - 4 * gi >= 4 ? 4 : W - 4 * gi;
+    return (row * W + 4 * gi) * (size_t)BS + (size_t)(slot * gw + (k & 3));
+}
+// byte offset of cell k of slot `slot` inside its row (for buffer accesses through a per-row descriptor)
+template <int W>
+__device__ __forceinline__ unsigned plane_cell_byte(const int BS, const unsigned slot, const int k) {
+    const int gi = k >> 2, gw = W - 4 * gi >= 4 ? 4 : W - 4 * gi;
+    return (unsigned)(4 * gi * BS) * 4u + (slot * (unsigned)gw + (unsigned)(k & 3)) * 4u;
+}
+// one strip of a row: cell(k) -> the dword of column k; rs = the row's descriptor
+template <int W, int GI, class F>
+__device__ __forceinline__ void plane_store_group(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, F& cell) {
+    constexpr int k = 4 * GI, gw = W - k >= 4 ? 4 : W - k;
+    // The group's offset travels in the VGPR offset, the SGPR offset field stays 0: a store of more than 64 bits reads its
+    // upper data registers after it has issued, and the compiler only keeps the next VALU write away from them (the "VMEM
+    // store data" hazard) when the SGPR offset field is NOT a register -- with `s_offset` = GI * BS * 16 it scheduled the next
+    // group's v_perm right behind the store, and on gfx950 the stored cells were then the NEXT group's (measured: band misses
+    // on every deep block; the same layout with dword stores was exact).
+    const unsigned vo = slot * (unsigned)(gw * 4) + (unsigned)(GI * BS * 16);
+#ifdef SXG_PLANE_NARROW
+    for (int x = 0; x < gw; ++x) __builtin_amdgcn_raw_buffer_store_b32(cell(k + x), rs, vo, 4 * x, 0);
+    return;
+#endif
+    if constexpr (gw == 4)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{cell(k), cell(k + 1), cell(k + 2), cell(k + 3)}, rs, vo, 0, 0);
+    else if constexpr (gw == 3)
+        __builtin_amdgcn_raw_buffer_store_b96(u32x3{cell(k), cell(k + 1), cell(k + 2)}, rs, vo, 0, 0);
+    else if constexpr (gw == 2)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{cell(k), cell(k + 1)}, rs, vo, 0, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b32(cell(k), rs, vo, 0, 0);
+}
+template <int W, class F, int... GI>
+__device__ __forceinline__ void plane_store_groups(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, F& cell, std::integer_sequence<int, GI...>) {
+    (plane_store_group<W, GI>(rs, slot, BS, cell), ...);
+}
+template <int W, class F>
+__device__ __forceinline__ void plane_store_strip(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, F cell) {
+    plane_store_groups<W>(rs, slot, BS, cell, std::make_integer_sequence<int, (W + 3) / 4>{});
+}
+template <int W, int GI>
+__device__ __forceinline__ void plane_load_group(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, unsigned (&out)[W]) {
+    constexpr int k = 4 * GI, gw = W - k >= 4 ? 4 : W - k;
+    if constexpr (gw == 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, slot << 4, GI * BS * 16, 0);
+        out[k] = v.x; out[k + 1] = v.y; out[k + 2] = v.z; out[k + 3] = v.w;
+    } else if constexpr (gw == 3) {
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, slot * 12u, GI * BS * 16, 0);
+        out[k] = v.x; out[k + 1] = v.y; out[k + 2] = v.z;
+    } else if constexpr (gw == 2) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, slot << 3, GI * BS * 16, 0);
+        out[k] = v.x; out[k + 1] = v.y;
+    } else
+        out[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, slot << 2, GI * BS * 16, 0);
+}
+template <int W, int... GI>
+__device__ __forceinline__ void plane_load_groups(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, unsigned (&out)[W], std::integer_sequence<int, GI...>) {
+    (plane_load_group<W, GI>(rs, slot, BS, out), ...);
+}
+template <int W>
+__device__ __forceinline__ void plane_load_strip(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, unsigned (&out)[W]) {
+    plane_load_groups<W>(rs, slot, BS, out, std::make_integer_sequence<int, (W + 3) / 4>{});
 }
 __device__ __forceinline__ int band_first_strip(const int hint_col, const int W, const int BS, const int T) {
     const int c = hint_col / W - (BS >> 1);
@@ -533,7 +605,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         const __amdgpu_buffer_rsrc_t rs_ring = p16_rsrc((const void*)((SXG_GLOBAL const char*)g_pool + (size_t)(ring && myslot >= 0 ? myslot : 0) * (size_t)RB), RB);
         const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
         const bool in_lo = (unsigned)(w0 + tt - bs0) < (unsigned)BS, in_hi = (unsigned)(w0 + 64 + tt - bs0) < (unsigned)BS;
-        const unsigned so_lo = (soff & 0xffffu) << 2, so_hi = (soff >> 16) << 2;   // strip s lives in slot s mod BS of its row (byte offsets)
+        const unsigned sl_lo = soff & 0xffffu, sl_hi = soff >> 16;   // strip s lives in slot s mod BS of its row
 // ring row + band cells of this row; CF(k) / CO(k) = the row's outgoing candidates of column k
 #define P16_STORES(CF, CO)                                                                                  \
     do {                                                                                                    \
@@ -549,20 +621,16 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             }                                                                                               \
         }                                                                                                   \
         if (band_lo) {                                                                                      \
-            if (in_lo) {                                                                                    \
-                _Pragma("unroll") for (int k = 0; k < W; ++k) {                                             \
+            if (in_lo)                                                                                      \
+                plane_store_strip<W>(rs_plane, sl_lo, BS, [&](const int k) -> unsigned {                    \
                     const u32x2 w = p16_pack_row<CVX, SW>(Hc[k], CF, CO);                                   \
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), rs_plane, so_lo, k * BS * 4, 0); \
-                }                                                                                           \
-            }                                                                                               \
+                    return __builtin_amdgcn_perm(w.y, w.x, 0x05040100u); });                                \
         }                                                                                                   \
         if (band_hi) {                                                                                      \
-            if (in_hi) {                                                                                    \
-                _Pragma("unroll") for (int k = 0; k < W; ++k) {                                             \
+            if (in_hi)                                                                                      \
+                plane_store_strip<W>(rs_plane, sl_hi, BS, [&](const int k) -> unsigned {                    \
                     const u32x2 w = p16_pack_row<CVX, SW>(Hc[k], CF, CO);                                   \
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), rs_plane, so_hi, k * BS * 4, 0); \
-                }                                                                                           \
-            }                                                                                               \
+                    return __builtin_amdgcn_perm(w.y, w.x, 0x07060302u); });                                \
         }                                                                                                   \
     } while (0)
         if (!next_sib) {
@@ -730,7 +798,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             if (!miss) { miss = true; miss_row = p; miss_delta = col - hint; }
             return 0u;
         }
-        return TBU(g_plane[((size_t)p * W + k) * BS + s % BS]);
+        return TBU(g_plane[plane_cell<W>((size_t)p, BS, s % BS, k)]);
     };
     auto wcol0 = [&](int l) -> int { return wj - ((l * slope) >> 8) - (TBW_COLS - 3); };  // first column the window holds of row wtop-l
     auto cell = [&](int p, int col) -> uint32_t {
@@ -781,7 +849,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                     for (int x2 = 0; x2 < TBW_COLS; ++x2) {
                         const int col = min(max(c0 + x2, 0), L);
                         const int s = col / W, k = col - s * W;
-                        v[x2] = g_plane[((size_t)row * W + k) * BS + s % BS];
+                        v[x2] = g_plane[plane_cell<W>((size_t)row, BS, s % BS, k)];
                     }
 #pragma unroll
                     for (int x2 = 0; x2 < TBW_COLS; ++x2) {
@@ -940,7 +1008,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                         const int s = col / W, k = col - s * W;
                         const bool inb = act && kept(hint, s);
                         int hval = 0;
-                        if (act && inb) hval = sext(g_plane[((size_t)i * W + k) * BS + s % BS]);
+                        if (act && inb) hval = sext(g_plane[plane_cell<W>((size_t)i, BS, s % BS, k)]);
                         const unsigned long long meq = __ballot(act && inb && hval + go + (x - 1) * ge == hv);
                         const unsigned long long moob = BANDED ? 0ull : __ballot(act && !inb);
                         const int feq = meq ? (int)__builtin_ctzll(meq) : 64, foob = moob ? (int)__builtin_ctzll(moob) : 64;

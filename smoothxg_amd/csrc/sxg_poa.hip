@@ -1001,7 +1001,7 @@ struct LaunchPlan {
 static int plane_strips_p16(int T, int W) {
     if (const char* e = getenv("SXG_POA_BAND_COLS")) {
         const int cols = std::max(atoi(e), W);
-        return std::min((cols + W - 1) / W, 2 * T);
+        return std::min(plane_round4((cols + W - 1) / W), 2 * T);
     }
     return p16_band_strips(T, W);
 }
