@@ -460,6 +460,12 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             else if (next_sib) ada_band(my_pl, my_pr, nhint, nbl, nbh);                   // (same single predecessor as mine)
         }
         const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
+// (Round 4 measured a PLANE CUT here: rows that no later row reads back kept only 16 strips either side of the strip of their
+// greatest H, the walk reported a miss for a cell such a row had not kept and that sequence's sweep was repeated with whole
+// bands.  c3b 1 374 -> 1 206 blocks/s with 10 % of the alignments repeated, i.e. nothing gained by writing a third of the
+// cells: the stores' cost is their acknowledgement latency in front of the next row's in-order vmcnt wait, not their volume,
+// and the number of store instructions per row does not change.  Dropped; the repeat also needs prep_rows again in B4 mode,
+// whose records overwrite the hints.)
 #define BAND_STORE(CF, CO)                                                                                  \
     do {                                                                                                    \
         if (in_lo)                                                                                          \

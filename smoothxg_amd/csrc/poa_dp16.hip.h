@@ -299,7 +299,10 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         }
         Hleft = pk2(h2[0], h2[1]);
     }
-    // a stored row: W columns of 8-byte words [column][lane], then the column LEFT of every lane's strips (4 bytes per lane)
+    // a stored row: W columns of 8-byte words [column][lane], then the column LEFT of every lane's strips (4 bytes per lane).
+    // (Pairs of columns per 16-byte access, as in the plane, were measured in round 4: 90 instead of 131 memory instructions in
+    // the row loop, 2 010 against 1 996 ms on the headline, c3 -1 %, c4 +1 %: the ring's cost is its volume, not its instruction
+    // count -- kept at 8 bytes.)
     const int RB = TW * 8 + T * 4;
     {
         const __amdgpu_buffer_rsrc_t rs0 = p16_rsrc((const void*)g_row0, RB);
