@@ -128,7 +128,10 @@ typedef struct sxg_poa_batch_in {
      * (:947), the last two by the decrees of DESIGN.md section 9 (odgi is absent from the reference snapshot).
      *   0 = off (the caller builds block graphs from the raw POA results);
      *   1 = bg_* arrays of the result are filled in addition to the raw results;
-     *   2 = ... and seq_path_nodes (one node id per base: two thirds of the download) is left out (NULL). */
+     *   2 = ... and seq_path_nodes (one node id per base: two thirds of the download) is left out (NULL);
+     *   3 = ... and the per-node / per-edge arrays of the raw POA graphs and cons_nodes as well (NULL; status, n_nodes,
+     *       n_edges, the offsets, score and cells stay): for a caller that only laces block graphs (sxg_smooth_gfa).
+     *   A request for the MSA (want_msa) turns 2 and 3 into 1: the MSA is formatted from the per-base paths. */
     int32_t want_block_graph;
     int32_t bg_consensus_visited_only; /* 1 = the consensus path keeps only nodes some sequence path visits (build_odgi_abPOA,
                                           src/smooth.cpp:2542-2548); 0 = every consensus node (build_odgi_SPOA, :2624-2627) */

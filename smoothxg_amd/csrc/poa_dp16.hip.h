@@ -94,20 +94,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t p16_rsrc(const void* base, con
 // which covers 1 KB of consecutive memory per wave (round 4; rounds 1-3 had [column][slot]: W four-byte instructions of
 // 256 B each -- the packed sweep's band stores were 24 % of its launch, most of it instruction issue and the vmcnt they hold).
 // BS is a multiple of 4: rows and groups start on 16-byte boundaries.
-__host__ __device__ constexpr int plane_round4(int bs) { return (bs + 3) & ~3; }
 __host__ __device__ constexpr int p16_band_strips(int T, int W) {
     return plane_round4((1100 + W - 1) / W) < 2 * T ? plane_round4((1100 + W - 1) / W) : 2 * T;
 }
 template <int W>
 __device__ __forceinline__ size_t plane_cell(const size_t row, const int BS, const int slot, const int k) {
-    const int gi = k >> 2, gw = W - 4 * gi >= 4 ? 4 : W - 4 * gi;
-    return (row * W + 4 * gi) * (size_t)BS + (size_t)(slot * gw + (k & 3));
+    return row * (size_t)(W * BS) + (size_t)plane_cell_in_row(W, BS, slot, k);   // (poa_types.h)
 }
 // byte offset of cell k of slot `slot` inside its row (for buffer accesses through a per-row descriptor)
 template <int W>
 __device__ __forceinline__ unsigned plane_cell_byte(const int BS, const unsigned slot, const int k) {
-    const int gi = k >> 2, gw = W - 4 * gi >= 4 ? 4 : W - 4 * gi;
-    return (unsigned)(4 * gi * BS) * 4u + (slot * (unsigned)gw + (unsigned)(k & 3)) * 4u;
+    return (unsigned)plane_cell_in_row(W, BS, (int)slot, k) * 4u;
 }
 // one strip of a row: cell(k) -> the dword of column k; rs = the row's descriptor
 template <int W, int GI, class F>

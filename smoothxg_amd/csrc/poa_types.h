@@ -43,6 +43,16 @@ enum : int {
 
 // Lower bound of every reachable global-alignment score: the all-gap path (a gap down a chain of
 // `rows` predecessors plus a gap over `cols` columns); H is a maximum over paths, so it is never below.
+// ---- layout of the packed sweeps' traceback plane (poa_dp16.hip.h, poa_band16.hip.h): host + device, so that the CPU suite
+// can check it.  A row holds BS slots (strip s in slot s mod BS) of W columns-in-strip, in GROUPS of four columns:
+// [group][slot][column of the group]; the last group is W - 4 * (groups - 1) columns wide.  BS is a multiple of 4.
+SXG_HD constexpr int plane_round4(int bs) { return (bs + 3) & ~3; }
+SXG_HD constexpr int plane_group_width(int W, int gi) { return W - 4 * gi >= 4 ? 4 : W - 4 * gi; }
+// dword of column-in-strip k of slot `slot` inside its row
+SXG_HD constexpr int plane_cell_in_row(int W, int BS, int slot, int k) {
+    return 4 * (k >> 2) * BS + slot * plane_group_width(W, k >> 2) + (k & 3);
+}
+
 SXG_HD long sxg_gap_cost(int g, int e, int q, int c, long k) {
     if (k <= 0) return 0;
     const long a = g + (k - 1) * (long)e, b = q + (k - 1) * (long)c;

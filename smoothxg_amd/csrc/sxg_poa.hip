@@ -494,6 +494,25 @@ __global__ __launch_bounds__(BG_THREADS) void block_graph_kernel(const BgArgs A)
 }
 
 // dense <- worst-case gather (one workgroup per block, grid-stride over blocks)
+// upload: letters above 4 read as N (4).  16 bytes per thread and step; the buffer is allocated with 16 bytes of slack.
+__global__ void clamp_bases_kernel(uint8_t* bases, const int64_t n) {
+    const int64_t n16 = (n + 15) / 16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        u32x4 v = ((const u32x4*)bases)[i];
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { const unsigned c = (w[k] >> (8 * b)) & 0xffu; o |= (c > 4u ? 4u : c) << (8 * b); }
+            any |= o != w[k];
+            w[k] = o;
+        }
+        if (any) ((u32x4*)bases)[i] = u32x4{w[0], w[1], w[2], w[3]};
+    }
+}
+
 template <class Tv>
 __global__ void gather_kernel(const Tv* __restrict__ src, Tv* __restrict__ dst, const int64_t* __restrict__ src_off,
                               const int64_t* __restrict__ dst_off, int n) {
@@ -732,6 +751,32 @@ struct PlanRes {
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 
+// Pinned host memory for the one big array of a download (the block graphs' step lists: 1.3 GB on the headline batch).  A
+// copy into pageable memory runs at about half the link's rate (the runtime stages it); pinning 1.3 GB takes longer than the
+// copy saves, so the buffers are pinned ONCE and lent out: a result holds one until sxg_poa_batch_free (any thread), the pool
+// lives as long as the handle or the last result that borrowed from it.  SXG_POA_NO_PINNED=1 switches it off.
+struct PinPool {
+    struct Buf { void* p; size_t cap; bool busy; };
+    std::mutex mu;
+    std::vector<Buf> bufs;
+    void* acquire(size_t bytes) {   // nullptr: nothing to lend (the caller allocates pageable memory)
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& b : bufs) if (!b.busy && b.cap >= bytes) { b.busy = true; return b.p; }
+        for (size_t i = 0; i < bufs.size(); ++i)
+            if (!bufs[i].busy) { (void)hipHostFree(bufs[i].p); bufs.erase(bufs.begin() + (long)i); break; }   // (an idle one that is too small)
+        if (bufs.size() >= 4) return nullptr;
+        void* q = nullptr;
+        const size_t cap = bytes + bytes / 8;
+        if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess || !q) { (void)hipGetLastError(); return nullptr; }
+        bufs.push_back(Buf{q, cap, true});
+        return q;
+    }
+    void release(void* p) {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& b : bufs) if (b.p == p) b.busy = false;
+    }
+    ~PinPool() { for (auto& b : bufs) (void)hipHostFree(b.p); }
+};
 struct sxg_poa_handle {
     std::vector<PlanRes*> planres;
     int device = 0;
@@ -756,6 +801,7 @@ struct sxg_poa_handle {
     DevBuf d_board;   // the per-CU progress board (sxg_balance_prio) the launches of a round share
     // block graphs (want_block_graph): inputs, outputs in per-block layouts, the per-block counts of the last execute
     int want_block_graph = 0, bg_cons_visited_only = 0;
+    std::shared_ptr<PinPool> pins;   // pinned host buffers lent to results (created with the handle)
     bool bg_done = false;
     DevBuf d_trim, d_bg_no, d_bg_eo, d_bg_len, d_bg_od, d_bg_id, d_bg_seq, d_bg_eto, d_bg_steps, d_bg_nsteps, d_bg_cons, d_bg_counts,
         d_bg_work, d_bg_queue, d_bg_arena;
@@ -804,6 +850,7 @@ extern "C" int sxg_poa_create(int device, sxg_poa_handle** out) {
     HIPCHK(hipSetDevice(device));
     sxg_poa_handle* h = new sxg_poa_handle();
     h->device = device;
+    h->pins = std::make_shared<PinPool>();
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     h->num_cu = prop.multiProcessorCount;
@@ -892,8 +939,8 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     }
     h->n_blocks = nb; h->n_seqs = ns; h->n_bases = nbases;
     h->want_consensus = in->want_consensus; h->want_msa = in->want_msa;
-    h->want_block_graph = in->want_block_graph < 0 || in->want_block_graph > 2 ? 0 : in->want_block_graph;
-    if (h->want_block_graph == 2 && in->want_msa) h->want_block_graph = 1;   // (the MSA is formatted from the per-base paths)
+    h->want_block_graph = in->want_block_graph < 0 || in->want_block_graph > 3 ? 0 : in->want_block_graph;
+    if (h->want_block_graph >= 2 && in->want_msa) h->want_block_graph = 1;   // (the MSA is formatted from the per-base paths)
     h->bg_cons_visited_only = in->bg_consensus_visited_only ? 1 : 0;
     h->bg_done = false;
     h->per_block_params = in->per_block_params;
@@ -929,24 +976,10 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
             m.fits = true;
         }
     }
-    // letters > 4 are read as N: only a batch that holds one is copied to a staging buffer and fixed there
-    // (the unconditional copy was 0.15 s of host time per 320 MB batch)
-    bool dirty = false;
-    {
-        uint8_t acc = 0;
-        for (int64_t i = 0; i < nbases && !dirty; i += 1 << 16) {
-            const int64_t hi = std::min<int64_t>(nbases, i + (1 << 16));
-            for (int64_t k = i; k < hi; ++k) acc |= (uint8_t)(in->bases[k] > 4);
-            dirty = acc != 0;
-        }
-    }
+    // letters > 4 are read as N: clamped on the device after the copy (clamp_bases_kernel; a host scan of the 320 MB of the
+    // headline batch was 10 ms of every upload, the unconditional staging copy before it 0.15 s)
     laps.lap("upload: checks");
-    std::vector<uint8_t> stage;
-    if (dirty) {
-        stage.resize((size_t)nbases);
-        for (int64_t i = 0; i < nbases; ++i) stage[i] = in->bases[i] > 4 ? 4 : in->bases[i];
-    }
-    const uint8_t* host_bases = dirty ? stage.data() : in->bases;
+    const uint8_t* host_bases = in->bases;
     int rc;
     if ((rc = h->d_blk_off.ensure(4 * (size_t)(nb + 1)))) return rc;
     if ((rc = h->d_seq_off.ensure(8 * (size_t)(ns + 1)))) return rc;
@@ -955,6 +988,11 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     HIPCHK(hipMemcpyAsync(h->d_blk_off.p, in->blk_off, 4 * (size_t)(nb + 1), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_seq_off.p, in->seq_off, 8 * (size_t)(ns + 1), hipMemcpyHostToDevice, h->stream));
     if (nbases) HIPCHK(hipMemcpyAsync(h->d_bases.p, host_bases, (size_t)nbases, hipMemcpyHostToDevice, h->stream));
+    if (nbases) {
+        hipLaunchKernelGGL(clamp_bases_kernel, dim3((unsigned)std::min<int64_t>((nbases / 16 + 255) / 256 + 1, 16384)), dim3(256), 0, h->stream,
+                           h->d_bases.as<uint8_t>(), nbases);
+        HIPCHK(hipGetLastError());
+    }
     if (nb) HIPCHK(hipMemcpyAsync(h->d_params.p, in->params, sizeof(sxg_poa_params) * (size_t)np, hipMemcpyHostToDevice, h->stream));
     h->has_weights = in->weights != nullptr;
     if (h->has_weights) {
@@ -1561,10 +1599,12 @@ template <class T> struct host_noinit_alloc : std::allocator<T> {
 };
 template <class T> using hvec = std::vector<T, host_noinit_alloc<T>>;
 struct OutOwner {
+    std::shared_ptr<PinPool> pin_pool;
+    int32_t* bg_steps_pinned = nullptr;   // the step lists when they were downloaded into a borrowed pinned buffer
     std::vector<int32_t> status, score, msa_cols;
     hvec<int32_t> node_rank, node_group, edge_tail, edge_head, cons_nodes;
     int32_t* seq_path_nodes = nullptr;   // one node id per base: the big one (1.3 GB on the headline batch), never zero-filled
-    ~OutOwner() { free(seq_path_nodes); }
+    ~OutOwner() { free(seq_path_nodes); if (bg_steps_pinned && pin_pool) pin_pool->release(bg_steps_pinned); }
     std::vector<int64_t> node_off, edge_off, cons_off, msa_off;
     hvec<uint8_t> node_code;
     hvec<uint32_t> edge_weight;
@@ -1632,6 +1672,8 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
         sxg_poa_batch_free(out);                                                                     \
         return rc;                                                                                   \
     }
+    const bool with_graphs = !(h->want_block_graph == 3 && h->bg_done);   // (3: the caller laces block graphs and reads nothing else)
+    if (with_graphs) {
     GD(uint8_t, h->d_node_code, o->node_off, o->node_code)
     GD(int32_t, h->d_node_rank, o->node_off, o->node_rank)
     GD(int32_t, h->d_node_group, o->node_off, o->node_group)
@@ -1639,9 +1681,10 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
     GD(int32_t, h->d_edge_head, o->edge_off, o->edge_head)
     GD(uint32_t, h->d_edge_w, o->edge_off, o->edge_weight)
     if (h->want_consensus) { GD(int32_t, h->d_cons, o->cons_off, o->cons_nodes) }
+    }
 #undef GD
     laps.lap("download: POA graphs");
-    const bool with_paths = !(h->want_block_graph == 2 && h->bg_done);
+    const bool with_paths = !(h->want_block_graph >= 2 && h->bg_done);
     if (with_paths) {
         o->seq_path_nodes = (int32_t*)host_big_alloc(4 * (size_t)std::max<int64_t>(h->n_bases, 1));
         if (!o->seq_path_nodes) { sxg_poa_batch_free(out); return fail(SXG_E_NOMEM, "host allocation of the path array failed"); }
@@ -1682,13 +1725,29 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
         GB_(uint8_t, src_no, h->d_bg_id, o->bg_node_off, o->bg_node_indeg)
         GB_(uint8_t, src_no, h->d_bg_seq, o->bg_seq_off, o->bg_seq)
         GB_(int32_t, src_eo, h->d_bg_eto, o->bg_edge_off, o->bg_edge_to)
-        GB_(int32_t, src_off, h->d_bg_steps, blk_steps, o->bg_steps)
+        {   // the step lists: into a borrowed pinned buffer when the pool has one (see PinPool)
+            const int64_t total = blk_steps[nb];
+            if (total >= ((int64_t)16 << 20) && h->pins && !getenv("SXG_POA_NO_PINNED")) {
+                if (void* q = h->pins->acquire(4 * (size_t)total)) { o->pin_pool = h->pins; o->bg_steps_pinned = (int32_t*)q; }
+            }
+            if (o->bg_steps_pinned) {
+                if ((rc = put_src(src_off)) || (rc = put_off(blk_steps)) || (rc = h->d_tmp_c.ensure(4 * (size_t)total))) { sxg_poa_batch_free(out); return rc; }
+                hipLaunchKernelGGL((gather_kernel<int32_t>), dim3((unsigned)std::min(nb, 4096)), dim3(256), 0, h->stream, h->d_bg_steps.as<int32_t>(),
+                                   h->d_tmp_c.as<int32_t>(), h->d_tmp_a.as<int64_t>(), h->d_tmp_b.as<int64_t>(), nb);
+                hipError_t e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(o->bg_steps_pinned, h->d_tmp_c.p, 4 * (size_t)total, hipMemcpyDeviceToHost, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                if (e != hipSuccess) { sxg_poa_batch_free(out); return fail(SXG_E_NODEVICE, std::string("download of the step lists: ") + hipGetErrorString(e)); }
+            } else {
+                GB_(int32_t, src_off, h->d_bg_steps, blk_steps, o->bg_steps)
+            }
+        }
         if (h->want_consensus) { GB_(int32_t, src_no, h->d_bg_cons, o->bg_cons_off, o->bg_cons_steps) }
 #undef GB_
         out->bg_node_off = o->bg_node_off.data(); out->bg_node_len = o->bg_node_len.data(); out->bg_node_outdeg = o->bg_node_outdeg.data();
         out->bg_node_indeg = o->bg_node_indeg.data(); out->bg_seq_off = o->bg_seq_off.data(); out->bg_seq = (char*)o->bg_seq.data();
         out->bg_edge_off = o->bg_edge_off.data(); out->bg_edge_to = o->bg_edge_to.data(); out->bg_step_off = o->bg_step_off.data();
-        out->bg_steps = o->bg_steps.data();
+        out->bg_steps = o->bg_steps_pinned ? o->bg_steps_pinned : o->bg_steps.data();
         if (h->want_consensus) { out->bg_cons_off = o->bg_cons_off.data(); out->bg_cons_steps = o->bg_cons_steps.data(); }
         laps.lap("download: block graphs");
     }
@@ -1697,11 +1756,13 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
         HIPCHK(hipMemcpy(o->cells.data(), h->d_cells.p, 8 * (size_t)ns, hipMemcpyDeviceToHost));
     }
     out->status = o->status.data();
-    out->node_off = o->node_off.data(); out->node_code = o->node_code.data(); out->node_rank = o->node_rank.data();
-    out->node_group = o->node_group.data(); out->edge_off = o->edge_off.data(); out->edge_tail = o->edge_tail.data();
-    out->edge_head = o->edge_head.data(); out->edge_weight = o->edge_weight.data();
+    out->node_off = o->node_off.data(); out->edge_off = o->edge_off.data();
+    if (with_graphs) {
+        out->node_code = o->node_code.data(); out->node_rank = o->node_rank.data(); out->node_group = o->node_group.data();
+        out->edge_tail = o->edge_tail.data(); out->edge_head = o->edge_head.data(); out->edge_weight = o->edge_weight.data();
+    }
     out->seq_path_nodes = o->seq_path_nodes; out->score = o->score.data(); out->cells = o->cells.data();
-    if (h->want_consensus) { out->cons_off = o->cons_off.data(); out->cons_nodes = o->cons_nodes.data(); }
+    if (h->want_consensus) { out->cons_off = o->cons_off.data(); if (with_graphs) out->cons_nodes = o->cons_nodes.data(); }
     if (h->want_msa && o->seq_path_nodes) {
         // S8: MSA column = aligned group in rank order; pure formatting of device results
         static const char dec[5] = {'A', 'C', 'G', 'T', 'N'};
@@ -1943,7 +2004,7 @@ void build_local(const sxg_poa_batch_in* in, const std::vector<int32_t>& part, L
     L.in.per_block_params = in->per_block_params; L.in.want_consensus = in->want_consensus; L.in.want_msa = 0;
     // the owning rank builds the block graphs of its blocks (the root only laces); the MSA is formatted on the root from
     // the per-base paths, which then travel as well
-    L.in.want_block_graph = in->want_block_graph == 2 && in->want_msa ? 1 : in->want_block_graph;
+    L.in.want_block_graph = in->want_block_graph >= 2 ? (in->want_msa ? 1 : 2) : in->want_block_graph;   // (3: the raw POA graphs travel with the blob; the root drops them)
     L.in.bg_consensus_visited_only = in->bg_consensus_visited_only;
     if (in->want_block_graph) {
         for (int b : part) L.trims.push_back(in->bg_trim ? in->bg_trim[b] : 0);
@@ -2077,6 +2138,7 @@ int assemble(const sxg_poa_batch_in* in, const std::vector<std::vector<int32_t>>
     int bg_mode = 0;   // what the ranks sent (the same on all of them: every rank was handed the same request)
     for (int r = 0; r < nranks; ++r) if (counts[(size_t)r * BC_N + BC_NB] > 0) bg_mode = std::max(bg_mode, (int)counts[(size_t)r * BC_N + BC_BG]);
     const bool with_paths = bg_mode != 2;
+    const bool with_graphs = true;   // (a sharded run always carries the raw POA graphs to the root)
     if (with_paths) {
         o->seq_path_nodes = (int32_t*)host_big_alloc(4 * (size_t)std::max<int64_t>(nbases, 1));
         if (!o->seq_path_nodes) return fail(SXG_E_NOMEM, "host allocation of the path array failed");
@@ -2176,9 +2238,11 @@ int assemble(const sxg_poa_batch_in* in, const std::vector<std::vector<int32_t>>
         if (in->want_consensus) { out->bg_cons_off = o->bg_cons_off.data(); out->bg_cons_steps = o->bg_cons_steps.data(); }
     }
     out->status = o->status.data();
-    out->node_off = o->node_off.data(); out->node_code = o->node_code.data(); out->node_rank = o->node_rank.data();
-    out->node_group = o->node_group.data(); out->edge_off = o->edge_off.data(); out->edge_tail = o->edge_tail.data();
-    out->edge_head = o->edge_head.data(); out->edge_weight = o->edge_weight.data();
+    out->node_off = o->node_off.data(); out->edge_off = o->edge_off.data();
+    if (with_graphs) {
+        out->node_code = o->node_code.data(); out->node_rank = o->node_rank.data(); out->node_group = o->node_group.data();
+        out->edge_tail = o->edge_tail.data(); out->edge_head = o->edge_head.data(); out->edge_weight = o->edge_weight.data();
+    }
     out->seq_path_nodes = o->seq_path_nodes; out->score = o->score.data(); out->cells = o->cells.data();
     if (in->want_consensus) { out->cons_off = o->cons_off.data(); out->cons_nodes = o->cons_nodes.data(); }
     if (in->want_msa && o->seq_path_nodes) {

@@ -2214,7 +2214,7 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
         if (fast) {   // A9 + A10 asked of the provider: trim = the block's padding, consensus filter of the abPOA path
             C.trims.resize((size_t)std::max<int64_t>(n, 1), 0);
             for (int64_t k = 0; k < n; ++k) C.trims[(size_t)k] = col[(size_t)(k0 + k)].poa_padding;
-            C.in.want_block_graph = 2; C.in.bg_trim = C.trims.data(); C.in.bg_consensus_visited_only = p->use_abpoa ? 1 : 0;
+            C.in.want_block_graph = 3; C.in.bg_trim = C.trims.data(); C.in.bg_consensus_visited_only = p->use_abpoa ? 1 : 0;
         }
         t_collect += since(t0);
     };

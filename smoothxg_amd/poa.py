@@ -228,7 +228,8 @@ class PoaEngine:
 
     def upload(self, bases, seq_off, blk_off, weights, params, want_consensus=False, want_msa=False, block_graph=0,
                bg_trim=None, bg_cons_visited_only=False):
-        """block_graph: 1 = also the normalised block graphs (BlockResult.bg), 2 = ... without the per-base paths."""
+        """block_graph: 1 = also the normalised block graphs (BlockResult.bg), 2 = ... without the per-base paths,
+        3 = ... and without the raw POA graphs (node_* / edge_* / consensus of the results are None)."""
         bi = self._mk_in(bases, seq_off, blk_off, weights, params, want_consensus, want_msa, block_graph, bg_trim,
                          bg_cons_visited_only)
         if self.lib.sxg_poa_batch_upload(self.h, C.byref(bi)):
@@ -270,12 +271,13 @@ class PoaEngine:
         node_off = _arr(out.node_off, nb + 1, np.int64)
         edge_off = _arr(out.edge_off, nb + 1, np.int64)
         nn, ne = (int(node_off[-1]), int(edge_off[-1])) if nb else (0, 0)
-        node_code = _arr(out.node_code, nn, np.uint8)
-        node_rank = _arr(out.node_rank, nn, np.int32)
-        node_group = _arr(out.node_group, nn, np.int32)
-        et = _arr(out.edge_tail, ne, np.int32)
-        eh = _arr(out.edge_head, ne, np.int32)
-        ew = _arr(out.edge_weight, ne, np.uint32)
+        has_raw = bool(out.node_code) or nn == 0      # (block_graph=3: the raw POA graphs are left out)
+        node_code = _arr(out.node_code, nn, np.uint8) if has_raw else None
+        node_rank = _arr(out.node_rank, nn, np.int32) if has_raw else None
+        node_group = _arr(out.node_group, nn, np.int32) if has_raw else None
+        et = _arr(out.edge_tail, ne, np.int32) if has_raw else None
+        eh = _arr(out.edge_head, ne, np.int32) if has_raw else None
+        ew = _arr(out.edge_weight, ne, np.uint32) if has_raw else None
         nbases = int(seq_off[-1]) if ns else 0
         paths = _arr(out.seq_path_nodes, nbases, np.int32) if out.seq_path_nodes else None
         bg = None
@@ -294,7 +296,7 @@ class PoaEngine:
         score = _arr(out.score, ns, np.int32)
         cells = _arr(out.cells, ns, np.uint64)
         cons_off = _arr(out.cons_off, nb + 1, np.int64) if out.cons_off else None
-        cons = _arr(out.cons_nodes, int(cons_off[-1]), np.int32) if cons_off is not None and nb else None
+        cons = _arr(out.cons_nodes, int(cons_off[-1]), np.int32) if cons_off is not None and nb and out.cons_nodes else None
         msa_off = _arr(out.msa_off, nb + 1, np.int64) if out.msa_off else None
         msa_cols = _arr(out.msa_cols, nb, np.int32) if out.msa_cols else None
         msa_raw = None
@@ -305,9 +307,9 @@ class PoaEngine:
             r = BlockResult()
             r.status = int(status[b])
             a, z = node_off[b], node_off[b + 1]
-            r.node_code, r.node_rank, r.node_group = node_code[a:z], node_rank[a:z], node_group[a:z]
+            r.node_code, r.node_rank, r.node_group = (node_code[a:z], node_rank[a:z], node_group[a:z]) if has_raw else (None, None, None)
             a, z = edge_off[b], edge_off[b + 1]
-            r.edge_tail, r.edge_head, r.edge_weight = et[a:z], eh[a:z], ew[a:z]
+            r.edge_tail, r.edge_head, r.edge_weight = (et[a:z], eh[a:z], ew[a:z]) if has_raw else (None, None, None)
             s0, s1 = int(blk_off[b]), int(blk_off[b + 1])
             r.paths = [paths[int(seq_off[s]):int(seq_off[s + 1])] for s in range(s0, s1)] if paths is not None else None
             r.bg = None

@@ -111,3 +111,20 @@ extern "C" int emul_block_graph(const uint8_t* node_code, int V, const int32_t* 
     block_graph(c, I, W, O);
     return counts[BGC_STATUS];
 }
+
+// Layout of the packed sweeps' traceback plane (poa_types.h): out[slot * W + k] = dword of cell (slot, k) inside its row.
+// Also replays what the sweeps' 16-byte stores do -- group gi of a lane's strip goes to dwords
+// [4 * gi * BS + slot * gw, + gw) -- and returns the number of cells whose stored place differs from plane_cell_in_row.
+extern "C" int emul_plane_layout(int W, int BS, int32_t* out) {
+    int bad = 0;
+    for (int slot = 0; slot < BS; ++slot)
+        for (int k = 0; k < W; ++k) out[slot * W + k] = sxg::plane_cell_in_row(W, BS, slot, k);
+    const int NG = (W + 3) / 4;
+    for (int slot = 0; slot < BS; ++slot)
+        for (int gi = 0; gi < NG; ++gi) {
+            const int gw = sxg::plane_group_width(W, gi);
+            for (int x = 0; x < gw; ++x)
+                if (4 * gi * BS + slot * gw + x != out[slot * W + 4 * gi + x]) ++bad;
+        }
+    return bad;
+}

@@ -99,6 +99,23 @@ def test_edge_cases(engine, oracle):
         assert_block_equal(res[b], g, sc, cells, label=f"edge{b}")
 
 
+def test_letters_above_four_read_as_n(engine, oracle):
+    """Codes 5..255 in the input are N (4): clamped on the device after the upload (clamp_bases_kernel), at every
+    alignment of the buffer and at its very end."""
+    rng = np.random.default_rng(8)
+    seqs = random_block(rng, 5, 333, div=0.05)
+    dirty = [s.copy() for s in seqs]
+    for s in dirty:
+        idx = rng.integers(0, len(s), 9)
+        s[idx] = rng.integers(5, 256, 9).astype(np.uint8)
+        s[-1] = 200
+    clean = [np.minimum(s, 4) for s in dirty]
+    res = engine.run_blocks([dirty, [np.array([9], np.uint8)]], gparams("convex_default", 0))
+    g, sc, cells = oracle.block_run(clean, None, oparams("convex_default", 0))
+    assert_block_equal(res[0], g, sc, cells, label="dirty letters")
+    assert res[1].status == 0 and res[1].node_code.tolist() == [4]
+
+
 def test_too_long_is_reported_not_crashed(engine):
     import smoothxg_amd as S
     blk = [[np.zeros(30000, np.uint8), np.zeros(10, np.uint8)]]

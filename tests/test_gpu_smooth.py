@@ -193,7 +193,7 @@ def test_device_block_graphs_equal_the_restatement(engine, oracle, cons_mode):
     """sxg_poa_batch_in::want_block_graph: A9 + A10 computed by the block-graph kernel right after the alignments (trim,
     path-supported edges, unchop, Kahn order, compact step lists) through the C ABI, against the Python restatement
     (oracle/smooth_oracle.py::build_block_graph) fed with the oracle's POA of the same block; with and without padding trim,
-    spoa-style and abPOA-style (visited nodes only) consensus; mode 2 leaves the per-base paths out."""
+    spoa-style and abPOA-style (visited nodes only) consensus; mode 2 leaves the per-base paths out, mode 3 the raw POA graphs too."""
     import numpy as np
     import smoothxg_amd as SX
     from helpers import random_block
@@ -216,10 +216,11 @@ def test_device_block_graphs_equal_the_restatement(engine, oracle, cons_mode):
     seq_off[1:] = np.cumsum([len(s) for s in flat])
     blk_off = np.zeros(len(blocks) + 1, np.int32)
     blk_off[1:] = np.cumsum([len(b) for b in blocks])
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         res = engine.run_flat(bases, seq_off, blk_off, None, prm, want_consensus=cons_mode > 0, block_graph=mode, bg_trim=trims,
                               bg_cons_visited_only=(cons_mode == 2))
-        assert (res[0].paths is None) == (mode == 2)
+        assert (res[0].paths is None) == (mode >= 2)
+        assert (res[0].node_code is None) == (mode == 3) and (res[0].edge_tail is None) == (mode == 3)
         for b, seqs in enumerate(blocks):
             assert res[b].status == 0
             g, _, _ = oracle.block_run(seqs, None, oracle.mkparams(1, -4, -6, -2, -26, -1, 0))
@@ -235,7 +236,7 @@ def test_device_block_graphs_equal_the_restatement(engine, oracle, cons_mode):
 
 
 def test_device_block_graphs_feed_the_same_gfa_as_host_built_ones(engine, monkeypatch):
-    """The iteration asks the engine for block graphs (want_block_graph = 2) and laces them without the laced graph;
+    """The iteration asks the engine for block graphs only (want_block_graph = 3) and laces them without the laced graph;
     SXG_SMOOTH_LEGACY=1 builds block graphs on the host from the per-base paths and laces through ograph_t: same bytes,
     with padding and consensus paths, on DRB1 with real block discovery."""
     text = open(DRB1).read()

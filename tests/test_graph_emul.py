@@ -191,3 +191,24 @@ def test_spoa_order_option_matches_its_restatement(emul, oracle):
             if g0.n_nodes != g.n_nodes or not (g0.nodes()[1] == rank).all():
                 differs += 1
     assert differs > 5
+
+
+def test_traceback_plane_layout_is_a_bijection_and_matches_the_wide_stores(emul):
+    """The packed sweeps' traceback plane keeps a row's cells in groups of four columns-in-strip ([group][slot][column],
+    poa_types.h::plane_cell_in_row): for every strip width the kernels are built for and every legal number of slots, the
+    map (slot, column) -> dword must cover the row's W * BS dwords exactly once, every group of a lane's strip must be
+    consecutive dwords starting on a 16-byte boundary (what the 16-byte stores assume), and the place a group store writes
+    to must be the place the traceback reads from."""
+    for W in range(2, 17):
+        for BS in (4, 8, 92, 100, 112, 124, 128, 512, 1024):
+            out = np.zeros(W * BS, np.int32)
+            bad = emul.emul_plane_layout(W, BS, _p(out, C.c_int32))
+            assert bad == 0, (W, BS)
+            assert sorted(out.tolist()) == list(range(W * BS)), (W, BS)
+            cells = out.reshape(BS, W)
+            for gi in range((W + 3) // 4):
+                gw = min(4, W - 4 * gi)
+                grp = cells[:, 4 * gi:4 * gi + gw]
+                assert (np.diff(grp, axis=1) == 1).all()
+                if gw == 4:
+                    assert (grp[:, 0] % 4 == 0).all()

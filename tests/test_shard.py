@@ -272,9 +272,9 @@ def _bg_lace_worker(rank, world, port, q):
         got = sm.smooth_gfa(S.default_params(**kw), prov.provider())
         if rank == 0:
             single = S.Smoother(text, tb).smooth_gfa(S.default_params(**kw), H.OracleProvider().provider())
-            if not (got is not None and got == single and stats["asked"] == 2 and 0 < stats["built"] < sm.n_blocks):
+            if not (got is not None and got == single and stats["asked"] == 3 and 0 < stats["built"] < sm.n_blocks):
                 print("MISMATCH", tb, kw, got == single, stats, sm.n_blocks, flush=True)
-            ok = ok and got is not None and got == single and stats["asked"] == 2 and 0 < stats["built"] < sm.n_blocks
+            ok = ok and got is not None and got == single and stats["asked"] == 3 and 0 < stats["built"] < sm.n_blocks
         else:
             ok = ok and got is None
     q.put((rank, bool(ok)))
