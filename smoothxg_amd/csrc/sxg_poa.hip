@@ -775,6 +775,7 @@ struct PinPool {
         std::lock_guard<std::mutex> g(mu);
         for (auto& b : bufs) if (b.p == p) b.busy = false;
     }
+    void prewarm(size_t bytes) { if (void* p = acquire(bytes)) release(p); }   // (pin now, lend later)
     ~PinPool() { for (auto& b : bufs) (void)hipHostFree(b.p); }
 };
 struct sxg_poa_handle {
@@ -802,6 +803,7 @@ struct sxg_poa_handle {
     // block graphs (want_block_graph): inputs, outputs in per-block layouts, the per-block counts of the last execute
     int want_block_graph = 0, bg_cons_visited_only = 0;
     std::shared_ptr<PinPool> pins;   // pinned host buffers lent to results (created with the handle)
+    std::thread pin_thread;          // pins the buffer of the coming download while the kernels run (joined before it is needed)
     bool bg_done = false;
     DevBuf d_trim, d_bg_no, d_bg_eo, d_bg_len, d_bg_od, d_bg_id, d_bg_seq, d_bg_eto, d_bg_steps, d_bg_nsteps, d_bg_cons, d_bg_counts,
         d_bg_work, d_bg_queue, d_bg_arena;
@@ -874,6 +876,7 @@ static void release_all(sxg_poa_handle* h) {
 extern "C" void sxg_poa_comm_destroy(sxg_poa_handle* h);
 extern "C" void sxg_poa_destroy(sxg_poa_handle* h) {
     if (!h) return;
+    if (h->pin_thread.joinable()) h->pin_thread.join();
     (void)hipSetDevice(h->device);
     sxg_poa_comm_destroy(h);
     h->d_blob.release(); h->d_recv.release(); h->d_counts.release();
@@ -1478,6 +1481,14 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             prio_base += (int)((plans[i].n_slots + h->num_cu - 1) / std::max(h->num_cu, 1));
         }
         HIPCHK(hipEventRecord(h->ev1, h->stream));
+        // While the kernels run: pin the host buffer the step lists will be downloaded into (first call of a handle, or a
+        // bigger batch than before; afterwards the pool already has it).  n_bases bounds the number of steps.
+        if (attempt == 0 && h->want_block_graph && h->pins && h->n_bases >= ((int64_t)16 << 20) && !getenv("SXG_POA_NO_PINNED")) {
+            if (h->pin_thread.joinable()) h->pin_thread.join();
+            h->pin_thread = std::thread([pool = h->pins, dev = h->device, bytes = 4 * (size_t)h->n_bases] {
+                if (hipSetDevice(dev) == hipSuccess) pool->prewarm(bytes);
+            });
+        }
         HIPCHK(hipStreamSynchronize(h->stream));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -1727,6 +1738,7 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
         GB_(int32_t, src_eo, h->d_bg_eto, o->bg_edge_off, o->bg_edge_to)
         {   // the step lists: into a borrowed pinned buffer when the pool has one (see PinPool)
             const int64_t total = blk_steps[nb];
+            if (h->pin_thread.joinable()) h->pin_thread.join();
             if (total >= ((int64_t)16 << 20) && h->pins && !getenv("SXG_POA_NO_PINNED")) {
                 if (void* q = h->pins->acquire(4 * (size_t)total)) { o->pin_pool = h->pins; o->bg_steps_pinned = (int32_t*)q; }
             }
