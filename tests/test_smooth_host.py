@@ -808,3 +808,30 @@ def test_repeat_aware_cut_length_of_break_blocks():
     blocks2 = SO.break_blocks(g, SO.smoothable_blocks(g, 4000 * 4, 4000, 100, 0), 2000)
     assert got == SO.smooth(g, blocks2)
     sm.close()
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_validation_catches_a_corrupted_block(legacy, monkeypatch):
+    """Every laced path must spell its original sequence (src/main.cpp:770-810).  A provider whose POA result has one
+    letter wrong -- a node that paths visit, turned into another base -- must make the iteration fail with the path's
+    name, on the flat path (run-wise comparison of consecutive node ids) and on the laced-graph path."""
+    class Corrupting(OracleProvider):
+        def _run(self, ctx, pin, pout):
+            rc = OracleProvider._run(self, ctx, pin, pout)
+            arrs = self.keep[-1]
+            code, paths = arrs["node_code"], arrs["paths"]
+            if len(paths) > 40:
+                v = int(paths[len(paths) // 2])        # (a node of the first block that a path steps on)
+                code[v] = (int(code[v]) + 1) % 4
+            return rc
+    if legacy:
+        monkeypatch.setenv("SXG_SMOOTH_LEGACY", "1")
+    else:
+        monkeypatch.delenv("SXG_SMOOTH_LEGACY", raising=False)
+    sm = S.Smoother(haplotype_gfa(2, n_paths=5, length=900), target_bp=300)
+    p = S.default_params()
+    good = sm.smooth_gfa(p, OracleProvider().provider())
+    assert good.startswith("H\tVN:Z:1.0")
+    with pytest.raises(S.SmoothError, match="corrupted"):
+        sm.smooth_gfa(p, Corrupting().provider())
+    sm.close()
