@@ -44,6 +44,8 @@ def test_random_blocks_random_scores_per_block(engine, seed):
         m, n, g, e, q, c = random_scores(rng)
         mode = int(rng.integers(0, 2))
         banded = int(rng.integers(0, 3)) if mode == 0 else 0
+        if mode == 1 and L <= 300 and trial % 2 == 1:
+            banded = 2   # abPOA's band in global mode (round 4); short enough for every score set to stay in the packed range
         blocks.append(seqs)
         weights.append(rng.integers(1, 6, len(seqs)).astype(np.uint32))
         gp.append(Params(m, n, g, e, q, c, mode, banded))
