@@ -106,6 +106,13 @@ template <int W>
 __device__ __forceinline__ unsigned plane_cell_byte(const int BS, const unsigned slot, const int k) {
     return (unsigned)plane_cell_in_row(W, BS, (int)slot, k) * 4u;
 }
+// Cache policy of the plane stores: NON-TEMPORAL (aux bit 1 = nt).  The plane is written once per row and read back by the
+// traceback for ~1 % of its cells (the banded sweep: by 40 % of the rows, a few rows later); streamed past the L2 it stops evicting
+// the ring rows and descriptors that ARE re-read.  Same box, one gpurun call: headline 1 987 -> 1 922 ms, c3b 1 400 -> 1 514
+// blocks/s, c2 +5 %.  (nt on the ring stores as well: +-0 on the headline; nt on the banded sweep's plane LOADS: c3b -2 %.)
+#ifndef SXG_PLANE_AUX
+#define SXG_PLANE_AUX 2
+#endif
 // one strip of a row: cell(k) -> the dword of column k; rs = the row's descriptor
 template <int W, int GI, class F>
 __device__ __forceinline__ void plane_store_group(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, F& cell) {
@@ -121,13 +128,13 @@ __device__ __forceinline__ void plane_store_group(const __amdgpu_buffer_rsrc_t r
     return;
 #endif
     if constexpr (gw == 4)
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{cell(k), cell(k + 1), cell(k + 2), cell(k + 3)}, rs, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{cell(k), cell(k + 1), cell(k + 2), cell(k + 3)}, rs, vo, 0, SXG_PLANE_AUX);
     else if constexpr (gw == 3)
-        __builtin_amdgcn_raw_buffer_store_b96(u32x3{cell(k), cell(k + 1), cell(k + 2)}, rs, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(u32x3{cell(k), cell(k + 1), cell(k + 2)}, rs, vo, 0, SXG_PLANE_AUX);
     else if constexpr (gw == 2)
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{cell(k), cell(k + 1)}, rs, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{cell(k), cell(k + 1)}, rs, vo, 0, SXG_PLANE_AUX);
     else
-        __builtin_amdgcn_raw_buffer_store_b32(cell(k), rs, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(cell(k), rs, vo, 0, SXG_PLANE_AUX);
 }
 template <int W, class F, int... GI>
 __device__ __forceinline__ void plane_store_groups(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, F& cell, std::integer_sequence<int, GI...>) {
