@@ -1403,17 +1403,12 @@ int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params
             const char* bs = B.seq;
             const uint32_t* so = B.soff;
             if (!v.rv) {
-                // (a path walks a topologically numbered block mostly through CONSECUTIVE ids, and consecutive nodes lie side by
-                //  side in the block's sequence bytes: one comparison per run of ids instead of two offset look-ups and a byte
-                //  loop per step)
-                for (int64_t j = 0; j < v.cnt;) {
-                    int64_t j2 = j;
-                    while (j2 + 1 < v.cnt && v.st[j2 + 1] == v.st[j2] + 1) ++j2;
-                    const uint32_t a0 = so[v.st[j]], a1 = so[v.st[j2] + 1];
+                // (comparing whole runs of consecutive ids with memcmp -- consecutive nodes lie side by side in the block's bytes --
+                //  was measured on the box: 0.060 s against 0.042 s for this loop; the runs are a few bases long)
+                for (int64_t j = 0; j < v.cnt; ++j) {
+                    const uint32_t a0 = so[v.st[j]], a1 = so[v.st[j] + 1];
                     if (at + (a1 - a0) > on) { ok = false; break; }
-                    ok &= memcmp(bs + a0, ob + at, (size_t)(a1 - a0)) == 0;
-                    at += a1 - a0;
-                    j = j2 + 1;
+                    for (uint32_t y = a0; y < a1; ++y) ok &= bs[y] == ob[at++];
                 }
             } else {
                 for (int64_t j = v.cnt - 1; j >= 0; --j) {
