@@ -1485,9 +1485,11 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         // bigger batch than before; afterwards the pool already has it).  n_bases bounds the number of steps.
         if (attempt == 0 && h->want_block_graph && h->pins && h->n_bases >= ((int64_t)16 << 20) && !getenv("SXG_POA_NO_PINNED")) {
             if (h->pin_thread.joinable()) h->pin_thread.join();
-            h->pin_thread = std::thread([pool = h->pins, dev = h->device, bytes = 4 * (size_t)h->n_bases] {
-                if (hipSetDevice(dev) == hipSuccess) pool->prewarm(bytes);
-            });
+            try {
+                h->pin_thread = std::thread([pool = h->pins, dev = h->device, bytes = 4 * (size_t)h->n_bases] {
+                    if (hipSetDevice(dev) == hipSuccess) pool->prewarm(bytes);
+                });
+            } catch (...) {}   // (no thread: the download pins, or falls back to pageable memory, itself)
         }
         HIPCHK(hipStreamSynchronize(h->stream));
         float ms = 0;
