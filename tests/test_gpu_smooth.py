@@ -296,3 +296,33 @@ def test_sharded_runs_carry_block_graphs_built_by_the_owning_rank(engine):
         sm.close()
     finally:
         engine.lib.sxg_poa_comm_destroy(engine.h)
+
+
+def test_step_lists_through_the_pinned_pool_equal_the_pageable_download(engine, monkeypatch):
+    """From 16 M steps on, the step lists of the block graphs are downloaded into a pinned buffer that the handle lends to
+    the result (PinPool; pinned in the background while the kernels run) and takes back when the result is freed.  Two
+    runs in a row (the second borrows the same buffer) and a run with SXG_POA_NO_PINNED=1 must give the same block graphs."""
+    import numpy as np
+    import smoothxg_amd as SX
+    from smoothxg_amd import synth
+    bases, seq_off, blk_off = synth.make_batch(80, 64, 5000)     # 25.6 M bases, ~0.8 steps per base at this depth: past the pool's 16 M steps
+    prm = SX.Params(1, -4, -6, -2, -26, -1, 0, 0)
+
+    def digest(res):
+        import hashlib
+        h = hashlib.sha256()
+        for r in res:
+            assert r.status == 0 and r.paths is None
+            for p in r.bg.paths:
+                h.update(np.ascontiguousarray(p, np.int32).tobytes())
+            h.update("".join(r.bg.node_seq).encode())
+        return h.hexdigest()
+
+    monkeypatch.delenv("SXG_POA_NO_PINNED", raising=False)
+    first = engine.run_flat(bases, seq_off, blk_off, None, prm, block_graph=3)
+    assert sum(len(p) for r in first for p in r.bg.paths) >= (16 << 20)
+    a = digest(first)
+    b = digest(engine.run_flat(bases, seq_off, blk_off, None, prm, block_graph=2))
+    monkeypatch.setenv("SXG_POA_NO_PINNED", "1")
+    c = digest(engine.run_flat(bases, seq_off, blk_off, None, prm, block_graph=2))
+    assert a == b == c
