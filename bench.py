@@ -40,6 +40,8 @@ WORKLOADS = {
     # config 4 is 50 000 mixed blocks over 8 GPUs: 6 250 per GPU; seqs/length are drawn per block (synth mixed=True)
     "c4": (6250, 0, 0, (1, -4, -6, -2, -26, -1), "config 4: mixed blocks, 8-128 seqs x 0.5-10 kbp, 6250 per GPU, convex 1,4,6,2,26,1"),
     "tiny": (64, 8, 400, (1, -4, -6, -2, -26, -1), "smoke: 64 blocks x 8 seqs x 400 bp"),
+    # configs 1 / 5: the reference's own ctest on its DRB1 input (CMakeLists.txt:565; timed whole in test/performance/check.md)
+    "drb1": (0, 0, 0, (1, -4, -6, -2, -26, -1), "DRB1-3123 seqwish GFA, three chained iterations -l 700,900,1100 -j 5k -e 5k -r 12 (the reference's ctest)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # VALU issue roof of the packed sweep.  256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD's issue port for
@@ -270,6 +272,104 @@ def profile_counters(key):
     w["matches_build"] = j.get("source_sha256") == source_hash()
     return w
 
+# fixture names of the blocks tests/golden/fullshape_oracle.json holds for a bench workload: (workload, mode) -> case name
+FIXTURE_CASE = {("ns", "sw"): "ns_sw", ("ns", "nw"): "ns_nw", ("c3", "sw"): "c3", ("c2", "sw"): "c2"}
+
+
+def digest_block(r):
+    """SHA-256 digests of one downloaded block, as tests/golden/make_fullshape.py::digest_block computes them."""
+    import hashlib
+
+    def sha(a, dt):
+        return hashlib.sha256(np.ascontiguousarray(np.asarray(a, dt)).tobytes()).hexdigest()
+    return {"node_code": sha(r.node_code, np.uint8), "node_rank": sha(r.node_rank, np.int32), "node_group": sha(r.node_group, np.int32),
+            "edge_tail": sha(r.edge_tail, np.int32), "edge_head": sha(r.edge_head, np.int32), "edge_weight": sha(r.edge_weight, np.uint32),
+            "paths": sha(np.concatenate([np.asarray(q, np.int32) for q in r.paths]) if len(r.paths) else np.zeros(0, np.int32), np.int32)}
+
+
+def verify_against_fixture(res, workload, mode, first_block, prm):
+    """The timed batch checked against COMMITTED oracle output (tests/golden/fullshape_oracle.json: scores of every sequence,
+    node / edge counts, cells, SHA-256 of nodes, ranks, groups, edges, weights, per-base paths) for the blocks of the batch
+    the fixture holds -- blocks 0 and 999 of the headline and of config 2, 0 and 4999 of config 3.  No oracle code runs.
+    Returns (verified, block ids, note); a mismatch raises."""
+    name = FIXTURE_CASE.get((workload, mode))
+    if name is None:
+        return None, [], "no committed full-shape fixture for this workload / mode"
+    cases = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "fullshape_oracle.json")))["cases"]
+             if c["name"] == name and list(c["params"]) == list(prm)]
+    done = []
+    for c in cases:
+        k = c["block_id"] - first_block
+        if k < 0 or k >= len(res):
+            continue
+        r = res[k]
+        label = "bench verification failed: %s block %d: " % (name, c["block_id"])
+        if r.status != 0:
+            raise SystemExit(label + "status %d" % r.status)
+        if [int(x) for x in r.scores] != c["scores"]:
+            raise SystemExit(label + "scores differ from the committed oracle output")
+        if int(np.asarray(r.cells, np.uint64).sum()) != c["cells"] or len(r.node_code) != c["n_nodes"] or len(r.edge_tail) != c["n_edges"]:
+            raise SystemExit(label + "cells / node count / edge count differ")
+        got = digest_block(r)
+        for key, want in c["digests"].items():
+            if key in got and got[key] != want:
+                raise SystemExit(label + key + " differs from the committed oracle output")
+        done.append(c["block_id"])
+    if not done:
+        return None, [], "none of the fixture's blocks is in this batch"
+    return True, done, "scores of all sequences, cells, node/edge counts and SHA-256 of nodes, ranks, groups, edges, weights, paths == tests/golden/fullshape_oracle.json"
+
+
+def bench_drb1(a, local_rank):
+    """Configs 1 / 5 as the reference's ctest runs them (CMakeLists.txt:565): THREE chained smoothing iterations
+    (-l 700,900,1100 -j 5k -e 5k -r 12) on test/data's DRB1-3123 seqwish GFA (committed as tests/golden/DRB1-3123.seqwish.gfa),
+    every iteration = block discovery on the previous GFA + collection + ONE batched POA call + lacing + GFA text, consensus
+    paths in the last.  A step is one whole chain; the value is its wall time in seconds (the only number the reference
+    publishes: 23-25 s for its whole run, test/performance/check.md:7-28 -- that run also writes a MAF and builds the
+    consensus graph, which this path does not, so vs_baseline stays null).  Every iteration's GFA is compared with the SHA-256
+    pinned in tests/golden/drb1_chain.json."""
+    import hashlib
+    import smoothxg_amd as S
+    from smoothxg_amd import smooth as SM
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "drb1_chain.json")))["iterations"]
+    text0 = open(os.path.join(ROOT, "tests", "golden", "DRB1-3123.seqwish.gfa")).read()
+    eng = S.PoaEngine(local_rank)
+    prov = SM.gpu_provider(eng)
+
+    def chain():
+        text, per, shas, kms, blocks = text0, [], [], [], []
+        for it, tl in enumerate((700, 900, 1100)):
+            t0 = time.perf_counter()
+            sm = SM.Smoother(text, discover=dict(target_poa_length=tl, n_haps=12, max_path_jump=5000, max_edge_jump=5000))
+            blocks.append(sm.n_blocks)
+            text = sm.smooth_gfa(SM.default_params(add_consensus=1 if it == 2 else 0), prov)
+            sm.close()
+            per.append(time.perf_counter() - t0)
+            kms.append(eng.stats()["kernel_ms"])
+            shas.append(hashlib.sha256(text.encode()).hexdigest())
+        return per, shas, kms, blocks
+    for _ in range(a.warmup):
+        chain()
+    t0 = time.perf_counter()
+    runs = [chain() for _ in range(a.steps)]
+    dt = time.perf_counter() - t0
+    ok = all(r[1] == [g["sha256"] for g in gold] for r in runs)
+    if not ok:
+        raise SystemExit("bench verification failed: a DRB1 iteration's GFA differs from tests/golden/drb1_chain.json")
+    per = [sum(r[0][k] for r in runs) / len(runs) for k in range(3)]
+    kms = [sum(r[2][k] for r in runs) / len(runs) for k in range(3)]
+    out = {"metric": "wall seconds of the reference's ctest chain on DRB1-3123 (three smoothing iterations)", "value": dt / a.steps, "unit": "s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": False, "scaling": "weak",
+           "vs_baseline": None, "dtype": "int16", "data": "tests/golden/DRB1-3123.seqwish.gfa (the reference's test/data input)",
+           "config": {"workload": WORKLOADS["drb1"][4], "blocks_per_iteration": runs[0][3], "mode": "sw"},
+           "iteration_seconds": per, "iteration_kernel_ms": kms,
+           "verified": True, "verified_what": "SHA-256 of every iteration's GFA == tests/golden/drb1_chain.json (oracle stack)",
+           "reference_published": "23.4-25.5 s wall for the reference's whole run of this input on a Ryzen 7 3700X (test/performance/check.md:7-28; "
+                                  "includes MAF output and the consensus graph, which are outside this path)",
+           "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out))
+    eng.close()
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -284,6 +384,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sxg_smooth_gfa measurement")
     ap.add_argument("--check", action="store_true", help="also verify 2 blocks against the oracle")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed batch's fixture blocks with tests/golden/fullshape_oracle.json")
     ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
                     help="N > 1: the hand-off of every step's results to rank 0 -- cabi: sxg_poa_batch_execute_sharded (the C ABI's own RCCL "
                          "communicator: counts all-gathered, one grouped ncclSend/ncclRecv per peer); torch: shard.RootGather "
@@ -305,6 +406,10 @@ def main():
     from smoothxg_amd import synth
     from smoothxg_amd import shard
 
+    if a.workload == "drb1":
+        if world > 1:
+            raise SystemExit("--workload drb1 is a single-GPU measurement (2000 small blocks per iteration)")
+        return bench_drb1(a, local_rank)
     nb, ns, ln, prm, desc = WORKLOADS[a.workload]
     if a.blocks:
         nb = a.blocks
@@ -405,6 +510,16 @@ def main():
         total_cells = float(cells)
     st = eng.stats()
 
+    # The number printed below is worth something only if the batch it timed is right: the blocks of the batch that the
+    # committed full-shape fixture holds are downloaded and compared (outside the timed region; no oracle code involved).
+    verified, verified_blocks, verified_note = None, [], "skipped (--no-verify)"
+    if rank == 0 and not a.no_verify:
+        if strong and exchange == "cabi":
+            verified_note = "strong scaling deals the blocks over the ranks: not checked here"
+        else:
+            vres = eng.download()
+            verified, verified_blocks, verified_note = verify_against_fixture(vres, a.workload, a.mode, 0, prm)
+            del vres
     if a.check and rank == 0:
         from oracle import oracle_py as O
         res = eng.download_sharded() if (strong and exchange == "cabi") else eng.download()
@@ -477,6 +592,38 @@ def main():
                          "algorithmic_frac": (min_ipc / exe_ipc) * valu_frac if exe_ipc else None,
                          "insts_per_cell_unit": "wave instructions x 128 cells / cells of the step"})
         valu_peak = simd_cycles_per_s
+        # Which roof binds: the one the launch sits closest to.  The packed full-matrix sweeps of the headline and of config 2
+        # are bound by VALU issue; config 3's full matrix and the banded (-A) sweeps move more bytes per instruction and sit
+        # closer to the HBM roof (counter bytes: FETCH_SIZE / WRITE_SIZE in their own passes, corrected as the guide prescribes).
+        hbm_counter_frac = hbm.get("counter_frac_of_peak")
+        hbm_bound = hbm_counter_frac is not None and (valu_frac is None or hbm_counter_frac > valu_frac)
+        roof = {"bound": "hbm" if (hbm_bound or valu_frac is None) else "valu"}
+        if roof["bound"] == "valu":
+            roof.update({"achieved": valu_rate / 1e9, "peak": valu_peak / 1e9, "unit": "G VALU issue cycles/s", "frac": valu_frac})
+        elif hbm_bound:
+            roof.update({"achieved": hbm["counter_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_counter_frac,
+                         "achieved_is": "HBM bytes the counters measured per second of kernel time (the 8(d) model's bytes are in hbm_8d_frac)"})
+        else:
+            roof.update({"achieved": algo_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo_gbs / HBM_PEAK_GBS,
+                         "achieved_is": "SURVEY 8(d) algorithmic bytes per second (no counters committed for this workload)"})
+        roof.update({
+            # every roof side by side, whatever binds:
+            "valu_frac": valu_frac,                                   # issue cycles of the executed VALU instructions / SIMD cycles
+            "algorithmic_frac": valu.get("algorithmic_frac"),         # ... counting only the recurrence's own instructions
+            "hbm_counter_frac": hbm_counter_frac,                     # measured HBM bytes / s over the 8 TB/s peak
+            "hbm_8d_frac": algo_gbs / HBM_PEAK_GBS,                   # SURVEY 8(d)'s 13 (9) B per cell / s over the peak
+            "hbm_8d_frac_is": "NOT an achieved fraction and not binding: rows whose only predecessor is the previous rank stay in "
+                              "registers and short-lived rows in LDS, so the sweep moves fewer bytes than the 8(d) model charges",
+            "traffic": traffic,
+            "kernel": "poa_block_kernel<T=%d, cols/lane=%d, %s>" % (
+                st["dom_threads"], st["dom_cols_per_lane"],
+                {2: "packed int16 sweep", 3: "banded packed int16 sweep (one wave, sliding window)"}.get(st["dom_row_mode"], "32-bit sweep")),
+            "kernel_ms_per_launch": kernel_ms / max(a.steps, 1), "kernel_ms_total": kernel_ms,
+            "launches_per_step": launches_per_step,
+            "per_launch_means": "per step: every dispatch of one pass over the batch (launches of different geometries run side by side)",
+            "algo_bytes_per_launch": algo_bytes / max(a.steps, 1),
+            "bytes_per_cell": algo_bytes / max(cells, 1),
+            "valu": valu, "hbm": hbm})
         out = {
             "metric": "POA blocks/sec (+ DP cells/sec) on 1000-block synthetic",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -485,26 +632,13 @@ def main():
             "config": {"workload": desc, "blocks_per_gpu": nb, "mode": a.mode,
                        "cells_per_step_per_gpu": cells / a.steps},
             "cells_per_sec": total_cells / dt,
+            "verified": verified, "verified_blocks": verified_blocks, "verified_what": verified_note,
             # The binding roof of this kernel is VALU issue, not HBM: the sweep keeps adjacent-rank rows in
             # registers and moves about half of SURVEY 8(d)'s 13 B/cell, so the 8(d) figure alone exceeds the HBM
             # peak (hbm.algo_frac_of_peak > 1 is NOT an achieved fraction).  frac = architectural issue cycles of the
             # VALU instructions executed per second / SIMD cycles per second (1024 SIMDs x measured clock);
             # hbm.counter_* is what FETCH_SIZE/WRITE_SIZE measured.
-            "roofline": {"bound": "valu" if valu_frac is not None else "hbm",
-                         "achieved": (valu_rate / 1e9) if valu_rate is not None else algo_gbs,
-                         "peak": (valu_peak / 1e9) if valu_rate is not None else HBM_PEAK_GBS,
-                         "unit": "G VALU issue cycles/s" if valu_rate is not None else "GB/s",
-                         "frac": valu_frac if valu_frac is not None else algo_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "kernel": "poa_block_kernel<T=%d, cols/lane=%d, %s>" % (
-                             st["dom_threads"], st["dom_cols_per_lane"],
-                             {2: "packed int16 sweep", 3: "banded packed int16 sweep (one wave, sliding window)"}.get(st["dom_row_mode"], "32-bit sweep")),
-                         "kernel_ms_per_launch": kernel_ms / max(a.steps, 1), "kernel_ms_total": kernel_ms,
-                         "launches_per_step": launches_per_step,
-                         "per_launch_means": "per step: every dispatch of one pass over the batch (launches of different geometries run side by side)",
-                         "algo_bytes_per_launch": algo_bytes / max(a.steps, 1),
-                         "bytes_per_cell": algo_bytes / max(cells, 1),
-                         "valu": valu, "hbm": hbm},
+            "roofline": roof,
             "engine": {"slots": st["n_slots"], "retries": st["retries"], "arena_bytes": st["device_bytes"]},
             "exchange": ({"path": "C ABI: sxg_poa_batch_execute_sharded (RCCL all-gather of sizes + grouped ncclSend/ncclRecv to rank 0)"
                           if exchange == "cabi" else exchange, **(eng.sharded_info() if exchange == "cabi" else {})} if world > 1 else None),

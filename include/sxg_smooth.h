@@ -32,14 +32,17 @@ extern "C" {
 typedef struct sxg_graph sxg_graph;       /* input graph: node sequences + paths (XG's role) */
 typedef struct sxg_blockset sxg_blockset; /* blockset_t: blocks of path ranges, src/blocks.hpp:29-120 */
 
-/* POA provider: exactly sxg_poa_batch_run's contract, ctx is its handle. */
+/* POA provider: exactly sxg_poa_batch_run's contract, ctx is its handle.  Both callbacks are only called while the
+ * sxg_* entry point they were passed to is running -- `run` possibly from a worker thread of that call (one call at a
+ * time), `free` on the calling thread, once per successful `run`, before the entry point returns: callbacks and ctx
+ * need not outlive the call. */
 typedef int (*sxg_poa_run_fn)(void *ctx, const sxg_poa_batch_in *in, sxg_poa_batch_out *out);
 typedef void (*sxg_poa_free_fn)(sxg_poa_batch_out *out);
 
 /* smoothxg's knobs on this path with their defaults (src/main.cpp:291-361,487). */
 /* 2: sxg_smooth_params starts with struct_size (set by sxg_smooth_default_params, checked by every entry point: a caller
  *    built against another header gets SXG_E_INVALID instead of fields read from whatever follows its struct) and ends
- *    with abpoa_band_local; scores whose engine form leaves int8 are rejected. */
+ *    with poa_spoa_order; scores whose engine form leaves int8 are rejected. */
 #define SXG_SMOOTH_ABI_VERSION 2
 int sxg_smooth_abi_version(void);
 

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libsxgpoa.so")
 SOURCES = ["sxg_poa.hip"]
-DEPS = SOURCES + ["poa_dp.hip.h", "poa_dp16.hip.h", "poa_band16.hip.h", "poa_graph_dev.h", "poa_types.h",
+DEPS = SOURCES + ["poa_dp.hip.h", "poa_dp16.hip.h", "poa_band16.hip.h", "poa_graph_dev.h", "poa_bgraph_dev.h", "poa_types.h",
                   os.path.join("..", "..", "include", "sxg_poa.h")]
 
 

@@ -255,7 +255,7 @@ SXG_HD_PHASE void block_graph(Ctx& c, const BgIn I, const BgScratch W, const BgO
         for (int pass = 0; pass < 2; ++pass) {
             int hn = 0, k = 0;
             bool over = false;
-            if (pass == 1) { h = (int*)W.tmp; for (int ci = 0; ci < nc; ++ci) W.indc[ci] = W.indeg[W.head_of[ci]]; }   // (the ready set outgrew the fast scratch: again, in HBM)
+            if (pass == 1) { h = (int*)W.tmp; for (int ci = 0; ci < nc; ++ci) W.indc[ci] = c.load_fresh(&W.indeg[W.head_of[ci]]); }   // (the ready set outgrew the fast scratch: again, in HBM)
             const int lim = pass == 0 ? cap : nc + 1;
             for (int ci = 0; ci < nc && !over; ++ci) if (W.indc[ci] == 0) { if (hn >= lim) over = true; else h[hn++] = ci; }   // (ascending: already a heap)
             while (hn > 0 && !over) {

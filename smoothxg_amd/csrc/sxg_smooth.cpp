@@ -1402,16 +1402,26 @@ int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params
             bool ok = true;
             const char* bs = B.seq;
             const uint32_t* so = B.soff;
+            // (the step lists come from the provider: every step must name a node of its block, and a sequence's steps must be
+            //  strictly ascending -- the block graph is topologically numbered and its paths walk forward; the size pass of the
+            //  text writer relies on it when it looks steps up by binary search)
+            const uint64_t nB = (uint64_t)B.n;
+            int64_t prev = -1;
             if (!v.rv) {
                 // (comparing whole runs of consecutive ids with memcmp -- consecutive nodes lie side by side in the block's bytes --
                 //  was measured on the box: 0.060 s against 0.042 s for this loop; the runs are a few bases long)
                 for (int64_t j = 0; j < v.cnt; ++j) {
+                    if ((uint64_t)(uint32_t)v.st[j] >= nB || (int64_t)v.st[j] <= prev) { ok = false; break; }
+                    prev = v.st[j];
                     const uint32_t a0 = so[v.st[j]], a1 = so[v.st[j] + 1];
                     if (at + (a1 - a0) > on) { ok = false; break; }
                     for (uint32_t y = a0; y < a1; ++y) ok &= bs[y] == ob[at++];
                 }
             } else {
+                prev = (int64_t)nB;
                 for (int64_t j = v.cnt - 1; j >= 0; --j) {
+                    if ((uint64_t)(uint32_t)v.st[j] >= nB || (int64_t)v.st[j] >= prev) { ok = false; break; }
+                    prev = v.st[j];
                     const uint32_t a0 = so[v.st[j]], a1 = so[v.st[j] + 1];
                     if (at + (a1 - a0) > on) { ok = false; break; }
                     for (uint32_t y = a1; y > a0; --y) ok &= comp(bs[y - 1]) == ob[at++];
@@ -2111,7 +2121,7 @@ struct reaper_t {
         std::lock_guard<std::mutex> lk(mu);
         if (th.joinable()) th.join();
         if (getenv("SXG_SMOOTH_NO_REAPER")) { fn(); return; }
-        th = std::thread(std::move(fn));
+        try { th = std::thread(fn); } catch (...) { fn(); }   // (thread creation failed: inline)
     }
     ~reaper_t() { if (th.joinable()) th.join(); }
 };
@@ -2319,19 +2329,25 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
     }
     if (fast) {
         const int rc = lace_fast(g, b, p, cblocks, out_gfa, lap);
-        // The block graphs and the providers' results (1 GB of steps on the headline batch) are released behind the
-        // caller's back: unmapping them is not on anybody's critical path.  The reaper is joined by the next iteration
-        // (and when the library is unloaded).
+        // The providers' results go back to the provider HERE, on the caller's thread, before the call returns: the free
+        // callback and its context need only live for the call (sxg_poa_free_fn, include/sxg_smooth.h), and a pinned
+        // download buffer is back in its pool before the next iteration asks for one.  What the library itself owns -- the
+        // compact block graphs (views, never dereferenced again), the collected sequences, the chunks' host arrays -- is
+        // released behind the caller's back: unmapping it is on nobody's critical path.  The reaper is joined by the next
+        // iteration (and when the library is unloaded); without a thread the release happens inline.
+        for (auto& C : chunks) if (C.keep_out && fre) { fre(&C.out); C.keep_out = false; }
         {
             struct grave_t { std::vector<cblock_t> cb; std::vector<chunk_t> ch; std::vector<collected_t> col; };
-            auto* graveyard = new grave_t();
-            graveyard->cb.swap(cblocks);
-            graveyard->ch.swap(chunks);
-            graveyard->col.swap(col);
-            reap([graveyard, fre]() {
-                for (auto& C : graveyard->ch) if (C.keep_out && fre) fre(&C.out);
+            grave_t* graveyard = nullptr;
+            try {
+                graveyard = new grave_t();
+                graveyard->cb.swap(cblocks);
+                graveyard->ch.swap(chunks);
+                graveyard->col.swap(col);
+                reap([graveyard]() { delete graveyard; });
+            } catch (...) {   // (no memory for the grave, no thread: release inline -- a finished iteration stays finished)
                 delete graveyard;
-            });
+            }
         }
         lap("teardown");
         return rc;

@@ -27,6 +27,9 @@ def test_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    for k in ("valu_frac", "algorithmic_frac", "hbm_counter_frac", "hbm_8d_frac"):   # every roof side by side
+        assert k in r, k
+    assert "verified" in d and d["verified"] is None      # (no committed full-shape fixture for the smoke workload)
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -56,3 +59,32 @@ def test_headline_line_takes_the_valu_roof_from_the_committed_counters():
         assert r["traffic"] and r["traffic"] > 0
     assert r["hbm"]["algo_bytes_per_cell"] == 13.0
     assert d["dtype"] == "int16" and d["config"]["blocks_per_gpu"] == 1000
+    # the line certifies itself: blocks 0 and 999 of the timed batch against the committed oracle output
+    assert d["verified"] is True and d["verified_blocks"] == [0, 999]
+    assert r["valu_frac"] == r["frac"] and r["hbm_8d_frac"] > 1.0 and 0.0 < r["algorithmic_frac"] < r["frac"]
+
+
+def test_a_wrong_result_fails_the_bench(tmp_path):
+    """The verification is not decoration: with a fixture whose expected scores are off by one the bench exits non-zero."""
+    import shutil
+    fake = tmp_path / "repo"
+    shutil.copytree(ROOT, fake, ignore=shutil.ignore_patterns(".git", "gpurun_out", "profiles", "__pycache__", "*.o"))
+    fx = fake / "tests" / "golden" / "fullshape_oracle.json"
+    j = json.loads(fx.read_text())
+    for c in j["cases"]:
+        if c["name"] == "c2":
+            c["scores"][3] += 1
+    fx.write_text(json.dumps(j))
+    out = subprocess.run([sys.executable, str(fake / "bench.py"), "--workload", "c2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e"],
+                         capture_output=True, text=True, timeout=600, cwd=str(fake))
+    assert out.returncode != 0 and "bench verification failed" in (out.stderr + out.stdout)
+
+
+def test_drb1_workload_reports_wall_seconds_and_checks_every_iteration():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "drb1", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["unit"] == "s" and d["higher_is_better"] is False and d["verified"] is True
+    assert len(d["iteration_seconds"]) == 3 and abs(sum(d["iteration_seconds"]) - d["value"]) < 0.05 * d["value"] + 0.05
+    assert d["config"]["blocks_per_iteration"] == [2161, 2066, 2025]

@@ -28,8 +28,8 @@ def random_scores(rng):
     return m, n, g, e, q, c
 
 
-# SXG_FUZZ_SEEDS=<n>: a longer campaign (the default three seeds keep the suite short)
-@pytest.mark.parametrize("seed", [9001 + k for k in range(int(os.environ.get("SXG_FUZZ_SEEDS", "3")))])
+# SXG_FUZZ_SEEDS=<n>: a longer campaign (the default twelve seeds cost ~40 s on the GPU box)
+@pytest.mark.parametrize("seed", [9001 + k for k in range(int(os.environ.get("SXG_FUZZ_SEEDS", "12")))])
 def test_random_blocks_random_scores_per_block(engine, seed):
     rng = np.random.default_rng(seed)
     blocks, weights, gp, op = [], [], [], []
@@ -59,8 +59,8 @@ def test_random_blocks_random_scores_per_block(engine, seed):
         assert (res[b].consensus == g_.consensus()).all(), label
 
 
-# SXG_FUZZ_LONG=<n>: more seeds of the long-block campaign (default one)
-@pytest.mark.parametrize("seed", [9501 + k for k in range(int(os.environ.get("SXG_FUZZ_LONG", "1")))])
+# SXG_FUZZ_LONG=<n>: more seeds of the long-block campaign (default three)
+@pytest.mark.parametrize("seed", [9501 + k for k in range(int(os.environ.get("SXG_FUZZ_LONG", "3")))])
 def test_random_long_banded_blocks(engine, seed):
     """Blocks of 3-9 kbp (strip widths 8 and 11, a window that slides and re-centres) in the two banded modes, with
     structural variants of 100-900 bases that push the alignment to and beyond the edge of the band: HIP == oracle."""
