@@ -53,6 +53,7 @@ __device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(
 __device__ __forceinline__ int pk_sub(int a, int b) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); }
 __device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
 __device__ __forceinline__ int pk_mad(int a, int b, int c) { return __builtin_bit_cast(int, (s16x2)(__builtin_bit_cast(s16x2, a) * __builtin_bit_cast(s16x2, b) + __builtin_bit_cast(s16x2, c))); }
+__device__ __forceinline__ int pk_lshr(int a, int sh) { return __builtin_bit_cast(int, (u16x2)(__builtin_bit_cast(u16x2, a) >> __builtin_bit_cast(u16x2, sh))); }
 __device__ __forceinline__ int pk2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
 __device__ __forceinline__ int pk_lo(int v) { return (int)(short)(v & 0xffff); }
 __device__ __forceinline__ int pk_hi(int v) { return v >> 16; }
@@ -76,6 +77,38 @@ __device__ __forceinline__ void p16_unpack_row(u32x2 w, int& h, int& of, int& oo
     oo = BIASED ? (int)((unsigned)h - (unsigned)dq) : pk_sub(h, dq);
 }
 
+// ---- 2-byte plane cells (CB = 2, round 5) --------------------------------------------------------------------------
+// The band stores of the traceback plane were the largest single cost of the packed sweep (cost map of round 4: 24 % of the
+// headline launch; 45 % of the sweep of 8000 blocks of 16 x 1 kbp, where the launch sits at the HBM write roof).  A plane cell
+// held H (16 bits) and the two distances H - oF, H - oO (8 bits each).  H need not be stored in full: along a row it moves in
+// small steps --
+//     g <= H[i][j] - H[i][j-1] <= m - g        (g = the cheapest gap opening, normalised scores; proof in DESIGN.md section 3.1:
+//     the lower bound is the in-row gap E >= H[j-1] + g, the upper one follows by induction over the ranks from
+//     H[i][j-1] >= H[p][j-1] + g for the predecessor p a diagonal step into (i, j) came from)
+// -- and the distances lie in [-e, -g] and [-c, -q].  A cell is therefore the 16-bit code
+//     (H[j] - H[j-1] - g)  |  (H - oF + e) << bH  |  (H - oO + c) << (bH + bF),      bH + bF + bO <= 16,
+// and a strip of a row is W + 1 halfwords: the H of the column LEFT of the strip (the value the sweep hands from lane to
+// lane anyway; strip 0: H of column 0, whose own step is written as 0), then the W codes.  12 bits for the default scores
+// 1,4,6,2,26,1; 16 for pggb's asm10 set; a score set that needs more (asm5: 1,19,39,3,81,1 -- 20 bits) takes the 4-byte
+// cells (CB = 4: the round-4 format, every kernel class exists in both).  The traceback rebuilds H by summing the steps of
+// a strip from its left end -- at most W additions for a cell it visits.
+struct P16Delta {
+    int bH, bF, bO;      // field widths
+    int g, eabs, cabs;   // what the fields are offset by: dH - g, dF - |e|, dO - |c| are >= 0
+};
+__host__ __device__ inline int p16_bits_for(int n_values) { int b = 0; while ((1 << b) < n_values) ++b; return b; }
+__host__ __device__ inline P16Delta p16_delta_of(const Scoring& S) {
+    P16Delta D;
+    D.g = S.g; D.eabs = -S.e; D.cabs = -S.c;
+    D.bH = p16_bits_for(S.m - 2 * S.g + 1);
+    D.bF = p16_bits_for(S.e - S.g + 1);
+    D.bO = S.convex ? p16_bits_for(S.c - S.q + 1) : 0;
+    return D;
+}
+__host__ __device__ inline bool p16_delta_fits(const Scoring& S) { const P16Delta D = p16_delta_of(S); return D.bH + D.bF + D.bO <= 16; }
+// dwords of one strip of a row: W + 1 halfwords
+__host__ __device__ constexpr int p16_slot_dwords(int W, int CB) { return CB == 2 ? (W + 2) / 2 : W; }
+
 // Buffer addressing for the sweep's rows: address = descriptor base (one row of the ring / of the plane,
 // built per row with a few SALU instructions) + SGPR offset (column k of the strip) + ONE loop-invariant VGPR
 // offset (the lane).  With global_load/store the compiler formed 64-bit VGPR addresses per access
@@ -94,8 +127,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t p16_rsrc(const void* base, con
 // which covers 1 KB of consecutive memory per wave (round 4; rounds 1-3 had [column][slot]: W four-byte instructions of
 // 256 B each -- the packed sweep's band stores were 24 % of its launch, most of it instruction issue and the vmcnt they hold).
 // BS is a multiple of 4: rows and groups start on 16-byte boundaries.
+// (geometries of up to 1408 columns keep every strip: the band would cover most of the row anyway, and a plane that holds
+//  whole rows doubles as the row ring -- see ring_plane in dp_fill_p16)
 __host__ __device__ constexpr int p16_band_strips(int T, int W) {
-    return plane_round4((1100 + W - 1) / W) < 2 * T ? plane_round4((1100 + W - 1) / W) : 2 * T;
+    return 2 * T * W <= 1408 ? 2 * T : (plane_round4((1100 + W - 1) / W) < 2 * T ? plane_round4((1100 + W - 1) / W) : 2 * T);
 }
 template <int W>
 __device__ __forceinline__ size_t plane_cell(const size_t row, const int BS, const int slot, const int k) {
@@ -167,6 +202,19 @@ template <int W>
 __device__ __forceinline__ void plane_load_strip(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, unsigned (&out)[W]) {
     plane_load_groups<W>(rs, slot, BS, out, std::make_integer_sequence<int, (W + 3) / 4>{});
 }
+// one strip of a row through a plain pointer (the traceback: every lane its own row): group by group, as wide as the group
+template <int SDW>
+__device__ __forceinline__ void plane_load_slot(SXG_GLOBAL const uint32_t* const row, const int BS, const int slot, unsigned (&out)[SDW]) {
+#pragma unroll
+    for (int gi = 0; gi < (SDW + 3) / 4; ++gi) {
+        const int gw = SDW - 4 * gi >= 4 ? 4 : SDW - 4 * gi;
+        SXG_GLOBAL const uint32_t* const q = row + 4 * gi * BS + slot * gw;
+        if (gw == 4) { const u32x4 v = *(SXG_GLOBAL const u32x4*)q; out[4 * gi] = v.x; out[4 * gi + 1] = v.y; out[4 * gi + 2] = v.z; out[4 * gi + 3] = v.w; }
+        else if (gw == 3) { typedef u32x3 __attribute__((aligned(4))) u32x3_a4; const u32x3 v = *(SXG_GLOBAL const u32x3_a4*)q; out[4 * gi] = v.x; out[4 * gi + 1] = v.y; out[4 * gi + 2] = v.z; }
+        else if (gw == 2) { const u32x2 v = *(SXG_GLOBAL const u32x2*)q; out[4 * gi] = v.x; out[4 * gi + 1] = v.y; }
+        else out[4 * gi] = *q;
+    }
+}
 __device__ __forceinline__ int band_first_strip(const int hint_col, const int W, const int BS, const int T) {
     const int c = hint_col / W - (BS >> 1);
     return min(max(c, 0), 2 * T - BS);
@@ -182,7 +230,14 @@ __device__ __forceinline__ int band_first_strip(const int hint_col, const int W,
 // (the kernel runs it in front of the real one), so that the difference between two builds prices a part of the row:
 // 1 = no band stores, 2 = no ring stores, 4 = no end-cell bookkeeping, 8 = no carry scans, 16 = no mailbox exchange,
 // 32 = every row takes the register-predecessor path (no fetch, no fold), 64 = no pass 2, 128 = no pass 1.
-template <int W, bool CVX, bool SW, int EXP = 0>
+// CB: bytes per plane cell (2: delta codes, see P16Delta; 4: H | H - oF | H - oO).
+// End cell of a LOCAL alignment (round 5): every lane keeps, per strip, ONE 32-bit key -- the strip's greatest H so far in the
+// upper half, 0xffff minus the row that first reached it in the lower -- updated with a max per row (5 instructions; rounds 2-4
+// compared, voted and searched the strip's columns in every row that improved any lane, i.e. nearly every row of the waves the
+// best diagonal runs through: 15 % of the row on 1 kbp blocks).  Rows are numbered within epochs of 65536; at an epoch's end the
+// wave folds its keys into a scalar 64-bit best.  The sweep returns the STRIP of the end cell (bj = -(strip + 1)); the
+// traceback reads the column out of the plane row it starts from.
+template <int W, bool CVX, bool SW, int CB = 4, int EXP = 0>
 __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R, const int N_,
                                              const uint8_t* seq, const int L_, const DpBuffers B,
                                              char* smem) {
@@ -215,6 +270,23 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     const unsigned SC_N4 = (unsigned)(sn & 0xff) * 0x01010101u, SC_MX = (unsigned)((sm ^ sn) & 0xff);
     const int We = W * e, Wc = W * c;
     const int BS = __builtin_amdgcn_readfirstlane(B.band_strips);
+    constexpr int SD = p16_slot_dwords(W, CB);   // dwords of one strip in a plane row
+    // (CB = 2) the multipliers that shift a cell's two distances into their fields of the code
+    const P16Delta DF = p16_delta_of(S);
+    const int KF2 = pk2(1 << __builtin_amdgcn_readfirstlane(DF.bH), 1 << __builtin_amdgcn_readfirstlane(DF.bH));
+    const int KO2 = pk2(1 << __builtin_amdgcn_readfirstlane(DF.bH + DF.bF), 1 << __builtin_amdgcn_readfirstlane(DF.bH + DF.bF));
+    // ... and what reading a row back out of the plane needs (full-width planes only, see ring_plane below)
+    const int dbH_ = __builtin_amdgcn_readfirstlane(DF.bH), dbF_ = __builtin_amdgcn_readfirstlane(DF.bF);
+    const int D_SH1 = pk2(dbH_, dbH_), D_SH2 = pk2(dbH_ + dbF_, dbH_ + dbF_);
+    const int D_MH = pk2((1 << dbH_) - 1, (1 << dbH_) - 1), D_MF = pk2((1 << dbF_) - 1, (1 << dbF_) - 1);
+    const int d_cst_ = g + ((-e) << dbH_) + ((CVX ? -c : 0) << (dbH_ + dbF_));
+    const int D_CST = pk2(d_cst_, d_cst_);
+    const int D_EA = pk2(-e, -e), D_CA = pk2(-c, -c);
+    // A plane that keeps EVERY strip of every row (sequences up to ~1.4 kbp -- the blocks smoothxg's default -l 700 ... 1100
+    // produces --, the every-strip plane of a band-miss re-run) already holds what the row ring would: stored rows are not
+    // written a second time, a stored predecessor is read back from its plane row and decoded.  (Cost map of 8000 x 16 x 1 kbp,
+    // round 5: ring stores 14 % of the sweep, at the HBM write roof.)
+    const bool ring_plane = CB == 2 && BS == 2 * T;
     // ---- wave pipeline.  The waves of a workgroup do NOT meet inside the row loop.  Wave w sweeps row i as soon as wave
     // w-1 has handed over, through a ring of P16_MBOX mailboxes in LDS, the three values that cross its left edge in row i:
     // E and Q entering its first column and H of the column left of it (one 16-byte word {E, Q, H, row}, written and read
@@ -315,8 +387,32 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             __builtin_amdgcn_raw_buffer_store_b64(p16_pack_row<CVX, SW>(Hp[k], Fp[k], Op[k]), rs0, ut8, k * T * 8, 0);
         __builtin_amdgcn_raw_buffer_store_b32((unsigned)Hleft, rs0, (unsigned)t * 4u, TW * 8, 0);
     }
-    int best_lo = SW ? BIAS : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;
+    int best_lo = NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bk_lo = 0, bk_hi = 0;   // (global alignment only)
     const int kL_lo = L - j0, kL_hi = L - j0h;  // strip-local index of the end column L
+    unsigned key_lo = 0u, key_hi = 0u;          // local alignment: (greatest H of my strip) << 16 | 0xffff - (row & 0xffff)
+    unsigned long long ekey = 0ull;             // wave-uniform: best of the finished epochs (value, row, strip -- see fold_keys)
+    // per-lane keys of the epoch that ends in front of row `i_end` -> ekey.  value << 32 | (0xFFFFF - row) << 12 | (0xFFF - strip):
+    // greatest score, then smallest row, then smallest strip (strips are disjoint column ranges in ascending order)
+    auto fold_keys = [&](const int i_end) {
+        const unsigned ep = (unsigned)(i_end - 1) >> 16;
+        auto k64 = [&](const unsigned k, const int strip) -> unsigned long long {
+            if (k == 0u) return 0ull;
+            const unsigned row = (ep << 16) | (0xffffu - (k & 0xffffu));
+            return ((unsigned long long)(k >> 16) << 32) | ((unsigned long long)(0xFFFFFu - row) << 12) | (unsigned long long)(0xFFFu - (unsigned)strip);
+        };
+        unsigned long long kk = k64(key_lo, s_lo);
+        const unsigned long long k2 = k64(key_hi, s_hi);
+        kk = k2 > kk ? k2 : kk;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(kk, d);
+            kk = o > kk ? o : kk;
+        }
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(kk >> 32)), lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)kk);
+        const unsigned long long ku = ((unsigned long long)hi_ << 32) | lo_;
+        ekey = ku > ekey ? ku : ekey;
+        key_lo = 0u; key_hi = 0u;
+    };
 
     bool next_sib = false;      // decided at the end of a row for its successor
     // (An L2 warm-up for the next row's stored predecessor -- one load per wave touching its 44 cache lines a row ahead,
@@ -401,6 +497,29 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         }                                                                                                   \
     } while (0)
 
+// ... or, with ring_plane, the row's strips out of its plane row: H of the column left of the strips, then per column the
+// code's three fields; HS_/FS_/OS_[k] receive the row's H and outgoing candidates (FO_ = false: H only, for a sibling)
+#define P16_FETCH_PLANE(p_, FO_, HS_, FS_, OS_, hl_)                                                        \
+    do {                                                                                                    \
+        const __amdgpu_buffer_rsrc_t rsp_ = p16_rsrc((const void*)(g_tb + (size_t)(p_) * (size_t)(SD * BS)), SD * BS * 4); \
+        unsigned dl_[SD], dh_[SD];                                                                          \
+        plane_load_strip<SD>(rsp_, soff & 0xffffu, BS, dl_);                                                \
+        plane_load_strip<SD>(rsp_, soff >> 16, BS, dh_);                                                    \
+        P16_PROF_FETCH();                                                                                   \
+        P16_DRAIN();                                                                                        \
+        int run_ = (int)__builtin_amdgcn_perm(dh_[0], dl_[0], 0x05040100u);                                 \
+        hl_ = t == 0 ? (int)(((unsigned)run_ & 0xffff0000u) | ((unsigned)FLOORV & 0xffffu)) : run_;         \
+        _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                     \
+            const int cn_ = pk_sub((int)__builtin_amdgcn_perm(dh_[(k + 1) >> 1], dl_[(k + 1) >> 1], ((k + 1) & 1) ? 0x07060302u : 0x05040100u), D_CST); \
+            run_ = pk_add(pk_add(run_, cn_ & D_MH), G2);                                                    \
+            HS_[k] = run_;                                                                                  \
+            if (FO_) {                                                                                      \
+                FS_[FO_ ? k : 0] = pk_sub(pk_sub(run_, pk_lshr(cn_, D_SH1) & D_MF), D_EA);                  \
+                if (CVX) OS_[FO_ ? k : 0] = pk_sub(pk_sub(run_, pk_lshr(cn_, D_SH2)), D_CA);                \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+
 // Every branch that loaded a stored row from HBM ends by draining its loads itself.  Otherwise the compiler, which cannot
 // know at the join which branch ran, waits for vmcnt(0) at the top of pass 1 of EVERY row (a loaded register that a branch
 // did not consume is reused there) -- and on gfx9 vmcnt also counts stores, so rows that read nothing waited for the
@@ -413,12 +532,18 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         if ((EXP & 32) || (np <= 1 && p0 == i - 1)) {
             // register predecessor: its outgoing candidates ARE this row's F and O
         } else if (sib) {
-            u32x2 wr[W];
             int hl;
-            P16_FETCH(p0, s0, wr, hl);
-            Hleft = hl;
+            if (ring_plane && s0 >= 0 && p0 != 0) {
+                int fd_[1], od_[1];
+                P16_FETCH_PLANE(p0, false, Hp, fd_, od_, hl);
+                (void)fd_; (void)od_;
+            } else {
+                u32x2 wr[W];
+                P16_FETCH(p0, s0, wr, hl);
 #pragma unroll
-            for (int k = 0; k < W; ++k) Hp[k] = (int)wr[k].x;
+                for (int k = 0; k < W; ++k) Hp[k] = (int)wr[k].x;
+            }
+            Hleft = hl;
         } else {
             // Several predecessors: D, F and O are plain maxima over them (which predecessor won is re-derived by the
             // traceback), so the fold order is free: when the previous row is one of them (ROW_REGPRED) the registers are
@@ -426,23 +551,35 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             // other predecessor is folded in.
             const bool regbase = (flags & ROW_REGPRED) != 0;
             if (!regbase) {
-                u32x2 wr[W];
                 int hl;
-                P16_FETCH(p0, s0, wr, hl);
-                Hleft = hl;
+                if (ring_plane && s0 >= 0 && p0 != 0) P16_FETCH_PLANE(p0, true, Hp, Fp, Op, hl);
+                else {
+                    u32x2 wr[W];
+                    P16_FETCH(p0, s0, wr, hl);
 #pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    p16_unpack_row<SW>(wr[k], Hp[k], Fp[k], Op[k]);
-                    SXG_PIN("+v"(Hp[k]), "+v"(Fp[k]), "+v"(Op[k]));
+                    for (int k = 0; k < W; ++k) {
+                        p16_unpack_row<SW>(wr[k], Hp[k], Fp[k], Op[k]);
+                        SXG_PIN("+v"(Hp[k]), "+v"(Fp[k]), "+v"(Op[k]));
+                    }
                 }
+                Hleft = hl;
             }
 // fold one more predecessor row (p_, slot sl_) into the running maxima
 #define P16_FOLD(p_, sl_)                                                                                   \
     do {                                                                                                    \
-        u32x2 wr[W];                                                                                        \
         int hl;                                                                                             \
+        if (ring_plane && (sl_) >= 0 && (p_) != 0) {                                                        \
+            int hs_[W], fs_[W], os_[W];                                                                     \
+            P16_FETCH_PLANE(p_, true, hs_, fs_, os_, hl);                                                   \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
+                Fp[k] = pk_max(Fp[k], fs_[k]);                                                              \
+                if (CVX) Op[k] = pk_max(Op[k], os_[k]);                                                     \
+                Hp[k] = pk_max(Hp[k], hs_[k]);                                                              \
+                SXG_PIN("+v"(Hp[k]), "+v"(Fp[k]), "+v"(Op[k]));                                             \
+            }                                                                                               \
+        } else {                                                                                            \
+        u32x2 wr[W];                                                                                        \
         P16_FETCH(p_, sl_, wr, hl);                                                                         \
-        Hleft = pk_max(Hleft, hl);                                                                          \
         _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                     \
             int hs, fs, os;                                                                                 \
             p16_unpack_row<SW>(wr[k], hs, fs, os);                                                          \
@@ -451,6 +588,8 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             Hp[k] = pk_max(Hp[k], hs);                                                                      \
             SXG_PIN("+v"(Hp[k]), "+v"(Fp[k]), "+v"(Op[k]));                                                 \
         }                                                                                                   \
+        }                                                                                                   \
+        Hleft = pk_max(Hleft, hl);                                                                          \
     } while (0)
             // (the first two predecessors in straight-line code: two-predecessor rows -- the closing node of every
             // bubble -- are a third of all rows; the loop form made the allocator spill around them)
@@ -574,18 +713,15 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         RP_MARK(4);  // waiting for the right neighbour's progress
 
         // ---- end cell bookkeeping
-        if (EXP & 4) { best_lo ^= rowmax & 1; }
+        if (EXP & 4) { key_lo ^= (unsigned)rowmax & 1u; }
         else if (SW) {
-            const bool il = pk_lo(rowmax) > best_lo, ih = pk_hi(rowmax) > best_hi;
-            if (__any(il || ih)) {  // wave-uniform: only the waves the best diagonal runs through
-                if (il) { best_lo = pk_lo(rowmax); bi_lo = i; }
-                if (ih) { best_hi = pk_hi(rowmax); bi_hi = i; }
-#pragma unroll
-                for (int k = W - 1; k >= 0; --k) {
-                    if (il && pk_lo(Hc[k]) == best_lo) bk_lo = k;
-                    if (ih && pk_hi(Hc[k]) == best_hi) bk_hi = k;
-                }
-            }
+            // (biased fields: 512 <= field <= 32767, so the keys order as unsigned numbers; a row that merely equals the
+            //  strip's best has a smaller lower half and changes nothing: first strictly greatest, decree S4)
+            if ((i & 0xffff) == 0) fold_keys(i);
+            unsigned inv = 0xffffu - ((unsigned)i & 0xffffu);
+            asm volatile("" : "+v"(inv));   // (one VGPR copy: v_perm / v_and_or take one scalar operand each)
+            key_lo = max(key_lo, __builtin_amdgcn_perm((unsigned)rowmax, inv, 0x05040100u));
+            key_hi = max(key_hi, ((unsigned)rowmax & 0xffff0000u) | inv);
         } else if (flags & ROW_SINK) {
 #pragma unroll
             for (int k = 0; k < W; ++k) {
@@ -610,9 +746,13 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         const bool band_hi = !(EXP & 1) && (w0 + 127 >= bs0) && (w0 + 64 < bs0 + BS);
         const bool ring = !(EXP & 2) && (flags & ROW_STORE) != 0;
         const __amdgpu_buffer_rsrc_t rs_ring = p16_rsrc((const void*)((SXG_GLOBAL const char*)g_pool + (size_t)(ring && myslot >= 0 ? myslot : 0) * (size_t)RB), RB);
-        const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
+        const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(SD * BS)), SD * BS * 4);
         const bool in_lo = (unsigned)(w0 + tt - bs0) < (unsigned)BS, in_hi = (unsigned)(w0 + 64 + tt - bs0) < (unsigned)BS;
         const unsigned sl_lo = soff & 0xffffu, sl_hi = soff >> 16;   // strip s lives in slot s mod BS of its row
+        // (CB = 2) the H left of my strips as the plane row keeps it: strip 0 has no left neighbour -- its own first column,
+        // whose step is then 0
+        int lhs = lh;
+        if (CB == 2 && t == 0) lhs = (int)(((unsigned)lh & 0xffff0000u) | ((unsigned)Hc[0] & 0x0000ffffu));
 // ring row + band cells of this row; CF(k) / CO(k) = the row's outgoing candidates of column k
 #define P16_STORES(CF, CO)                                                                                  \
     do {                                                                                                    \
@@ -621,12 +761,33 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
                 P16_LDS_ROW(la_, lf_, -2 - myslot);                                                         \
                 _Pragma("unroll") for (int k = 0; k < W; ++k) la_[k * 64] = p16_pack_row<CVX, SW>(Hc[k], CF, CO); \
                 *lf_ = (unsigned)lh;                                                                        \
-            } else {                                                                                        \
+            } else if (!ring_plane) {                                                                       \
                 _Pragma("unroll") for (int k = 0; k < W; ++k)                                               \
                     __builtin_amdgcn_raw_buffer_store_b64(p16_pack_row<CVX, SW>(Hc[k], CF, CO), rs_ring, ut8, k * T * 8, 0); \
                 __builtin_amdgcn_raw_buffer_store_b32((unsigned)lh, rs_ring, ut8 >> 1, TW * 8, 0);          \
             }                                                                                               \
         }                                                                                                   \
+        if (CB == 2) {                                                                                      \
+            if (band_lo || band_hi) {                                                                       \
+                /* delta codes of my two strips (see P16Delta): both halves of a register at once */       \
+                int code_[W], prev_ = lhs;                                                                  \
+                _Pragma("unroll") for (int k = 0; k < W; ++k) {                                             \
+                    const int h_ = Hc[k], of_ = (CF), oo_ = (CO);                                           \
+                    const int d2_ = SW ? (int)((unsigned)h_ - (unsigned)of_) : pk_sub(h_, of_);             \
+                    int cd_ = pk_mad(d2_, KF2, pk_sub(h_, prev_));                                          \
+                    if (CVX) cd_ = pk_mad(SW ? (int)((unsigned)h_ - (unsigned)oo_) : pk_sub(h_, oo_), KO2, cd_); \
+                    code_[k] = cd_;                                                                         \
+                    prev_ = h_;                                                                             \
+                }                                                                                           \
+                /* dword x of a strip: halfwords 2x, 2x + 1 of (left H, code 0, ..., code W-1) */            \
+                if (band_lo && in_lo)                                                                       \
+                    plane_store_strip<SD>(rs_plane, sl_lo, BS, [&](const int x) -> unsigned {               \
+                        return __builtin_amdgcn_perm((unsigned)(2 * x < W ? code_[2 * x < W ? 2 * x : 0] : 0), (unsigned)(x ? code_[x ? 2 * x - 1 : 0] : lhs), 0x05040100u); }); \
+                if (band_hi && in_hi)                                                                       \
+                    plane_store_strip<SD>(rs_plane, sl_hi, BS, [&](const int x) -> unsigned {               \
+                        return __builtin_amdgcn_perm((unsigned)(2 * x < W ? code_[2 * x < W ? 2 * x : 0] : 0), (unsigned)(x ? code_[x ? 2 * x - 1 : 0] : lhs), 0x07060302u); }); \
+            }                                                                                               \
+        } else {                                                                                            \
         if (band_lo) {                                                                                      \
             if (in_lo)                                                                                      \
                 plane_store_strip<W>(rs_plane, sl_lo, BS, [&](const int k) -> unsigned {                    \
@@ -638,6 +799,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
                 plane_store_strip<W>(rs_plane, sl_hi, BS, [&](const int k) -> unsigned {                    \
                     const u32x2 w = p16_pack_row<CVX, SW>(Hc[k], CF, CO);                                   \
                     return __builtin_amdgcn_perm(w.y, w.x, 0x07060302u); });                                \
+        }                                                                                                   \
         }                                                                                                   \
     } while (0)
         if (!next_sib) {
@@ -667,6 +829,25 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
 #undef P16_DEC
 #undef P16_INC
 
+    if (SW) {
+        // ---- end cell of a local alignment: the wave's keys, then the workgroup's; the column is found by the traceback
+        fold_keys(N + 1);
+        __syncthreads();
+        unsigned long long* kl = (unsigned long long*)lds;
+        if (lane == 0) kl[wv] = ekey;
+        __syncthreads();
+        unsigned long long key = kl[0];
+        for (int x = 1; x < NW; ++x) key = kl[x] > key ? kl[x] : key;
+        __syncthreads();
+        const int val = (int)(unsigned)(key >> 32) - BIAS;
+        if (key == 0ull || val <= 0) { res.best = 0; res.bi = -1; res.bj = -1; }
+        else {
+            res.best = val;
+            res.bi = (int)(0xFFFFFu - (unsigned)((key >> 12) & 0xFFFFFu));
+            res.bj = -1 - (int)(0xFFFu - (unsigned)(key & 0xFFFu));   // -(strip + 1): see traceback_p16
+        }
+        return res;
+    }
     // ---- end cell: greatest score, then smallest row, then smallest column (two candidates per lane)
     unsigned long long key = 0;
     if (bi_lo >= 0)
@@ -721,7 +902,11 @@ enum : int { TBM_FLAG = 208, TBM_ROW = 209, TBM_DELTA = 210 };
 
 // BANDED (poa_band16.hip.h): a row keeps exactly the strips of its band, max(0, hint - w) / W .. (hint + w) / W, and a
 // cell outside the band does not exist (it reads as -inf and is never a miss).
-template <bool PAIRS, int W, bool CVX, bool BANDED = false>
+// CB = 2: the plane holds delta codes (P16Delta); the helpers below rebuild the cells the walk asks for -- H by summing a
+// strip's steps from its left end -- in the round-4 word format (H | H - oF | H - oO), so the walk itself is the same code.
+// j < 0 on entry: the sweep of a local alignment names the STRIP of the end cell, -(strip + 1); the column is the first
+// of that strip's cells in row i that holds the best score.
+template <bool PAIRS, int W, bool CVX, bool BANDED = false, int CB = 4>
 // (views by value: a reference to the kernel's private copy trips an AMDGPU back-end assertion on
 // the private-aperture null check for some strip widths)
 __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const Scoring S_, const uint8_t* seq, const int L_,
@@ -758,6 +943,24 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
         }
         return (unsigned)(s - band_first_strip(hint, W, BS, T)) < (unsigned)BS;
     };
+    static_assert(!(BANDED && CB == 2), "the banded sweep keeps 4-byte cells");
+    constexpr int SD = p16_slot_dwords(W, CB);     // dwords of one strip in a plane row
+    // (CB = 2) fields of a cell's code
+    const P16Delta DF = p16_delta_of(S_);
+    const int dbH = __builtin_amdgcn_readfirstlane(DF.bH), dbF = __builtin_amdgcn_readfirstlane(DF.bF);
+    const unsigned dmH = (1u << dbH) - 1u, dmF = (1u << dbF) - 1u;
+    const int dG = __builtin_amdgcn_readfirstlane(DF.g), dE = __builtin_amdgcn_readfirstlane(DF.eabs), dC = __builtin_amdgcn_readfirstlane(DF.cabs);
+    // The sweep adds the raw step and distances into the code; taking their least values off first (mod 2^16) leaves three
+    // non-negative fields side by side.
+    const unsigned dCst = (unsigned)(dG + (dE << dbH) + ((CVX ? dC : 0) << (dbH + dbF))) & 0xffffu;
+    auto d_norm = [&](const unsigned raw16) -> unsigned { return (raw16 - dCst) & 0xffffu; };
+    // normalised code -> step of H; the cell word given H
+    auto d_step = [&](const unsigned code) -> int { return (int)(code & dmH) + dG; };
+    auto d_word = [&](const int h, const unsigned code) -> uint32_t {
+        return ((uint32_t)h & 0xffffu) | ((((code >> dbH) & dmF) + (unsigned)dE) << 16) | (((code >> (dbH + dbF)) + (unsigned)(CVX ? dC : 0)) << 24);
+    };
+    // halfword hw (0 = the H left of the strip, 1 + k = code of column k) of a strip whose dwords are d[0..SD)
+    auto d_half = [&](const unsigned (&d)[SD], const int hw) -> unsigned { return (hw & 1) ? d[hw >> 1] >> 16 : d[hw >> 1] & 0xffffu; };
     // outputs and letters through global pointers: a FLAT store also counts on lgkmcnt, and the walk
     // waits on lgkmcnt for its LDS reads every step -- i.e. it would wait for the previous step's store to
     // reach HBM
@@ -805,6 +1008,18 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             if (!miss) { miss = true; miss_row = p; miss_delta = col - hint; }
             return 0u;
         }
+        if constexpr (CB == 2) {
+            // lanes 0 .. SD-1 fetch the strip's dwords; the steps up to column k are summed on the scalar unit
+            const unsigned dw = lane < SD ? g_plane[(size_t)p * (size_t)(SD * BS) + (size_t)plane_cell_in_row(SD, BS, s % BS, min(lane, SD - 1))] : 0u;
+            int h = (int)(short)(TBU(__builtin_amdgcn_readlane((int)dw, 0)) & 0xffffu);
+            unsigned cd = 0;
+            for (int t2 = 0; t2 <= k; ++t2) {
+                const unsigned d = TBU(__builtin_amdgcn_readlane((int)dw, (t2 + 1) >> 1));
+                cd = d_norm(((t2 + 1) & 1) ? d >> 16 : d & 0xffffu);
+                h += d_step(cd);
+            }
+            return d_word(h, cd);
+        }
         return TBU(g_plane[plane_cell<W>((size_t)p, BS, s % BS, k)]);
     };
     auto wcol0 = [&](int l) -> int { return wj - ((l * slope) >> 8) - (TBW_COLS - 3); };  // first column the window holds of row wtop-l
@@ -824,6 +1039,32 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
 #ifdef SXG_ROW_PROF
     unsigned long long tb_steps = 0, tb_loads = 0, tb_t0 = __builtin_readcyclecounter(), tb_ld = 0;
 #endif
+    if (j < 0) {
+        // The sweep of a local alignment found the end cell's row and STRIP (dp_fill_p16): its column is the first cell of
+        // that strip, in row i, that holds the score.  A strip the row did not keep is a band miss like any other.
+        const int s = -1 - j;
+        const int hint = (int)TBU(g_meta[8 * (size_t)(i - 1) + HW]);
+        j = 0;
+        if (!kept(hint, s)) { miss = true; miss_row = i; miss_delta = s * W + W / 2 - hint; }
+        else {
+            int kf = -1;
+            if constexpr (CB == 2) {
+                const unsigned dw = lane < SD ? g_plane[(size_t)i * (size_t)(SD * BS) + (size_t)plane_cell_in_row(SD, BS, s % BS, min(lane, SD - 1))] : 0u;
+                int h = (int)(short)(TBU(__builtin_amdgcn_readlane((int)dw, 0)) & 0xffffu);
+                for (int t2 = 0; t2 < W && kf < 0; ++t2) {
+                    const unsigned d = TBU(__builtin_amdgcn_readlane((int)dw, (t2 + 1) >> 1));
+                    h += d_step(d_norm(((t2 + 1) & 1) ? d >> 16 : d & 0xffffu));
+                    if (h == hv) kf = t2;
+                }
+            } else {
+                const uint32_t cw = lane < W ? g_plane[plane_cell<W>((size_t)i, BS, s % BS, min(lane, W - 1))] : 0u;
+                const unsigned long long meq = __ballot(lane < W && sext(cw) == hv);
+                if (meq) kf = (int)__builtin_ctzll(meq);
+            }
+            if (kf < 0) { miss = true; miss_row = i; miss_delta = 0; }   // (cannot happen: the strip's key came from these cells)
+            else j = s * W + kf;
+        }
+    }
     while (!miss) {
 #ifdef SXG_ROW_PROF
         ++tb_steps;
@@ -852,11 +1093,35 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                     const int c0 = wcol0(lane);
                     // (a cell's address does not depend on the row's band start: cells and descriptor travel together)
                     uint32_t v[TBW_COLS], valid = 0;
+                    uint32_t* en = win + lane * TBW_STRIDE;
+                    if constexpr (CB == 2) {
+                        // whole strips of the row, from the one that holds the window's first column: every strip is decoded from
+                        // its left end and each cell that falls into the window goes straight to its place in my window row
+                        constexpr int NS = W >= 8 ? 2 : 3;
+                        const int s0w = max(c0, 0) / W;
+                        unsigned raw[NS][SD];
+#pragma unroll
+                        for (int si = 0; si < NS; ++si) plane_load_slot<SD>(g_plane + (size_t)row * (size_t)(SD * BS), BS, min(s0w + si, 2 * T - 1) % BS, raw[si]);
+#pragma unroll
+                        for (int x2 = 0; x2 < TBW_COLS; ++x2) v[x2] = 0u;
+#pragma unroll
+                        for (int si = 0; si < NS; ++si) {
+                            int h = (int)(short)(raw[si][0] & 0xffffu);
+                            const int xb = (s0w + si) * W - c0;   // window place of the strip's first column
+#pragma unroll
+                            for (int k = 0; k < W; ++k) {
+                                const unsigned cd = d_norm(d_half(raw[si], 1 + k));
+                                h += d_step(cd);
+                                if ((unsigned)(xb + k) < (unsigned)TBW_COLS && s0w + si < 2 * T) en[xb + k] = d_word(h, cd);
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int x2 = 0; x2 < TBW_COLS; ++x2) {
                         const int col = min(max(c0 + x2, 0), L);
                         const int s = col / W, k = col - s * W;
                         v[x2] = g_plane[plane_cell<W>((size_t)row, BS, s % BS, k)];
+                    }
                     }
 #pragma unroll
                     for (int x2 = 0; x2 < TBW_COLS; ++x2) {
@@ -866,9 +1131,10 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                             else if (BANDED) { v[x2] = 0x0000C000u; valid |= 1u << x2; }
                         }
                     }
-                    uint32_t* en = win + lane * TBW_STRIDE;
+                    if constexpr (CB != 2) {
 #pragma unroll
                     for (int x2 = 0; x2 < TBW_COLS; ++x2) en[x2] = v[x2];
+                    }
                     en[EO_PB] = (uint32_t)d0.x; en[EO_INFO] = (uint32_t)d0.y; en[EO_Q0] = (uint32_t)d0.z; en[EO_Q1] = (uint32_t)d1.x;
                     en[EO_NODE] = (uint32_t)node | (valid << 24);
                 }
@@ -1015,6 +1281,16 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                         const int s = col / W, k = col - s * W;
                         const bool inb = act && kept(hint, s);
                         int hval = 0;
+                        if constexpr (CB == 2) {
+                            if (act && inb) {
+                                unsigned raw[SD];
+                                plane_load_slot<SD>(g_plane + (size_t)i * (size_t)(SD * BS), BS, s % BS, raw);
+                                int h = (int)(short)(raw[0] & 0xffffu);
+#pragma unroll
+                                for (int t2 = 0; t2 < W; ++t2) if (t2 <= k) h += d_step(d_norm(d_half(raw, 1 + t2)));
+                                hval = h;
+                            }
+                        } else
                         if (act && inb) hval = sext(g_plane[plane_cell<W>((size_t)i, BS, s % BS, k)]);
                         const unsigned long long meq = __ballot(act && inb && hval + go + (x - 1) * ge == hv);
                         const unsigned long long moob = BANDED ? 0ull : __ballot(act && !inb);

@@ -9,7 +9,7 @@
 #define SXG_HD __host__ __device__ __forceinline__
 // the graph phases stay OUT of line in the persistent kernel: inlined, their ~50 array
 // descriptors stay live across the DP sweep and push it into scratch spills
-#define SXG_HD_PHASE __host__ __device__ __noinline__
+#define SXG_HD_PHASE __host__ __device__ __noinline__ inline
 #else
 #define SXG_HD inline
 #define SXG_HD_PHASE inline
