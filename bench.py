@@ -32,6 +32,8 @@ WORKLOADS = {
     # name: (blocks, seqs, length, params (m,n,g,e,q,c spoa convention), description)
     "ns": (1000, 64, 5000, (1, -4, -6, -2, -26, -1), "north-star: 1000 blocks x 64 seqs x 5 kbp, convex 1,4,6,2,26,1"),
     "c2": (1000, 16, 1000, (1, -4, -6, -2, -26, -1), "config 2: 1000 blocks x 16 seqs x 1 kbp, convex 1,4,6,2,26,1"),
+    # the headline shape with smoothxg's four-parameter scores (spoa: q = g, c = e): in --mode nw the all-gap corner is -20 006
+    "ns4": (1000, 64, 5000, (1, -4, -6, -2, -6, -2), "headline shape, affine 1,4,6,2 (four-parameter form): 1000 blocks x 64 seqs x 5 kbp"),
     "c3": (5000, 64, 5000, (1, -4, -8, -2, -8, -2), "config 3: 5000 blocks x 64 seqs x 5 kbp, affine (abPOA o+k*e => g=-(o+e)), full matrix"),
     # config 3 as the reference's -A (abPOA) path runs it: banded, wb=311 wf=0.03 (src/smooth.cpp:266-271); cells = band cells
     "c3b": (5000, 64, 5000, (1, -4, -8, -2, -8, -2), "config 3 banded: 5000 blocks x 64 seqs x 5 kbp, affine, band w = 311 + 0.03 L (abPOA path)"),
@@ -273,7 +275,7 @@ def profile_counters(key):
     return w
 
 # fixture names of the blocks tests/golden/fullshape_oracle.json holds for a bench workload: (workload, mode) -> case name
-FIXTURE_CASE = {("ns", "sw"): "ns_sw", ("ns", "nw"): "ns_nw", ("c3", "sw"): "c3", ("c2", "sw"): "c2"}
+FIXTURE_CASE = {("ns", "sw"): "ns_sw", ("ns", "nw"): "ns_nw", ("ns4", "nw"): "ns_nw_affine", ("c3", "sw"): "c3", ("c2", "sw"): "c2"}
 
 
 def digest_block(r):

@@ -27,7 +27,11 @@ typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 // constant "addrspacecast(smem) + 512" argument of the out-of-line graph phases after inter-procedural constant propagation,
 // whose null check -- 0 against the shared aperture -- the AMDGPU back end emits as an illegal VOPC encoding for some kernels)
 typedef __attribute__((address_space(3))) int sxg_lds_int;
-struct WgCtx {
+// GBv: elements per thread and step of the graph phases' loops (poa_graph_dev.h): 4 for workgroups of four waves and more,
+// 8 / 16 for two- / one-wave workgroups (the kernels pick the context by their run-time thread count)
+template <int GBv>
+struct WgCtxT {
+    static constexpr int GB = GBv, GBH = GBv > 8 ? 8 : GBv, SCAN_K = GBv;
     sxg_lds_int* lds;  // >= 2*16+2 ints of LDS scratch
     __device__ __forceinline__ int tid() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
@@ -89,6 +93,7 @@ struct WgCtx {
         return r;
     }
 };
+typedef WgCtxT<4> WgCtx;
 
 // ---------------------------------------------------------------------------------------
 // packed row words of the row pool

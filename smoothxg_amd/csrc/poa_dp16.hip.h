@@ -39,6 +39,15 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NEGP = -16384;  // "minus infinity" of the packed sweep
+// GLOBAL alignments whose all-gap corner scores leave int16 (affine 1,4,6,2 at 5 kbp: -20 006) still run the packed sweep
+// (round 5): H is clamped at P16_NWFLOOR from below -- the same one instruction per cell that clamps a local alignment at
+// 0 -- which bounds every gap state too (each is some H plus one opening at least).  A clamped cell is larger than its true
+// value, and whatever it feeds gains at most m per column, so every cell with H > P16_NWFLOOR + m * L + m is EXACT, and so is
+// every decision the traceback takes in such a cell (a candidate out of the clamped region cannot equal its value).  The
+// traceback checks that of every cell it visits; a walk that meets a smaller H -- two sequences with little in common --
+// reports ST_RANGE_OVERFLOW and the block is re-run on the 32-bit sweep, as before.  (Rounds 1-4 sent every global
+// alignment whose corner did not fit down that ladder up front: 130 blocks/s instead of the packed sweep's rate.)
+constexpr int P16_NWFLOOR = -16000;
 // LOCAL alignments run the packed sweep on BIASED fields: a register half holds score + P16_BIAS, always inside
 // [P16_FLOOR, 32767].  Every reachable value of a local alignment is >= min(g, q) >= -120 (H >= 0, every gap state is
 // some H plus at most one opening) and the few "minus infinity" inputs (the column left of column 0, a carry that enters
@@ -262,7 +271,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     const int sm = __builtin_amdgcn_readfirstlane(S.m), sn = __builtin_amdgcn_readfirstlane(S.n);
     // local alignment: biased fields (see P16_BIAS); "x + K" for a penalty K <= 0 is then x - |K| * 0x10001 in 32 bits
     constexpr int BIAS = SW ? P16_BIAS : 0, FLOORV = SW ? P16_FLOOR : NEGP;
-    const int NEG2 = pk2(FLOORV, FLOORV), B2 = pk2(BIAS, BIAS);
+    const int NEG2 = pk2(FLOORV, FLOORV), B2 = pk2(BIAS, BIAS), NWF2 = pk2(P16_NWFLOOR, P16_NWFLOOR);
     const unsigned Gm = (unsigned)(-g) * 0x10001u, Em = (unsigned)(-e) * 0x10001u, Qm = (unsigned)(-q) * 0x10001u, Cm = (unsigned)(-c) * 0x10001u;
 #define P16_DEC(x, Km, K2) (SW ? (int)((unsigned)(x) - (Km)) : pk_add((x), (K2)))   /* x + K */
 #define P16_INC(x, Km, K2) (SW ? (int)((unsigned)(x) + (Km)) : pk_sub((x), (K2)))   /* x - K */
@@ -357,7 +366,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         for (int hf = 0; hf < 2; ++hf) {
             const int j = (hf ? j0h : j0) + k;
             int h = BIAS;
-            if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = max(a > b ? a : b, NEGP); }
+            if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = max(a > b ? a : b, P16_NWFLOOR); }
             h2[hf] = h;
         }
         Hp[k] = pk2(h2[0], h2[1]);
@@ -370,7 +379,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         for (int hf = 0; hf < 2; ++hf) {
             const int j = (hf ? j0h : j0) - 1;
             int h = BIAS;
-            if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = max(a > b ? a : b, NEGP); }
+            if (!SW && j > 0) { const int a = g + (j - 1) * e, b = q + (j - 1) * c; h = max(a > b ? a : b, P16_NWFLOOR); }
             h2[hf] = j < 0 ? FLOORV : h;
         }
         Hleft = pk2(h2[0], h2[1]);
@@ -688,7 +697,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             if (EXP & 64) { rowmax = pk_max(rowmax, Hc[k] ^ E ^ Q); continue; }
             int h = pk_max(Hc[k], E);
             if (CVX) h = pk_max(h, Q);
-            if (SW) h = pk_max(h, B2);
+            h = pk_max(h, SW ? B2 : NWF2);   // (local: 0; global: P16_NWFLOOR)
             Hc[k] = h;
             rowmax = pk_max(rowmax, h);
             E = pk_max(P16_DEC(h, Gm, G2), P16_DEC(E, Em, E2));
@@ -898,7 +907,7 @@ constexpr int TBW_LET = 128;    // query letters of columns jtop, jtop-1, ... ke
 static_assert((TBW_ROWS * TBW_STRIDE + TBW_LET) * 4 <= LDS_META_BYTES / 2, "traceback window lives in the descriptor area");
 
 // words of LDS (control area) through which the walk reports a band miss to the workgroup
-enum : int { TBM_FLAG = 208, TBM_ROW = 209, TBM_DELTA = 210 };
+enum : int { TBM_FLAG = 208, TBM_ROW = 209, TBM_DELTA = 210, TBM_RANGE = 211 /* a clamped cell on the walk: see P16_NWFLOOR */ };
 
 // BANDED (poa_band16.hip.h): a row keeps exactly the strips of its band, max(0, hint - w) / W .. (hint + w) / W, and a
 // cell outside the band does not exist (it reads as -inf and is never a miss).
@@ -994,8 +1003,12 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     auto h_row0 = [&](int col) -> int {
         if (sw || col <= 0) return bias;
         const int a = g + (col - 1) * e, b = q + (col - 1) * c;
-        return max(a > b ? a : b, NEGP);
+        return max(a > b ? a : b, BANDED ? NEGP : P16_NWFLOOR);
     };
+    // global alignment on the full matrix: cells at or below `thr` may be clamped ones (see P16_NWFLOOR); the walk must not
+    // take a decision in one
+    const int thr = (!BANDED && !sw) ? P16_NWFLOOR + sm * L + sm : -0x40000000;
+    bool range = false;
     int wtop = -1, wj = 0;
     bool miss = false;
     int miss_row = 0, miss_delta = 0;
@@ -1076,6 +1089,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             continue;
         }
         if (sw && st == SRC_STOP && hv == bias) break;
+        if (st == SRC_STOP && hv <= thr) { range = true; break; }
         {   // (re)fill the window when row i or column j leave it
             const int l = wtop - i;
             const int x = j - wcol0(l);
@@ -1169,7 +1183,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                                         (unsigned)lo >= (unsigned)TBW_LET) continue;
                                     if (!((nva >> (24 + xa)) & 1u) || !((nvb >> (24 + xb)) & 1u)) continue;
                                     const int hcell = sext(me[x2]);
-                                    if (sw && hcell == bias) continue;
+                                    if ((sw && hcell == bias) || hcell <= thr) continue;
                                     const int ha = sext(win[la * TBW_STRIDE + xa]), hb = np2 == 2 ? sext(win[lb * TBW_STRIDE + xb]) : ha;
                                     const bool second = np2 == 2 && hb > ha;    // (first predecessor in list order on ties)
                                     const int best2 = second ? hb : ha;
@@ -1333,7 +1347,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
         }
     }
 #undef TBU
-    if (lane == 0) { ctl[TBM_FLAG] = miss ? 1 : 0; ctl[TBM_ROW] = miss_row; ctl[TBM_DELTA] = miss_delta; }
+    if (lane == 0) { ctl[TBM_FLAG] = miss ? 1 : 0; ctl[TBM_ROW] = miss_row; ctl[TBM_DELTA] = miss_delta; ctl[TBM_RANGE] = range ? 1 : 0; }
 #ifdef SXG_ROW_PROF
     if (lane == 0 && B.row_prof) {
         B.row_prof[8] += tb_steps; B.row_prof[9] += tb_loads;

@@ -21,10 +21,13 @@ namespace sxg {
 // The scans below give every thread SCAN_K consecutive elements: the block-wide scan (LDS hop, two barriers) runs
 // once per SCAN_K * T elements, and the SCAN_K loads of a thread are independent -- with one wave per block (1 kbp
 // blocks, the banded sweep) these loops are bound by the latency of dependent HBM loads, not by instructions.
-constexpr int SCAN_K = 4;
+// SCAN_K and the batch sizes GB / GBH of the loops further down belong to the execution context (round 5): a one-wave
+// workgroup takes 16 elements per thread and step, so that a graph of ~1 000 nodes is ONE round of independent loads per stage
+// instead of five (graph phases of 8000 x 16 x 1 kbp: 28 % of the slot time with 4 everywhere).
 
 template <class Ctx, class F, class P>
 SXG_HD int array_excl_sum(Ctx& c, int n, F get, P out) {
+    constexpr int SCAN_K = Ctx::SCAN_K;
     const int T = c.nthreads(), t = c.tid();
     int carry = 0;
     for (int base = 0; base < n; base += SCAN_K * T) {
@@ -49,6 +52,7 @@ SXG_HD int array_excl_sum(Ctx& c, int n, F get, P out) {
 // out[i] = max_{x<=i} get(x)
 template <class Ctx, class F, class P>
 SXG_HD void array_incl_max(Ctx& c, int n, F get, P out) {
+    constexpr int SCAN_K = Ctx::SCAN_K;
     const int T = c.nthreads(), t = c.tid();
     const int NONE = -0x7fffffff;
     int carry = NONE;
@@ -72,6 +76,7 @@ SXG_HD void array_incl_max(Ctx& c, int n, F get, P out) {
 // out[i] = min_{x>=i} get(x)
 template <class Ctx, class F, class P>
 SXG_HD void array_suffix_min(Ctx& c, int n, F get, P out) {
+    constexpr int SCAN_K = Ctx::SCAN_K;
     const int T = c.nthreads(), t = c.tid();
     const int NONE = -0x7fffffff;
     int carry = NONE;
@@ -122,7 +127,7 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq_,
     const int BIG = 0x3fffffff;
     c.sync();
     // P1: classify every position: 0 = existing node, 1 = new sibling, 2 = new unaligned
-    constexpr int GB = 4;   // positions per thread and iteration, stage by stage (see prep_rows)
+    constexpr int GB = Ctx::GB;   // positions per thread and iteration, stage by stage (see prep_rows)
     for (int i0 = t; i0 < len; i0 += GB * T) {
         int cc[GB], a[GB], ld[GB], tg[GB];
 #pragma unroll
@@ -221,7 +226,7 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq_,
     }
     // P4: edges between consecutive path nodes, weight += 2*w (S6)
     for (int i0 = t; i0 < len; i0 += GB * T) {
-        int u_[GB], v_[GB], both[GB], e0[GB], h0[GB], n0[GB];
+        int u_[GB], v_[GB], both[GB], e0[GB], h0[GB], n0[GB];   // (six values per position: fits GB = 16 in 128 registers)
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             const int i = i0 + u * T;
@@ -363,7 +368,7 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
     const int n_store = array_excl_sum(c, N, [&](int r) { return (R.flags[r] & ROW_STORE) ? 1 : 0; }, R.sseq);
     if (t == 0) R.sseq[N] = n_store;
     c.sync();
-    constexpr int GB = 4;
+    constexpr int GB = Ctx::GB;
     int worst = 0;
     for (int r0 = t; r0 < N; r0 += GB * T) {
         int fl[GB], lu[GB], sr[GB], sl[GB];
@@ -404,10 +409,11 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
             if (R.pred_off[r + 1] - R.pred_off[r] <= 1) R.tbx[r] = -1;
         c.sync();
     }
-    for (int r0 = t; r0 < N; r0 += GB * T) {
-        int pb[GB], np[GB], cf[GB], p0[GB], p1[GB], q0[GB], q1[GB], ms[GB], mt[GB];
+    constexpr int GBH = Ctx::GBH;   // (nine values per row live across three stages of loads)
+    for (int r0 = t; r0 < N; r0 += GBH * T) {
+        int pb[GBH], np[GBH], cf[GBH], p0[GBH], p1[GBH], q0[GBH], q1[GBH], ms[GBH], mt[GBH];
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
+        for (int u = 0; u < GBH; ++u) {
             const int r = r0 + u * T;
             pb[u] = r < N ? R.pred_off[r] : 0;
             np[u] = r < N ? R.pred_off[r + 1] - pb[u] : 0;
@@ -416,12 +422,12 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
             mt[u] = r < N ? R.tbx[r] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
+        for (int u = 0; u < GBH; ++u) {
             p0[u] = np[u] >= 1 ? R.preds[pb[u]] : 0;
             p1[u] = np[u] >= 2 ? R.preds[pb[u] + 1] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
+        for (int u = 0; u < GBH; ++u) {
             const int r = r0 + u * T;
             if (hinted == 3) { q0[u] = 0; q1[u] = 0; }
             else if (hinted == 2) {
@@ -433,7 +439,7 @@ SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& ca
             }
         }
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
+        for (int u = 0; u < GBH; ++u) {
             const int r = r0 + u * T;
             if (r >= N) continue;
             int32_t* d = R.meta + 8 * (size_t)r;
@@ -455,7 +461,7 @@ SXG_HD_PHASE void rows_remain(Ctx& c, const GraphView& G, int N, SXG_GP int32_t*
     SXG_GP int32_t* nx[2] = {G.preva, G.newidx};
     SXG_GP int32_t* ds[2] = {G.nexta, G.target};
     c.sync();
-    constexpr int GB = 4;
+    constexpr int GB = Ctx::GB;
     for (int r0 = t; r0 < N; r0 += GB * T) {
         int e[GB], best[GB];
         uint32_t bw[GB];
@@ -512,7 +518,7 @@ SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const 
     if (N > caps.rows_cap) return ST_ROWS_OVERFLOW;
     // (GB rows per thread and iteration, every stage of dependent loads issued for all of them before the next: the chains
     // order -> in_head -> e_tail -> rank are four HBM round trips deep, and one wave per block has nothing else to hide them)
-    constexpr int GB = 4;
+    constexpr int GB = Ctx::GB;
     for (int r0 = t; r0 < N; r0 += GB * T) {
         int v[GB], cd[GB], xp[GB];
 #pragma unroll
@@ -533,34 +539,35 @@ SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const 
     if (t == 0) R.pred_off[N] = E;
     c.sync();
     // preds in rank space; store / sink flags; last reader of every row (kept in R.slot)
-    for (int r0 = t; r0 < N; r0 += GB * T) {
-        int v[GB], o[GB], ei[GB], eo[GB], od[GB], ti[GB], ho[GB], ni[GB], no[GB], ri[GB], ro[GB];
+    constexpr int GBH = Ctx::GBH;   // (eleven values per row)
+    for (int r0 = t; r0 < N; r0 += GBH * T) {
+        int v[GBH], o[GBH], ei[GBH], eo[GBH], od[GBH], ti[GBH], ho[GBH], ni[GBH], no[GBH], ri[GBH], ro[GBH];
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
+        for (int u = 0; u < GBH; ++u) {
             const int r = r0 + u * T;
             v[u] = r < N ? G.order[r] : -1;
             o[u] = r < N ? R.pred_off[r] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
+        for (int u = 0; u < GBH; ++u) {
             ei[u] = v[u] >= 0 ? G.in_head[v[u]] : -1;
             eo[u] = v[u] >= 0 ? G.out_head[v[u]] : -1;
             od[u] = v[u] >= 0 ? G.out_deg[v[u]] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {   // the first edge of either list (most nodes have one of each)
+        for (int u = 0; u < GBH; ++u) {   // the first edge of either list (most nodes have one of each)
             ti[u] = ei[u] >= 0 ? G.e_tail[ei[u]] : -1;
             ni[u] = ei[u] >= 0 ? G.e_next_in[ei[u]] : -1;
             ho[u] = eo[u] >= 0 ? G.e_head[eo[u]] : -1;
             no[u] = eo[u] >= 0 ? G.e_next_out[eo[u]] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
+        for (int u = 0; u < GBH; ++u) {
             ri[u] = ti[u] >= 0 ? G.rank[ti[u]] : -1;
             ro[u] = ho[u] >= 0 ? G.rank[ho[u]] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < GB; ++u) {
+        for (int u = 0; u < GBH; ++u) {
             const int r = r0 + u * T;
             if (r >= N) continue;
             int oo = o[u], regpred = 0;

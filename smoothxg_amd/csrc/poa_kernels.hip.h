@@ -212,7 +212,8 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             int score = 0;
             if (RM != 3 && len + 1 > T * CPL) { status = ST_TOO_LONG; break; }
             if (N + len > A.lay.nodes_cap || *V.G.n_edges + len > A.lay.nodes_cap) { status = ST_NODES_OVERFLOW; break; }
-            if (RM != 1 && !S.sw &&
+            // (the packed full-matrix sweep clamps instead and lets the traceback decide: see P16_NWFLOOR)
+            if (RM != 1 && RM != 2 && !S.sw &&
                 -(sxg_gap_cost(S.g, S.e, S.q, S.c, N) + sxg_gap_cost(S.g, S.e, S.q, S.c, len)) >= (RM >= 2 ? 15800 : 30000)) {
                 status = ST_RANGE_OVERFLOW;
                 break;
@@ -220,7 +221,11 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             if (N > 0 && len > 0) {
                 PROF(0);
                 const int band_mode = RM == 3 ? (int)A.params[A.per_block_params ? b : 0].banded : 0;   // 1 = B2, 2 = adaptive (B4)
-                status = prep_rows(ctx, V.G, V.R, caps, RM == 3 ? (band_mode == 2 ? 3 : 2) : (RM == 2 ? 1 : 0));
+                // (workgroups of one and two waves take more elements per thread and step: see WgCtxT)
+                const int hinted_ = RM == 3 ? (band_mode == 2 ? 3 : 2) : (RM == 2 ? 1 : 0);
+                if (TMAX <= 256 && T <= 64) { WgCtxT<16> c16{ctx.lds}; status = prep_rows(c16, V.G, V.R, caps, hinted_); }
+                else if (TMAX <= 256 && T <= 128) { WgCtxT<8> c8{ctx.lds}; status = prep_rows(c8, V.G, V.R, caps, hinted_); }
+                else status = prep_rows(ctx, V.G, V.R, caps, hinted_);
                 if (status != ST_OK) break;
                 PROF(1);
                 DpResult res;
@@ -256,13 +261,14 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                         res = dp_fill_p16<W, CVX, SW, CB>(S, V.R, N, seq, len, V.B, smem);
                         __syncthreads();
                         PROF(2);
-                        if (t == 0) lds[TBM_FLAG] = 0;
+                        if (t == 0) { lds[TBM_FLAG] = 0; lds[TBM_RANGE] = 0; }
                         __syncthreads();
                         if (t < 64 && res.bi >= 0)
                             traceback_p16<false, W, CVX, false, CB>(V.R, V.B, S, seq, len, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj,
                                                                     V.G.posnode, nullptr, nullptr, smem);
                         __syncthreads();
                         PROF(3);
+                        if (lds[TBM_RANGE]) { status = ST_RANGE_OVERFLOW; break; }
                         if (!lds[TBM_FLAG]) break;
                         if (att == 5) { status = ST_BAND_MISS; break; }
                         const int mrow = lds[TBM_ROW], mdelta = lds[TBM_DELTA];
@@ -285,7 +291,9 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             }
             if (t == 0) { A.score[s] = score; if (RM != 3 || N == 0 || len == 0) A.cells[s] = RM == 3 ? 0ull : (unsigned long long)N * (unsigned long long)len; }
             done_cells += (unsigned long long)N * (unsigned long long)len;
-            add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
+            if (TMAX <= 256 && T <= 64) { WgCtxT<16> c16{ctx.lds}; add_alignment(c16, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
+            else if (TMAX <= 256 && T <= 128) { WgCtxT<8> c8{ctx.lds}; add_alignment(c8, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
+            else add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
             if (A.params[A.per_block_params ? b : 0].mode & SXG_ORDER_SPOA) {   // S7': spoa's depth-first re-sort (one lane)
                 if (t == 0) spoa_resort(V.G);
                 __syncthreads();

@@ -222,17 +222,22 @@ static bool h16_safe(const Scoring& S, int maxlen, int rows) {
 }
 // Packed-int16 sweep: every reachable score and every intermediate (score +- one penalty, difference
 // of two scores) must stay inside int16 with NEGP = -16384 as "-inf".
-static bool p16_safe(const Scoring& S, int maxlen, int rows) {
+// clamp_ok: the caller can re-run a block whose walk met a clamped cell (whole blocks on the full matrix: P16_NWFLOOR in
+// poa_dp16.hip.h) -- a global alignment then only needs its POSITIVE range to fit; the align-only API and the banded sweep
+// keep the strict rule (no re-run / -inf cells of their own).  SXG_POA_NO_NW_CLAMP=1: strict everywhere (A/B runs).
+static bool p16_safe(const Scoring& S, int maxlen, int rows, bool clamp_ok = false) {
     if (getenv("SXG_POA_NO_PACKED")) return false;
     // stored rows keep H - max(H+g, F+e) and H - max(H+q, O+c) in one byte each
     if (std::abs(S.g) > 120 || std::abs(S.q) > 120) return false;
     // local alignment: every existing cell has 0 <= H <= m * L and F, O, E, Q >= -|q|; the range is one-sided
     if (S.sw) return (long)std::abs(S.m) * maxlen < 30000;
-    return (long)std::abs(S.m) * maxlen < 15800 && score_floor(S, maxlen, rows) < 15800;
+    if ((long)std::abs(S.m) * maxlen >= 15800) return false;
+    if (clamp_ok && !getenv("SXG_POA_NO_NW_CLAMP")) return (long)std::abs(S.m) * maxlen + std::abs(S.m) < 10000;   // (leaves the walk 6 000 below zero)
+    return score_floor(S, maxlen, rows) < 15800;
 }
 // narrowest mode >= `at_least` (2 = packed < 0 = int16 row words < 1 = int32 row words)
-static int row_mode(const Scoring& S, int maxlen, int rows, int at_least = 2) {
-    if (at_least == 2 && p16_safe(S, maxlen, rows)) return 2;
+static int row_mode(const Scoring& S, int maxlen, int rows, int at_least = 2, bool clamp_ok = false) {
+    if (at_least == 2 && p16_safe(S, maxlen, rows, clamp_ok)) return 2;
     if (at_least != 1 && h16_safe(S, maxlen, rows)) return 0;
     return 1;
 }
@@ -501,7 +506,8 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
             if (s > in->blk_off[b]) m.cost += (double)len * (l1 + 0.05 * prev);
             prev += (double)len;
         }
-        m.rm = row_mode(m.S, m.maxlen, m.maxlen);  // optimistic; the kernel re-checks (see score_floor)
+        // (optimistic; the kernel re-checks -- see score_floor -- and a packed global sweep checks the cells its traceback visits)
+        m.rm = row_mode(m.S, m.maxlen, m.maxlen, 2, h->h_params[in->per_block_params ? b : 0].banded == 0);
         m.fits = variant_for_len(m.maxlen, m.rm, &m.variant, m.S.sw);
         m.variant.CB = m.rm == 2 ? plane_cell_bytes(m.S) : 4;
         // A11: the reference's abPOA path is banded (wb=311, wf=0.03); local alignments whose scores fit the packed

@@ -12,6 +12,7 @@
 using namespace sxg;
 
 struct SerialCtx {
+    static constexpr int GB = 4, GBH = 4, SCAN_K = 4;
     int tid() const { return 0; }
     int nthreads() const { return 1; }
     void sync() {}

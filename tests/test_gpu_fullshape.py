@@ -4,7 +4,8 @@ tests/golden/fullshape_oracle.json (made by tests/golden/make_fullshape.py in th
 holds, per block, the oracle's scores and SHA-256 digests of node codes / ranks / groups / edges /
 weights / all sequence paths / consensus.  The HIP path runs the same seeded blocks through the C ABI
 and must reproduce every one of them: north-star headline local + global (64 x 5 kbp, convex), config 3
-(64 x 5 kbp, affine 1,4,8,2), config 2 (16 x 1 kbp), config 4's extremes (128 x 10 kbp, 8 x 0.5 kbp).
+(64 x 5 kbp, affine 1,4,8,2), config 2 (16 x 1 kbp), config 4's extremes (128 x 10 kbp, 8 x 0.5 kbp), and the headline shape in
+GLOBAL mode with the four-parameter affine scores 1,4,6,2, whose all-gap corner leaves int16 (the packed sweep's clamped form).
 """
 import json
 import os
@@ -31,7 +32,7 @@ def _digests(r):
                         r.consensus)
 
 
-@pytest.mark.parametrize("group", ["ns_sw", "ns_nw", "c3", "c2+c4_min", "c4_max"])
+@pytest.mark.parametrize("group", ["ns_sw", "ns_nw", "ns_nw_affine", "c3", "c2+c4_min", "c4_max"])
 def test_full_shape_blocks_match_committed_oracle_output(engine, group):
     names = group.split("+")
     cases = [c for c in _cases() if c["name"] in names]

@@ -302,19 +302,29 @@ def test_every_packed_strip_width_and_wave_count(engine, oracle, monkeypatch, sp
         assert_block_equal(res[0], g, sc, cells, label=f"packed T={T} cols/lane={cpl} L={L} spread={spread}")
 
 
-def test_global_alignment_outgrows_the_packed_range_and_is_rerun_wider(engine, oracle):
-    """Affine global alignment, 3 kbp: the packed sweep is chosen for the smallest possible graph, the
-    divergent sequences grow the graph until gap(N) + gap(L) leaves +-15800, the kernel answers
-    RANGE_OVERFLOW and the engine re-runs the block with the 32-bit sweep -- same results."""
+def test_global_alignment_beyond_the_int16_corner_stays_packed_and_a_clamped_walk_is_rerun_wider(engine, oracle):
+    """Affine global alignment (1,4,6,2): the all-gap corner of the matrix, -(g + 2(N-1)) - (g + 2(L-1)), leaves int16 from
+    N + L ~ 8 000 on.  Round 5: the packed sweep clamps H at P16_NWFLOOR and the traceback checks that every cell it decides
+    in lies above the level a clamped cell could have lifted -- a block of related sequences runs packed to the end, whatever
+    its corner; two sequences with nothing in common walk through clamped cells, the kernel answers RANGE_OVERFLOW and the
+    engine re-runs the block on the 32-bit sweep.  Same results as the oracle in both cases."""
     rng = np.random.default_rng(77)
     seqs = random_block(rng, 8, 3000, div=0.25)
     g, sc, cells = oracle.block_run(seqs, None, oparams("affine_4param", 1))
-    assert len(g.nodes()[0]) > 5200                      # -(g + 2(N-1)) - (g + 2(L-1)) < -15800 from N ~ 4900 on
+    assert len(g.nodes()[0]) > 5200                      # the corner is beyond -15 800 from N ~ 4 900 on
     res = engine.run_blocks([seqs], gparams("affine_4param", 1))
     st = engine.stats()
+    assert st["dom_row_mode"] == 2       # (a retry here is the capacity ladder: at 25 % divergence the graph outgrows the first tier)
+    assert_block_equal(res[0], g, sc, cells, label="clamped-packed")
+    # nothing in common: the optimal walk runs thousands below zero, into what clamped cells can reach
+    far = [rng.integers(0, 4, 9400, dtype=np.uint8), rng.integers(0, 4, 9300, dtype=np.uint8)]
+    g3, sc3, cells3 = oracle.block_run(far, None, oparams("affine_4param", 1))
+    assert sc3[1] < -16000 + 9400 + 1
+    res3 = engine.run_blocks([far], gparams("affine_4param", 1))
+    st = engine.stats()
     assert st["retries"] >= 1 and st["dom_row_mode"] != 2
-    assert_block_equal(res[0], g, sc, cells, label="range-rerun")
-    # ... while a similar block that stays small runs packed to the end
+    assert_block_equal(res3[0], g3, sc3, cells3, label="clamped-walk-rerun")
+    # ... while a similar block that stays small never needed either
     calm = random_block(rng, 4, 3000, div=0.01)
     g2, sc2, cells2 = oracle.block_run(calm, None, oparams("affine_4param", 1))
     res2 = engine.run_blocks([calm], gparams("affine_4param", 1))
