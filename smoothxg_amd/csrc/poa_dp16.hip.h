@@ -1035,7 +1035,8 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
         }
         return TBU(g_plane[plane_cell<W>((size_t)p, BS, s % BS, k)]);
     };
-    auto wcol0 = [&](int l) -> int { return wj - ((l * slope) >> 8) - (TBW_COLS - 3); };  // first column the window holds of row wtop-l
+    int wgeo = slope;   // slope the current window was laid out with
+    auto wcol0 = [&](int l) -> int { return wj - ((l * wgeo) >> 8) - (TBW_COLS - 3); };  // first column the window holds of row wtop-l
     auto cell = [&](int p, int col) -> uint32_t {
         const int l = wtop - p;
         if (wtop >= 0 && (unsigned)l < (unsigned)WR) {
@@ -1046,11 +1047,149 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
         return gcell(p, col);
     };
     auto sext = [](uint32_t w) -> int { return (int)(short)(w & 0xffffu); };
+    // ---- window fills in two halves (round 5): win_issue sends a window's loads (lane l: row top - l -- descriptor, node id, the
+    // plane cells around the column where the walk is expected to cross that row, and two query letters), win_commit decodes
+    // them into the LDS window and precomputes the diagonal runs.  The NEXT window is issued as soon as the current one is
+    // committed, at the place the running slope predicts, and committed without a round trip when the walk enters it there
+    // (rounds 2-4: every window was two dependent round trips, half of the walk's time on 1 kbp blocks).
+    constexpr int NSW = CB == 2 ? (W >= 8 ? 2 : 3) : 1;            // strips a lane fetches (CB = 2: whole strips)
+    constexpr int NRAW = CB == 2 ? NSW * SD : TBW_COLS;
+    struct WinRaw { i32x4 d0, d1; int node; unsigned cells[NRAW]; uint32_t let0, let1; };
+    auto win_issue = [&](const int top, const int jj, const int slp, WinRaw& R_) {
+        const int row = top - lane;
+        R_.d0 = i32x4{0, 0, 0, 0}; R_.d1 = R_.d0; R_.node = 0;
+#pragma unroll
+        for (int x2 = 0; x2 < NRAW; ++x2) R_.cells[x2] = 0u;
+        if (row >= 1) {
+            SXG_GLOBAL const i32x4* dm = (SXG_GLOBAL const i32x4*)(g_meta + 8 * (size_t)(row - 1));
+            R_.d0 = dm[0]; R_.d1 = dm[1];
+            R_.node = g_row_node[row - 1];
+            const int c0 = jj - ((lane * slp) >> 8) - (TBW_COLS - 3);
+            // (a cell's address does not depend on the row's band start: cells and descriptor travel together)
+            if constexpr (CB == 2) {
+                const int s0w = max(c0, 0) / W;
+#pragma unroll
+                for (int si = 0; si < NSW; ++si) {
+                    unsigned tmp[SD];
+                    plane_load_slot<SD>(g_plane + (size_t)row * (size_t)(SD * BS), BS, min(s0w + si, 2 * T - 1) % BS, tmp);
+#pragma unroll
+                    for (int x2 = 0; x2 < SD; ++x2) R_.cells[si * SD + x2] = tmp[x2];
+                }
+            } else {
+#pragma unroll
+                for (int x2 = 0; x2 < TBW_COLS; ++x2) {
+                    const int col = min(max(c0 + x2, 0), L);
+                    const int s = col / W, k = col - s * W;
+                    R_.cells[x2] = g_plane[plane_cell<W>((size_t)row, BS, s % BS, k)];
+                }
+            }
+        }
+        // (letters: one per column; the walk never reads them from HBM -- a global load inside a step
+        // makes the compiler wait for vmcnt(0) there, i.e. for the previous step's output store)
+        R_.let0 = (jj - lane >= 1) ? (uint32_t)g_seq[jj - lane - 1] : 255u;
+        R_.let1 = (jj - 64 - lane >= 1) ? (uint32_t)g_seq[jj - 64 - lane - 1] : 255u;
+    };
+    // (the window's geometry -- wtop, wj, wgeo -- is set by the caller before the commit)
+    auto win_commit = [&](const WinRaw& R_) {
+        const int row = wtop - lane;
+        if (row >= 1 && lane < WR) {
+            const i32x4 d0 = R_.d0, d1 = R_.d1;
+            const int c0 = wcol0(lane);
+            uint32_t v[TBW_COLS], valid = 0;
+            uint32_t* en = win + lane * TBW_STRIDE;
+            if constexpr (CB == 2) {
+                // whole strips of the row, from the one that holds the window's first column: every strip is decoded from
+                // its left end and each cell that falls into the window goes straight to its place in my window row
+                const int s0w = max(c0, 0) / W;
+#pragma unroll
+                for (int x2 = 0; x2 < TBW_COLS; ++x2) v[x2] = 0u;
+#pragma unroll
+                for (int si = 0; si < NSW; ++si) {
+                    int h = (int)(short)(R_.cells[si * SD] & 0xffffu);
+                    const int xb = (s0w + si) * W - c0;   // window place of the strip's first column
+#pragma unroll
+                    for (int k = 0; k < W; ++k) {
+                        const unsigned dwk = R_.cells[si * SD + ((1 + k) >> 1)];
+                        const unsigned cd = d_norm(((1 + k) & 1) ? dwk >> 16 : dwk & 0xffffu);
+                        h += d_step(cd);
+                        if ((unsigned)(xb + k) < (unsigned)TBW_COLS && s0w + si < 2 * T) en[xb + k] = d_word(h, cd);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int x2 = 0; x2 < TBW_COLS; ++x2) v[x2] = R_.cells[x2];
+            }
+#pragma unroll
+            for (int x2 = 0; x2 < TBW_COLS; ++x2) {
+                const int col = c0 + x2;
+                if (col >= 0 && col <= L) {
+                    if (kept(ada ? d1.z : d1.w, col / W)) valid |= 1u << x2;
+                    else if (BANDED) { v[x2] = 0x0000C000u; valid |= 1u << x2; }
+                }
+            }
+            if constexpr (CB != 2) {
+#pragma unroll
+                for (int x2 = 0; x2 < TBW_COLS; ++x2) en[x2] = v[x2];
+            }
+            en[EO_PB] = (uint32_t)d0.x; en[EO_INFO] = (uint32_t)d0.y; en[EO_Q0] = (uint32_t)d0.z; en[EO_Q1] = (uint32_t)d1.x;
+            en[EO_NODE] = (uint32_t)R_.node | (valid << 24);
+        }
+        wlet[lane] = R_.let0;
+        wlet[64 + lane] = R_.let1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {   // D transitions of my row's cells (rule D of poa_vtb.c, rows with one or two predecessors)
+            const int row2 = wtop - lane;
+            uint32_t tw[TBW_COLS];
+#pragma unroll
+            for (int x2 = 0; x2 < TBW_COLS; ++x2) tw[x2] = 0u;
+            if (row2 >= 1 && lane < WR) {
+                const uint32_t* me = win + lane * TBW_STRIDE;
+                const uint32_t nv = me[EO_NODE];
+                const int inf2 = (int)me[EO_INFO], np2 = inf2 & 0xffff, code2 = (inf2 >> 16) & 0xff;
+                const int pa = (int)me[EO_Q0], pbb = (int)me[EO_Q1];
+                const int c0 = wcol0(lane);
+                if (np2 >= 1 && np2 <= 2 && pa >= 1 && (np2 == 1 || pbb >= 1)) {
+                    const int la = wtop - pa, lb = np2 == 2 ? wtop - pbb : la;
+                    if ((unsigned)la < (unsigned)WR && (unsigned)lb < (unsigned)WR) {
+                        const int ca = wcol0(la), cb = wcol0(lb);
+                        const uint32_t nva = win[la * TBW_STRIDE + EO_NODE], nvb = win[lb * TBW_STRIDE + EO_NODE];
+#pragma unroll
+                        for (int x2 = 0; x2 < TBW_COLS; ++x2) {
+                            const int col = c0 + x2;
+                            const int xa = col - 1 - ca, xb = col - 1 - cb, lo = wj - col;
+                            if (!((nv >> (24 + x2)) & 1u) || col < 1 || (unsigned)xa >= (unsigned)TBW_COLS || (unsigned)xb >= (unsigned)TBW_COLS ||
+                                (unsigned)lo >= (unsigned)TBW_LET) continue;
+                            if (!((nva >> (24 + xa)) & 1u) || !((nvb >> (24 + xb)) & 1u)) continue;
+                            const int hcell = sext(me[x2]);
+                            if ((sw && hcell == bias) || hcell <= thr) continue;
+                            const int ha = sext(win[la * TBW_STRIDE + xa]), hb = np2 == 2 ? sext(win[lb * TBW_STRIDE + xb]) : ha;
+                            const bool second = np2 == 2 && hb > ha;    // (first predecessor in list order on ties)
+                            const int best2 = second ? hb : ha;
+                            if (best2 + ((int)wlet[lo] == code2 ? sm : sn) == hcell)
+                                tw[x2] = 0x80000000u | (uint32_t)(second ? lb : la) | ((uint32_t)(second ? xb : xa) << 6);
+                        }
+                    }
+                }
+            }
+            if (lane < WR) {
+#pragma unroll
+                for (int x2 = 0; x2 < TBW_COLS; ++x2) trans[lane * TBW_COLS + x2] = tw[x2];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+    WinRaw pf;                     // the window asked for ahead of the walk
+    int pf_top = -1, pf_j = 0, pf_slope = 0;
+    int wslope = slope;            // running estimate of the columns the walk advances per row (1/256)
     int n = 0;
     int st = SRC_STOP;           // SRC_STOP = "in H", SRC_F / SRC_O = walking up a gap in the sequence
     int hv = best + bias, gv = 0;       // H of the current cell / value of the gap state being walked
 #ifdef SXG_ROW_PROF
-    unsigned long long tb_steps = 0, tb_loads = 0, tb_t0 = __builtin_readcyclecounter(), tb_ld = 0;
+    unsigned long long tb_steps = 0, tb_loads = 0, tb_t0 = __builtin_readcyclecounter(), tb_ld = 0, tb_hits = 0;
 #endif
     if (j < 0) {
         // The sweep of a local alignment found the end cell's row and STRIP (dp_fill_p16): its column is the first cell of
@@ -1094,113 +1233,44 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             const int l = wtop - i;
             const int x = j - wcol0(l);
             if (wtop < 0 || l < 0 || l > WR - 3 || x < 2 || x >= TBW_COLS) {
-                wtop = i; wj = j;
 #ifdef SXG_ROW_PROF
                 ++tb_loads;
                 const unsigned long long tl0 = __builtin_readcyclecounter();
 #endif
-                const int row = i - lane;
-                if (row >= 1 && lane < WR) {
-                    SXG_GLOBAL const i32x4* dm = (SXG_GLOBAL const i32x4*)(g_meta + 8 * (size_t)(row - 1));
-                    const i32x4 d0 = dm[0], d1 = dm[1];
-                    const int node = g_row_node[row - 1];
-                    const int c0 = wcol0(lane);
-                    // (a cell's address does not depend on the row's band start: cells and descriptor travel together)
-                    uint32_t v[TBW_COLS], valid = 0;
-                    uint32_t* en = win + lane * TBW_STRIDE;
-                    if constexpr (CB == 2) {
-                        // whole strips of the row, from the one that holds the window's first column: every strip is decoded from
-                        // its left end and each cell that falls into the window goes straight to its place in my window row
-                        constexpr int NS = W >= 8 ? 2 : 3;
-                        const int s0w = max(c0, 0) / W;
-                        unsigned raw[NS][SD];
-#pragma unroll
-                        for (int si = 0; si < NS; ++si) plane_load_slot<SD>(g_plane + (size_t)row * (size_t)(SD * BS), BS, min(s0w + si, 2 * T - 1) % BS, raw[si]);
-#pragma unroll
-                        for (int x2 = 0; x2 < TBW_COLS; ++x2) v[x2] = 0u;
-#pragma unroll
-                        for (int si = 0; si < NS; ++si) {
-                            int h = (int)(short)(raw[si][0] & 0xffffu);
-                            const int xb = (s0w + si) * W - c0;   // window place of the strip's first column
-#pragma unroll
-                            for (int k = 0; k < W; ++k) {
-                                const unsigned cd = d_norm(d_half(raw[si], 1 + k));
-                                h += d_step(cd);
-                                if ((unsigned)(xb + k) < (unsigned)TBW_COLS && s0w + si < 2 * T) en[xb + k] = d_word(h, cd);
-                            }
-                        }
-                    } else {
-#pragma unroll
-                    for (int x2 = 0; x2 < TBW_COLS; ++x2) {
-                        const int col = min(max(c0 + x2, 0), L);
-                        const int s = col / W, k = col - s * W;
-                        v[x2] = g_plane[plane_cell<W>((size_t)row, BS, s % BS, k)];
-                    }
-                    }
-#pragma unroll
-                    for (int x2 = 0; x2 < TBW_COLS; ++x2) {
-                        const int col = c0 + x2;
-                        if (col >= 0 && col <= L) {
-                            if (kept(ada ? d1.z : d1.w, col / W)) valid |= 1u << x2;
-                            else if (BANDED) { v[x2] = 0x0000C000u; valid |= 1u << x2; }
-                        }
-                    }
-                    if constexpr (CB != 2) {
-#pragma unroll
-                    for (int x2 = 0; x2 < TBW_COLS; ++x2) en[x2] = v[x2];
-                    }
-                    en[EO_PB] = (uint32_t)d0.x; en[EO_INFO] = (uint32_t)d0.y; en[EO_Q0] = (uint32_t)d0.z; en[EO_Q1] = (uint32_t)d1.x;
-                    en[EO_NODE] = (uint32_t)node | (valid << 24);
+                // the slope the walk really had across the window it leaves (rows of other branches are skipped, so it differs from
+                // L / N locally), blended into the running estimate
+                if (wtop >= 0 && wtop > i) {
+                    const int est = ((wj - j) << 8) / (wtop - i);
+                    wslope = min(max((wslope + est) >> 1, 16), 512);
                 }
-                // (letters: one per column; the walk never reads them from HBM -- a global load inside a step
-                // makes the compiler wait for vmcnt(0) there, i.e. for the previous step's output store)
-                wlet[lane] = (j - lane >= 1) ? (uint32_t)g_seq[j - lane - 1] : 255u;
-                wlet[64 + lane] = (j - 64 - lane >= 1) ? (uint32_t)g_seq[j - 64 - lane - 1] : 255u;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                {   // D transitions of my row's cells (rule D of poa_vtb.c, rows with one or two predecessors)
-                    const int row2 = i - lane;
-                    uint32_t tw[TBW_COLS];
-#pragma unroll
-                    for (int x2 = 0; x2 < TBW_COLS; ++x2) tw[x2] = 0u;
-                    if (row2 >= 1 && lane < WR) {
-                        const uint32_t* me = win + lane * TBW_STRIDE;
-                        const uint32_t nv = me[EO_NODE];
-                        const int inf2 = (int)me[EO_INFO], np2 = inf2 & 0xffff, code2 = (inf2 >> 16) & 0xff;
-                        const int pa = (int)me[EO_Q0], pbb = (int)me[EO_Q1];
-                        const int c0 = wcol0(lane);
-                        if (np2 >= 1 && np2 <= 2 && pa >= 1 && (np2 == 1 || pbb >= 1)) {
-                            const int la = wtop - pa, lb = np2 == 2 ? wtop - pbb : la;
-                            if ((unsigned)la < (unsigned)WR && (unsigned)lb < (unsigned)WR) {
-                                const int ca = wcol0(la), cb = wcol0(lb);
-                                const uint32_t nva = win[la * TBW_STRIDE + EO_NODE], nvb = win[lb * TBW_STRIDE + EO_NODE];
-#pragma unroll
-                                for (int x2 = 0; x2 < TBW_COLS; ++x2) {
-                                    const int col = c0 + x2;
-                                    const int xa = col - 1 - ca, xb = col - 1 - cb, lo = wj - col;
-                                    if (!((nv >> (24 + x2)) & 1u) || col < 1 || (unsigned)xa >= (unsigned)TBW_COLS || (unsigned)xb >= (unsigned)TBW_COLS ||
-                                        (unsigned)lo >= (unsigned)TBW_LET) continue;
-                                    if (!((nva >> (24 + xa)) & 1u) || !((nvb >> (24 + xb)) & 1u)) continue;
-                                    const int hcell = sext(me[x2]);
-                                    if ((sw && hcell == bias) || hcell <= thr) continue;
-                                    const int ha = sext(win[la * TBW_STRIDE + xa]), hb = np2 == 2 ? sext(win[lb * TBW_STRIDE + xb]) : ha;
-                                    const bool second = np2 == 2 && hb > ha;    // (first predecessor in list order on ties)
-                                    const int best2 = second ? hb : ha;
-                                    if (best2 + ((int)wlet[lo] == code2 ? sm : sn) == hcell)
-                                        tw[x2] = 0x80000000u | (uint32_t)(second ? lb : la) | ((uint32_t)(second ? xb : xa) << 6);
-                                }
-                            }
-                        }
-                    }
-                    if (lane < WR) {
-#pragma unroll
-                        for (int x2 = 0; x2 < TBW_COLS; ++x2) trans[lane * TBW_COLS + x2] = tw[x2];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // the window asked for while the walk was still in the last one, if the walk enters it where it was expected
+                bool hit = false;
+                if (pf_top >= 1) {
+                    const int l2 = pf_top - i;
+                    const int x2 = j - (pf_j - ((l2 * pf_slope) >> 8) - (TBW_COLS - 3));
+                    hit = l2 >= 0 && l2 <= WR / 2 && x2 >= 3 && x2 < TBW_COLS - 1;
                 }
+#ifdef SXG_ROW_PROF
+                if (hit) ++tb_hits;
+#endif
+                if (hit) { wtop = pf_top; wj = pf_j; wgeo = pf_slope; win_commit(pf); }
+                else {
+                    wtop = i; wj = j; wgeo = wslope;
+                    WinRaw cur;
+                    win_issue(wtop, wj, wgeo, cur);
+                    win_commit(cur);
+                }
+                // ... and ask for the next one right away: its loads travel while the walk crosses this window
+                pf_top = wtop - (WR - 6); pf_slope = wslope; pf_j = max(wj - (((WR - 6) * wslope) >> 8), 0);
+#ifdef SXG_TB_NO_PREFETCH
+                pf_top = -1;   // (A/B builds: every window is fetched when the walk needs it, as in rounds 2-4)
+#endif
+                // (Measured, round 5: the walk enters the predicted window in only 16-22 % of the cases -- rows of other branches make
+                //  its path through rank space too irregular for a straight line eight columns wide -- which pays on one- and
+                //  two-wave workgroups, where nothing else hides the round trips (16 x 1 kbp: 43.2 -> 42.1 ms), and costs 1.6 % on the
+                //  four-wave headline class, whose other waves do: those keep fetching on demand.)
+                if (T > 128) pf_top = -1;
+                if (pf_top >= 1) win_issue(pf_top, pf_j, pf_slope, pf); else pf_top = -1;
 #ifdef SXG_ROW_PROF
                 tb_ld += __builtin_readcyclecounter() - tl0;
 #endif
@@ -1351,7 +1421,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
 #ifdef SXG_ROW_PROF
     if (lane == 0 && B.row_prof) {
         B.row_prof[8] += tb_steps; B.row_prof[9] += tb_loads;
-        B.row_prof[10] += __builtin_readcyclecounter() - tb_t0; B.row_prof[11] += tb_ld;
+        B.row_prof[10] += __builtin_readcyclecounter() - tb_t0; B.row_prof[11] += tb_ld; B.row_prof[12] += tb_hits;
     }
 #endif
     __builtin_amdgcn_s_setprio(0);

@@ -752,11 +752,11 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
     }
 #ifdef SXG_ROW_PROF
     {
-        unsigned long long ra[12] = {0};
+        unsigned long long ra[13] = {0};
         for (int64_t sl = 0; sl < P.n_slots; ++sl) {
-            unsigned long long one[12];
+            unsigned long long one[13];
             HIPCHK(hipMemcpy(one, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64 + 28 * 8, sizeof(one), hipMemcpyDeviceToHost));
-            for (int k = 0; k < 12; ++k) ra[k] += one[k];
+            for (int k = 0; k < 13; ++k) ra[k] += one[k];
         }
         double rt = 1e-9;
         for (int k = 0; k < 8; ++k) rt += (double)ra[k];
@@ -766,9 +766,9 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
         fprintf(stderr, "[sxg]   row profile:");
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", seg[k], 100.0 * (double)ra[k] / rt);
         fprintf(stderr, "\n");
-        fprintf(stderr, "[sxg]   traceback: %.3g steps, %.1f steps per window load, %.0f cycles per step of which %.0f waiting for window loads\n",
-                (double)ra[8], (double)ra[8] / std::max<double>((double)ra[9], 1), (double)ra[10] / std::max<double>((double)ra[8], 1),
-                (double)ra[11] / std::max<double>((double)ra[8], 1));
+        fprintf(stderr, "[sxg]   traceback: %.3g steps, %.1f steps per window, %.0f %% of the windows prefetched, %.0f cycles per step of which %.0f in window fills\n",
+                (double)ra[8], (double)ra[8] / std::max<double>((double)ra[9], 1), 100.0 * (double)ra[12] / std::max<double>((double)ra[9], 1),
+                (double)ra[10] / std::max<double>((double)ra[8], 1), (double)ra[11] / std::max<double>((double)ra[8], 1));
     }
 #endif
     double tot = 1e-9;
