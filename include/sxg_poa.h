@@ -42,13 +42,15 @@
 extern "C" {
 #endif
 
-/* 4: block graphs on the device: sxg_poa_batch_in gained want_block_graph / bg_consensus_visited_only / bg_trim at its END
+/* 5: sxg_poa_batch_out gained block_cycles (before _owner): per-block time on the device, the reference's POA_DEBUG column
+ *    poa.time.ms (src/smooth.cpp:2121-2265); sxg_poa_sharded_timing.
+ * 4: block graphs on the device: sxg_poa_batch_in gained want_block_graph / bg_consensus_visited_only / bg_trim at its END
  *    (callers must zero-initialise the struct, as before), sxg_poa_batch_out the bg_* arrays before _owner; stats.bg_ms.
  * 3: params.banded = 2 (adaptive band); sxg_poa_batch_run_sharded fails on all ranks together and needs the exchange buffer
  *    that sxg_poa_comm_init / _attach allocate; a band miss is repaired inside the engine at any length.
  * 2 (round 2, never numbered): params.reserved became params.banded -- callers must zero it --, stats.reserved became
  *    dom_clock_mhz, status 7 (SXG_ST_BAND_MISS), SXG_POA_MAX_SEQ_LEN 12287 -> 26623 with SXG_POA_MAX_SEQ_LEN_WIDE. */
-#define SXG_POA_ABI_VERSION 4
+#define SXG_POA_ABI_VERSION 5
 
 #define SXG_MODE_LOCAL 0  /* spoa::AlignmentType::kSW */
 #define SXG_MODE_GLOBAL 1 /* spoa::AlignmentType::kNW */
@@ -180,6 +182,12 @@ typedef struct sxg_poa_batch_out {
     int32_t *bg_steps;        /* node id of every step of every sequence path */
     int64_t *bg_cons_off;     /* [n_blocks+1] (NULL unless want_consensus) */
     int32_t *bg_cons_steps;   /* steps of the consensus path */
+    /* Per-block time on the device (what the reference's -DPOA_DEBUG build tabulates per block as poa.time.ms,
+     * src/smooth.cpp:2121-2265, 2319-2350): shader-clock cycles between the moment a slot took the block and the moment it
+     * wrote the block's status -- every alignment, traceback and graph update of the block, in its LAST run (a block that
+     * was re-run on a larger arena or a wider sweep reports that run).  Milliseconds = cycles / (stats.dom_clock_mhz * 1e3).
+     * NULL in the results of a sharded run (the peers' blobs do not carry it). */
+    uint64_t *block_cycles;   /* [n_blocks] */
     void *_owner;
 } sxg_poa_batch_out;
 
@@ -292,6 +300,9 @@ int sxg_poa_batch_upload_sharded(sxg_poa_handle *h, const sxg_poa_batch_in *in);
 int sxg_poa_batch_execute_sharded(sxg_poa_handle *h);
 int sxg_poa_batch_download_sharded(sxg_poa_handle *h, const sxg_poa_batch_in *in, sxg_poa_batch_out *out);
 int sxg_poa_sharded_info(sxg_poa_handle *h, int32_t *ranks_seen, uint64_t *bytes_received);
+/* Host-clock milliseconds of the last _execute_sharded on this rank: packing its results into one device blob, and the
+ * exchange (two size all-gathers + the blobs to rank 0; includes waiting for the slowest rank to finish its share). */
+int sxg_poa_sharded_timing(sxg_poa_handle *h, double *pack_ms, double *exchange_ms);
 /* Test entry: the same partition / packing / assembly with `nranks` simulated ranks on this one GPU. */
 int sxg_poa_batch_run_sharded_local(sxg_poa_handle *h, const sxg_poa_batch_in *in, int nranks, sxg_poa_batch_out *out);
 

@@ -143,6 +143,7 @@ struct BlockArgs {
     uint32_t* prio_board;              // [PRIO_BOARD_CUS][PRIO_BOARD_SLOTS] progress board, shared by the launches of a round
     int prio_base;                     // first board rank of this launch (the launches before it took the ranks below)
     const unsigned long long* est;     // [n_work] estimated cells of work item wi (host cost model)
+    unsigned long long* blk_cycles;    // [n_blocks] shader-clock cycles the slot spent on block b (sxg_poa_batch_out::block_cycles)
 };
 
 // Kernel classes <TMAX, W>: TMAX bounds blockDim.x (the actual T = 64 * strips is a run-time
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             if (t == 0 && prof[8] == 0) { prof[8] = (unsigned long long)wall_clock64(); prof[6] = (unsigned long long)clock64(); }
         }
         unsigned long long tc0 = clock64(), tc1;
+        const unsigned long long tblk0 = tc0;
 #define PROF(k) do { if (t == 0) { tc1 = clock64(); prof[k] += tc1 - tc0; tc0 = tc1; } } while (0)
         for (int s = s0; s < s1 && status == ST_OK; ++s) {
             const int64_t so = A.seq_off[s];
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             if (A.want_consensus && t == 0) nc = consensus_serial(V.G, V.cons_sc, V.cons_pr, A.cons_nodes + base0);
             if (t == 0) { A.n_nodes[b] = N; A.n_edges[b] = E; A.n_cons[b] = nc; }
         } else if (t == 0) { A.n_nodes[b] = 0; A.n_edges[b] = 0; A.n_cons[b] = 0; }
-        if (t == 0) A.status[b] = status;
+        if (t == 0) { A.status[b] = status; if (A.blk_cycles) A.blk_cycles[b] = (unsigned long long)clock64() - tblk0; }
         if (t == 0 && V.B.prio_board) __hip_atomic_store(V.B.prio_board + V.B.prio_rank, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PROF(5);
         if (t == 0) { prof[9] = (unsigned long long)wall_clock64(); prof[7] = (unsigned long long)clock64(); }

@@ -337,7 +337,7 @@ struct sxg_poa_handle {
     DevBuf d_blk_off, d_seq_off, d_bases, d_weights, d_params;
     bool has_weights = false;
     DevBuf d_status, d_nn, d_ne, d_nc, d_node_code, d_node_rank, d_node_group, d_edge_tail, d_edge_head, d_edge_w,
-        d_paths, d_score, d_cells, d_cons, d_work, d_queue, d_arena;
+        d_paths, d_score, d_cells, d_cons, d_work, d_queue, d_arena, d_blk_cycles;
     DevBuf d_tmp_a, d_tmp_b, d_tmp_c, d_tmp_d;
     DevBuf d_board;   // the per-CU progress board (sxg_balance_prio) the launches of a round share
     // block graphs (want_block_graph): inputs, outputs in per-block layouts, the per-block counts of the last execute
@@ -364,6 +364,7 @@ struct sxg_poa_handle {
     bool sh_dealt = false, sh_exchanged = false;
     uint64_t sh_bytes_received = 0;
     int sh_ranks_seen = 0;
+    double sh_pack_ms = 0, sh_exchange_ms = 0;   // last sxg_poa_batch_execute_sharded: packing the blob; size all-gathers + blob exchange (waits for the slowest rank)
 };
 
 extern "C" int sxg_poa_abi_version(void) { return SXG_POA_ABI_VERSION; }
@@ -407,7 +408,7 @@ static void release_all(sxg_poa_handle* h) {
     DevBuf* bufs[] = {&h->d_blk_off, &h->d_seq_off, &h->d_bases, &h->d_weights, &h->d_params, &h->d_status, &h->d_nn,
                       &h->d_ne, &h->d_nc, &h->d_node_code, &h->d_node_rank, &h->d_node_group, &h->d_edge_tail,
                       &h->d_edge_head, &h->d_edge_w, &h->d_paths, &h->d_score, &h->d_cells, &h->d_cons, &h->d_work,
-                      &h->d_queue, &h->d_arena, &h->d_tmp_a, &h->d_tmp_b, &h->d_tmp_c, &h->d_tmp_d, &h->d_board, &h->d_trim, &h->d_bg_no, &h->d_bg_eo,
+                      &h->d_queue, &h->d_arena, &h->d_blk_cycles, &h->d_tmp_a, &h->d_tmp_b, &h->d_tmp_c, &h->d_tmp_d, &h->d_board, &h->d_trim, &h->d_bg_no, &h->d_bg_eo,
                       &h->d_bg_len, &h->d_bg_od, &h->d_bg_id, &h->d_bg_seq, &h->d_bg_eto, &h->d_bg_steps, &h->d_bg_nsteps, &h->d_bg_cons,
                       &h->d_bg_counts, &h->d_bg_work, &h->d_bg_queue, &h->d_bg_arena};
     for (DevBuf* b : bufs) b->release();
@@ -559,7 +560,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
         (rc = h->d_node_group.ensure(4 * NB)) || (rc = h->d_edge_tail.ensure(4 * NB)) ||
         (rc = h->d_edge_head.ensure(4 * NB)) || (rc = h->d_edge_w.ensure(4 * NB)) || (rc = h->d_paths.ensure(4 * NB)) ||
         (rc = h->d_score.ensure(4 * NS)) || (rc = h->d_cells.ensure(8 * NS)) || (rc = h->d_queue.ensure(256)) ||
-        (rc = h->d_work.ensure(4 * NBL)))
+        (rc = h->d_work.ensure(4 * NBL)) || (rc = h->d_blk_cycles.ensure(8 * NBL)))
         return rc;
     if (h->want_consensus && (rc = h->d_cons.ensure(4 * NB))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -716,6 +717,7 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, const int p
     A.prio_board = getenv("SXG_POA_NO_BALANCE") ? nullptr : h->d_board.as<uint32_t>();
     A.prio_base = prio_base;
     A.est = R.est.as<unsigned long long>();
+    A.blk_cycles = h->d_blk_cycles.as<unsigned long long>();
     // every slot's header (counters, phase times, clock readings) starts a launch at zero: one strided memset
     HIPCHK(hipMemset2DAsync(R.arena.as<uint8_t>() + P.lay.hdr, P.lay.total, 0, 512, (size_t)P.n_slots, R.stream));
     HIPCHK(hipStreamWaitEvent(R.stream, h->ev0, 0));
@@ -886,6 +888,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         HIPCHK(hipMemsetAsync(h->d_nn.p, 0, 4 * (size_t)nb, h->stream));
         HIPCHK(hipMemsetAsync(h->d_ne.p, 0, 4 * (size_t)nb, h->stream));
         HIPCHK(hipMemsetAsync(h->d_nc.p, 0, 4 * (size_t)nb, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_blk_cycles.p, 0, 8 * (size_t)nb, h->stream));
     }
     lap("setup");
     std::vector<LaunchPlan> all_plans;
@@ -1165,7 +1168,7 @@ struct OutOwner {
     std::vector<int64_t> node_off, edge_off, cons_off, msa_off;
     hvec<uint8_t> node_code;
     hvec<uint32_t> edge_weight;
-    std::vector<uint64_t> cells;
+    std::vector<uint64_t> cells, block_cycles;
     std::vector<char> msa;
     // block graphs
     std::vector<int64_t> bg_node_off, bg_seq_off, bg_edge_off, bg_step_off, bg_cons_off;
@@ -1309,6 +1312,9 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
         if (h->want_consensus) { out->bg_cons_off = o->bg_cons_off.data(); out->bg_cons_steps = o->bg_cons_steps.data(); }
         laps.lap("download: block graphs");
     }
+    o->block_cycles.assign((size_t)std::max(nb, 1), 0);
+    if (nb) HIPCHK(hipMemcpy(o->block_cycles.data(), h->d_blk_cycles.p, 8 * (size_t)nb, hipMemcpyDeviceToHost));
+    out->block_cycles = o->block_cycles.data();
     if (ns) {
         HIPCHK(hipMemcpy(o->score.data(), h->d_score.p, 4 * (size_t)ns, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(o->cells.data(), h->d_cells.p, 8 * (size_t)ns, hipMemcpyDeviceToHost));
@@ -1918,7 +1924,11 @@ extern "C" int sxg_poa_batch_execute_sharded(sxg_poa_handle* h) {
     counts.assign((size_t)nranks * BC_N, 0);
     int64_t* mine = counts.data() + (size_t)rank * BC_N;
     int rc = h->have_batch ? sxg_poa_batch_execute(h) : fail(SXG_E_INVALID, "no batch uploaded");
+    const auto t_pack = std::chrono::steady_clock::now();
     if (!rc || rc == SXG_E_BLOCK) rc = pack_blob(h, mine);   // (per-block failures travel in the status array)
+    const auto t_xch = std::chrono::steady_clock::now();
+    h->sh_pack_ms = std::chrono::duration<double, std::milli>(t_xch - t_pack).count();
+    h->sh_exchange_ms = 0;
     if (!h->comm) {
         if (rc) return rc;
         h->sh_at.assign(2, 0); h->sh_exchanged = true; h->sh_ranks_seen = 1;
@@ -1982,7 +1992,15 @@ extern "C" int sxg_poa_batch_execute_sharded(sxg_poa_handle* h) {
             if (r != 0 && rank == 0) h->sh_bytes_received += (uint64_t)counts[(size_t)r * BC_N + BC_BYTES];
         }
     }
+    h->sh_exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_xch).count();
     h->sh_exchanged = true;
+    return SXG_OK;
+}
+
+extern "C" int sxg_poa_sharded_timing(sxg_poa_handle* h, double* pack_ms, double* exchange_ms) {
+    if (!h) return fail(SXG_E_INVALID, "handle is NULL");
+    if (pack_ms) *pack_ms = h->sh_pack_ms;
+    if (exchange_ms) *exchange_ms = h->sh_exchange_ms;
     return SXG_OK;
 }
 

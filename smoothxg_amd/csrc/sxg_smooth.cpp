@@ -1156,6 +1156,7 @@ struct cblock_t {
     std::vector<int32_t> range_useq;                          // path range (rank in the block) -> dedup'd sequence
     std::vector<char> range_rev;                              //                                  -> collected in reverse
     std::unique_ptr<cstore_t> own;
+    int validated = 0;                                        // 1 / -1: its ranges were checked (ok / not) when its chunk came back
     void index(const collected_t& c, size_t n_ranges, uint32_t* so, uint32_t* eo) {
         uint32_t a = 0, e = 0;
         for (int64_t v = 0; v < n; ++v) { so[(size_t)v] = a; eo[(size_t)v] = e; a += (uint32_t)len[v]; e += (uint32_t)outdeg[v]; }
@@ -1311,6 +1312,62 @@ struct write_sink_t {
 //     chains live in small per-block tables, node ids shift by the number of removed nodes in front of them;
 //   * edges keep their order under that renumbering except those that leave a merged chain and the links, which are
 //     sorted apart and merged in by position while the L lines are written.
+// Validation of one fragment (src/main.cpp:770-810, per range): the steps of the range's sequence in its block graph spell the
+// range's original sequence.  `st` / `cnt` / `rv`: the dedup'd sequence's step list and whether the range was collected in reverse.
+// Also checks what the text writer relies on: every step names a node of the block, a sequence's steps ascend strictly.
+static bool fragment_spells_its_range(const sxg_graph* g, const path_range_t& r, const cblock_t& B, const int32_t* st, int64_t cnt, bool rv) {
+    // the range's original sequence, once, into a thread-local buffer; then the fragment's nodes against it
+    static thread_local std::string os;
+    os.clear();
+    for (uint64_t q = r.begin; q < r.end; ++q) {
+        const handle_t h = g->steps[r.path][q];
+        const std::string& sq = g->seq[nid(h)];
+        if (!rev(h)) os.append(sq);
+        else { const size_t a0 = os.size(); os.resize(a0 + sq.size()); for (size_t y = 0; y < sq.size(); ++y) os[a0 + y] = comp(sq[sq.size() - 1 - y]); }
+    }
+    const char* ob = os.data();
+    const size_t on = os.size();
+    size_t at = 0;
+    bool ok = true;
+    const char* bs = B.seq;
+    const uint32_t* so = B.soff;
+    // (the step lists come from the provider: every step must name a node of its block, and a sequence's steps must be
+    //  strictly ascending -- the block graph is topologically numbered and its paths walk forward; the size pass of the
+    //  text writer relies on it when it looks steps up by binary search)
+    const uint64_t nB = (uint64_t)B.n;
+    int64_t prev = -1;
+    if (!rv) {
+        // (comparing whole runs of consecutive ids with memcmp -- consecutive nodes lie side by side in the block's bytes --
+        //  was measured on the box: 0.060 s against 0.042 s for this loop; the runs are a few bases long)
+        for (int64_t j = 0; j < cnt; ++j) {
+            if ((uint64_t)(uint32_t)st[j] >= nB || (int64_t)st[j] <= prev) { ok = false; break; }
+            prev = st[j];
+            const uint32_t a0 = so[st[j]], a1 = so[st[j] + 1];
+            if (at + (a1 - a0) > on) { ok = false; break; }
+            for (uint32_t y = a0; y < a1; ++y) ok &= bs[y] == ob[at++];
+        }
+    } else {
+        prev = (int64_t)nB;
+        for (int64_t j = cnt - 1; j >= 0; --j) {
+            if ((uint64_t)(uint32_t)st[j] >= nB || (int64_t)st[j] >= prev) { ok = false; break; }
+            prev = st[j];
+            const uint32_t a0 = so[st[j]], a1 = so[st[j] + 1];
+            if (at + (a1 - a0) > on) { ok = false; break; }
+            for (uint32_t y = a1; y > a0; --y) ok &= comp(bs[y - 1]) == ob[at++];
+        }
+    }
+    return ok && at == on;
+}
+// ... of every range of a block (the chunk pipeline calls this while the POA provider works on the next chunk)
+static bool block_spells_its_ranges(const sxg_graph* g, const std::vector<path_range_t>& ranges, const cblock_t& B) {
+    if (B.n == 0) return true;
+    for (size_t ri = 0; ri < ranges.size(); ++ri) {
+        const int32_t u = B.range_useq[ri];
+        if (!fragment_spells_its_range(g, ranges[ri], B, u >= 0 ? B.upath[(size_t)u].first : nullptr, u >= 0 ? B.upath[(size_t)u].second : 0, B.range_rev[ri] != 0)) return false;
+    }
+    return true;
+}
+
 struct lace_timer_t { std::function<void(const char*)> lap; };
 int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params* p, std::vector<cblock_t>& cb, char** out_gfa,
               const std::function<void(const char*)>& lap) {
@@ -1384,50 +1441,15 @@ int lace_fast(const sxg_graph* g, const sxg_blockset* b, const sxg_smooth_params
         int64_t bad = -1;
 #pragma omp parallel for schedule(dynamic, 16)
         for (int64_t f = 0; f < (int64_t)nf; ++f) {
-            const fview_t v = fview((size_t)f);
             const cblock_t& B = cb[(size_t)mapping[(size_t)f].block];
-            const path_range_t& r = b->blocks[(size_t)mapping[(size_t)f].block][(size_t)mapping[(size_t)f].target];
-            // the range's original sequence, once, into a thread-local buffer; then the fragment's nodes against it
-            static thread_local std::string os;
-            os.clear();
-            for (uint64_t st = r.begin; st < r.end; ++st) {
-                const handle_t h = g->steps[r.path][st];
-                const std::string& sq = g->seq[nid(h)];
-                if (!rev(h)) os.append(sq);
-                else { const size_t a0 = os.size(); os.resize(a0 + sq.size()); for (size_t y = 0; y < sq.size(); ++y) os[a0 + y] = comp(sq[sq.size() - 1 - y]); }
+            if (B.validated == 1) continue;   // (done per block while the provider worked on a later chunk)
+            bool ok = B.validated == 0;       // (-1: that check failed -- report it with the path's name here)
+            if (ok) {
+                const fview_t v = fview((size_t)f);
+                const path_range_t& r = b->blocks[(size_t)mapping[(size_t)f].block][(size_t)mapping[(size_t)f].target];
+                ok = fragment_spells_its_range(g, r, B, v.st, v.cnt, v.rv);
             }
-            const char* ob = os.data();
-            const size_t on = os.size();
-            size_t at = 0;
-            bool ok = true;
-            const char* bs = B.seq;
-            const uint32_t* so = B.soff;
-            // (the step lists come from the provider: every step must name a node of its block, and a sequence's steps must be
-            //  strictly ascending -- the block graph is topologically numbered and its paths walk forward; the size pass of the
-            //  text writer relies on it when it looks steps up by binary search)
-            const uint64_t nB = (uint64_t)B.n;
-            int64_t prev = -1;
-            if (!v.rv) {
-                // (comparing whole runs of consecutive ids with memcmp -- consecutive nodes lie side by side in the block's bytes --
-                //  was measured on the box: 0.060 s against 0.042 s for this loop; the runs are a few bases long)
-                for (int64_t j = 0; j < v.cnt; ++j) {
-                    if ((uint64_t)(uint32_t)v.st[j] >= nB || (int64_t)v.st[j] <= prev) { ok = false; break; }
-                    prev = v.st[j];
-                    const uint32_t a0 = so[v.st[j]], a1 = so[v.st[j] + 1];
-                    if (at + (a1 - a0) > on) { ok = false; break; }
-                    for (uint32_t y = a0; y < a1; ++y) ok &= bs[y] == ob[at++];
-                }
-            } else {
-                prev = (int64_t)nB;
-                for (int64_t j = v.cnt - 1; j >= 0; --j) {
-                    if ((uint64_t)(uint32_t)v.st[j] >= nB || (int64_t)v.st[j] >= prev) { ok = false; break; }
-                    prev = v.st[j];
-                    const uint32_t a0 = so[v.st[j]], a1 = so[v.st[j] + 1];
-                    if (at + (a1 - a0) > on) { ok = false; break; }
-                    for (uint32_t y = a1; y > a0; --y) ok &= comp(bs[y - 1]) == ob[at++];
-                }
-            }
-            if (!ok || at != on) {
+            if (!ok) {
 #pragma omp critical(sxg_lace_bad)
                 if (bad < 0 || f < bad) bad = f;
             }
@@ -2275,6 +2297,10 @@ static int smooth_iteration(const sxg_graph* g, const sxg_blockset* b, const sxg
                     cblock_from_raw(Bk, c, b->blocks[(size_t)k].size(), out.node_code + n0, nn, sp, hc ? out.cons_nodes + out.cons_off[slot] : nullptr,
                                     hc ? out.cons_off[slot + 1] - out.cons_off[slot] : 0, p->add_consensus != 0, p->use_abpoa != 0);
                 }
+                // With several chunks in flight this stage runs while the provider -- on a sharded run: every rank's GPU -- works
+                // on the next chunk: the block's share of the validation (src/main.cpp:770-810) is done here, off the serial
+                // tail behind the last chunk.  (One chunk: nothing to overlap with, lace_fast does it.)
+                if (nc > 1) Bk.validated = block_spells_its_ranges(g, b->blocks[(size_t)k], Bk) ? 1 : -1;
                 continue;   // (the padded sequences go with everything else when the iteration is over)
             }
             graphs[(size_t)k] = block_graph_from_out(col[(size_t)k], C.B, out, slot, cons_name(*p, k), p->use_abpoa != 0);

@@ -47,7 +47,7 @@ class BatchOut(C.Structure):
                 ("bg_node_off", _i64p), ("bg_node_len", _i32p), ("bg_node_outdeg", _i32p), ("bg_node_indeg", _u8p),
                 ("bg_seq_off", _i64p), ("bg_seq", C.c_void_p), ("bg_edge_off", _i64p), ("bg_edge_to", _i32p),
                 ("bg_step_off", _i64p), ("bg_steps", _i32p), ("bg_cons_off", _i64p), ("bg_cons_steps", _i32p),
-                ("_owner", C.c_void_p)]
+                ("block_cycles", _u64p), ("_owner", C.c_void_p)]
 
 
 class AlignIn(C.Structure):
@@ -82,7 +82,8 @@ EXPORTS = ["sxg_poa_batch_device_view", "sxg_poa_abi_version", "sxg_poa_device_c
            "sxg_poa_batch_download", "sxg_poa_batch_free", "sxg_poa_align_batch", "sxg_poa_align_free",
            "sxg_poa_get_stats", "sxg_poa_set_memory_budget", "sxg_xxh64", "sxg_poa_comm_unique_id", "sxg_poa_comm_init",
            "sxg_poa_comm_attach", "sxg_poa_comm_destroy", "sxg_poa_batch_run_sharded", "sxg_poa_batch_run_sharded_local",
-           "sxg_poa_batch_upload_sharded", "sxg_poa_batch_execute_sharded", "sxg_poa_batch_download_sharded", "sxg_poa_sharded_info"]
+           "sxg_poa_batch_upload_sharded", "sxg_poa_batch_execute_sharded", "sxg_poa_batch_download_sharded", "sxg_poa_sharded_info",
+           "sxg_poa_sharded_timing"]
 COMM_ID_BYTES = 128
 NOT_ROOT = 1
 
@@ -125,6 +126,7 @@ def load_library(build_if_missing=True):
     L.sxg_poa_batch_execute_sharded.argtypes = [vp]
     L.sxg_poa_batch_download_sharded.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(BatchOut)]
     L.sxg_poa_sharded_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    L.sxg_poa_sharded_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.sxg_xxh64.restype = C.c_uint64
     L.sxg_xxh64.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
     _lib = L
@@ -148,7 +150,7 @@ def _arr(ptr, n, dtype):
 class BlockResult:
     """POA result of one block (what build_odgi_SPOA reads from spoa::Graph)."""
     __slots__ = ("status", "node_code", "node_rank", "node_group", "edge_tail", "edge_head", "edge_weight",
-                 "paths", "scores", "cells", "consensus", "msa", "bg")
+                 "paths", "scores", "cells", "consensus", "msa", "bg", "device_cycles")
 
 
 class BlockGraph:
@@ -295,6 +297,7 @@ class PoaEngine:
                 bg["cs"] = _arr(out.bg_cons_steps, int(bg["co"][-1]), np.int32)
         score = _arr(out.score, ns, np.int32)
         cells = _arr(out.cells, ns, np.uint64)
+        cycles = _arr(out.block_cycles, nb, np.uint64) if out.block_cycles else None
         cons_off = _arr(out.cons_off, nb + 1, np.int64) if out.cons_off else None
         cons = _arr(out.cons_nodes, int(cons_off[-1]), np.int32) if cons_off is not None and nb and out.cons_nodes else None
         msa_off = _arr(out.msa_off, nb + 1, np.int64) if out.msa_off else None
@@ -326,6 +329,7 @@ class PoaEngine:
                 g.consensus = bg["cs"][int(bg["co"][b]):int(bg["co"][b + 1])] if "co" in bg else None
                 r.bg = g
             r.scores, r.cells = score[s0:s1], cells[s0:s1]
+            r.device_cycles = int(cycles[b]) if cycles is not None else None   # (sxg_poa_batch_out::block_cycles)
             r.consensus = cons[cons_off[b]:cons_off[b + 1]] if cons is not None else None
             r.msa = None
             if msa_raw is not None and r.status == 0:
@@ -404,7 +408,9 @@ class PoaEngine:
     def sharded_info(self):
         n, b = C.c_int32(), C.c_uint64()
         self.lib.sxg_poa_sharded_info(self.h, C.byref(n), C.byref(b))
-        return {"ranks_seen": n.value, "bytes_received": b.value}
+        pk, ex = C.c_double(), C.c_double()
+        self.lib.sxg_poa_sharded_timing(self.h, C.byref(pk), C.byref(ex))
+        return {"ranks_seen": n.value, "bytes_received": b.value, "pack_ms": pk.value, "exchange_ms": ex.value}
 
     def run_blocks(self, blocks, params, weights=None, want_consensus=False, want_msa=False, check=True):
         """blocks: list of lists of uint8 code arrays (one inner list per block, alignment order)."""

@@ -25,14 +25,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "missing export " + n
     from smoothxg_amd import poa
     assert sorted(poa.EXPORTS) == names
-    assert lib.sxg_poa_abi_version() == 4
+    assert lib.sxg_poa_abi_version() == 5
 
 
 def test_struct_layouts_match_header():
     from smoothxg_amd import poa
     assert C.sizeof(poa.Params) == 8
     assert C.sizeof(poa.BatchIn) == 8 + 5 * 8 + 5 * 4 + 4 + 8  # n_blocks(+pad), 5 pointers, 5 ints (+pad), bg_trim
-    assert C.sizeof(poa.BatchOut) == 8 + 8 + 17 * 8 + 12 * 8 + 8   # n_blocks(+pad), n_seqs, 17 + 12 (block graph) pointers, _owner
+    assert C.sizeof(poa.BatchOut) == 8 + 8 + 17 * 8 + 12 * 8 + 8 + 8   # n_blocks(+pad), n_seqs, 17 + 12 (block graph) pointers, block_cycles, _owner
     assert C.sizeof(poa.Stats) == 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 4 + 4 + 4 + 4 + 8
 
 

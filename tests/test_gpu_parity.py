@@ -408,7 +408,8 @@ def test_sharded_run_reassembles_in_block_order(engine, oracle):
         engine.upload_sharded(bases, seq_off, blk_off, w, gp, want_consensus=True, want_msa=True)
         for _ in range(2):
             engine.execute_sharded()
-            assert engine.sharded_info() == {"ranks_seen": 1, "bytes_received": 0}
+            info = engine.sharded_info()
+            assert (info["ranks_seen"], info["bytes_received"]) == (1, 0) and info["pack_ms"] >= 0 and info["exchange_ms"] >= 0
         same(engine.download_sharded())
     finally:
         engine.lib.sxg_poa_comm_destroy(engine.h)
@@ -484,3 +485,19 @@ def test_spoa_order_option_on_the_device(engine, oracle, mode):
         gg, sc, cells = oracle.block_run(seqs, None, op)
         assert_block_equal(res[b], gg, sc, cells, f"spoa order, block {b}")
         assert (res[b].consensus == gg.consensus()).all() and res[b].msa == gg.msa(True)
+
+
+def test_per_block_device_time_is_reported(engine):
+    """SURVEY section 5 / the reference's POA_DEBUG table (src/smooth.cpp:2121-2265): every block comes back with the
+    shader-clock cycles its slot spent on it.  A block of 12 x 1 kbp costs more than one of 3 x 300 bp, an empty block nothing
+    worth mentioning, and the sum over a batch cannot exceed slots x kernel time."""
+    from smoothxg_amd import synth
+    big = synth.make_block(1, 12, 1000)
+    small = synth.make_block(2, 3, 300)
+    res = engine.run_blocks([big, small, [], big], gparams("convex_default", 0))
+    st = engine.stats()
+    cyc = [r.device_cycles for r in res]
+    assert all(c is not None for c in cyc) and cyc[0] > 4 * cyc[1] > 0 and cyc[2] < cyc[1]
+    assert abs(cyc[0] - cyc[3]) < 0.5 * cyc[0]
+    ms = [c / (st["dom_clock_mhz"] * 1e3) for c in cyc]
+    assert 0 < max(ms) <= st["kernel_ms"] * 1.05

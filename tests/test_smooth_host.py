@@ -529,7 +529,7 @@ def test_integration_snippet_compiles_and_links_against_the_c_abi(tmp_path):
                            "-Wl,-rpath," + os.path.join(root, "smoothxg_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 4" in r.stdout
+    assert "abi 5" in r.stdout
 
 
 def test_ready_made_and_multi_gpu_snippets_compile_and_link(tmp_path):
@@ -834,4 +834,9 @@ def test_validation_catches_a_corrupted_block(legacy, monkeypatch):
     assert good.startswith("H\tVN:Z:1.0")
     with pytest.raises(S.SmoothError, match="corrupted"):
         sm.smooth_gfa(p, Corrupting().provider())
+    if not legacy:   # several chunks: every block's ranges are checked when its chunk comes back, the failure surfaces the same way
+        monkeypatch.setenv("SXG_SMOOTH_CHUNK_BLOCKS", "2")
+        assert sm.smooth_gfa(p, OracleProvider().provider()) == good
+        with pytest.raises(S.SmoothError, match="corrupted"):
+            sm.smooth_gfa(p, Corrupting().provider())
     sm.close()
