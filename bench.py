@@ -32,6 +32,9 @@ WORKLOADS = {
     # name: (blocks, seqs, length, params (m,n,g,e,q,c spoa convention), description)
     "ns": (1000, 64, 5000, (1, -4, -6, -2, -26, -1), "north-star: 1000 blocks x 64 seqs x 5 kbp, convex 1,4,6,2,26,1"),
     "c2": (1000, 16, 1000, (1, -4, -6, -2, -26, -1), "config 2: 1000 blocks x 16 seqs x 1 kbp, convex 1,4,6,2,26,1"),
+    # config 2's shape in the batch size real runs have (DRB1 at -l 700: 2 161 blocks per iteration; a human chromosome: 10^5): the
+    # batch fills the chip with one wave per block
+    "c2x8": (8000, 16, 1000, (1, -4, -6, -2, -26, -1), "config 2's blocks, 8000 of them: 8000 blocks x 16 seqs x 1 kbp, convex 1,4,6,2,26,1"),
     # the headline shape with smoothxg's four-parameter scores (spoa: q = g, c = e): in --mode nw the all-gap corner is -20 006
     "ns4": (1000, 64, 5000, (1, -4, -6, -2, -6, -2), "headline shape, affine 1,4,6,2 (four-parameter form): 1000 blocks x 64 seqs x 5 kbp"),
     "c3": (5000, 64, 5000, (1, -4, -8, -2, -8, -2), "config 3: 5000 blocks x 64 seqs x 5 kbp, affine (abPOA o+k*e => g=-(o+e)), full matrix"),
@@ -275,7 +278,7 @@ def profile_counters(key):
     return w
 
 # fixture names of the blocks tests/golden/fullshape_oracle.json holds for a bench workload: (workload, mode) -> case name
-FIXTURE_CASE = {("ns", "sw"): "ns_sw", ("ns", "nw"): "ns_nw", ("ns4", "nw"): "ns_nw_affine", ("c3", "sw"): "c3", ("c2", "sw"): "c2"}
+FIXTURE_CASE = {("c2x8", "sw"): "c2", ("ns", "sw"): "ns_sw", ("ns", "nw"): "ns_nw", ("ns4", "nw"): "ns_nw_affine", ("c3", "sw"): "c3", ("c2", "sw"): "c2"}
 
 
 def digest_block(r):
@@ -645,7 +648,7 @@ def main():
             "exchange": ({"path": "C ABI: sxg_poa_batch_execute_sharded (RCCL all-gather of sizes + grouped ncclSend/ncclRecv to rank 0)"
                           if exchange == "cabi" else exchange, **(eng.sharded_info() if exchange == "cabi" else {})} if world > 1 else None),
         }
-        if world == 1 and not a.no_e2e and a.workload in ("ns", "c2", "tiny"):
+        if world == 1 and not a.no_e2e and a.workload in ("ns", "c2", "c2x8", "tiny"):
             e_s, e_bytes, e_first = end_to_end(eng, bases, seq_off, blk_off, prm, mode)
             out["end_to_end"] = {"what": "sxg_smooth_gfa on the same %d blocks: host collection + upload + POA kernels + "
                                          "download + block graphs + lacing + validation + unchop + GFA text (padding off)" % nb,

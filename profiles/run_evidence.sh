@@ -19,13 +19,18 @@ for ITEM in ${WLS:-c2 c3b c4 ns:nw c3}; do
   WL=${ITEM%%:*}; MODE=sw; NAME=$WL; case $ITEM in *:*) MODE=${ITEM##*:}; NAME=${WL}_$MODE;; esac
   python bench.py --workload $WL --mode $MODE --steps ${WL_STEPS:-2} --warmup 1 --no-cpu-baseline --no-e2e > $OUT/bench_$NAME.json 2> $OUT/bench_$NAME.err
 done
+# round 5: the small-block shape at 8000 blocks (the batch fills the chip), config 2 with its end-to-end figure and CPU baseline,
+# the reference's DRB1 ctest chain (wall seconds)
+python bench.py --workload c2 --steps 5 --warmup 2 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+python bench.py --workload c2x8 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_c2x8.json 2> $OUT/bench_c2x8.err
+python bench.py --workload drb1 --steps 3 --warmup 1 > $OUT/bench_drb1.json 2> $OUT/bench_drb1.err
 tail -3 $OUT/ev_collect.log
 for f in $OUT/bench_*.json; do python - "$f" <<'PY'
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
-    r = d["roofline"]
-    print(sys.argv[1].split("/")[-1], round(d["value"], 1), d["unit"], "kernel ms", round(r["kernel_ms_per_launch"], 1), r["bound"], round(r["frac"], 3),
+    r = d["roofline"] or {"kernel_ms_per_launch": 0.0, "bound": "-", "frac": 0.0}
+    print(sys.argv[1].split("/")[-1], round(d["value"], 3), d["unit"], "verified", d.get("verified"), "kernel ms", round(r["kernel_ms_per_launch"], 1), r["bound"], round(r["frac"], 3),
           "match", r.get("valu", {}).get("counters_match_build"), "e2e", (d.get("end_to_end") or {}).get("ratio_to_kernel_only"))
 except Exception as e:
     print(sys.argv[1], "unreadable", e)

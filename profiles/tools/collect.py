@@ -147,6 +147,6 @@ for src in sorted(glob.glob(os.path.join(OUT, "bench_*.json"))):
         continue
     name = os.path.basename(src)
     open(os.path.join(dst, name), "w").write(json.dumps(bl) + "\n")
-    r = bl["roofline"]
-    print("%s: %.1f %s, kernel %.1f ms, bound %s, frac %.3f, counters_match_build %s" % (
+    r = bl["roofline"] or {"kernel_ms_per_launch": 0.0, "bound": "-", "frac": 0.0}
+    print("%s: %.3f %s, kernel %.1f ms, bound %s, frac %.3f, counters_match_build %s" % (
         name, bl["value"], bl["unit"], r["kernel_ms_per_launch"], r["bound"], r["frac"], r.get("valu", {}).get("counters_match_build")))

@@ -246,7 +246,10 @@ __device__ __forceinline__ int band_first_strip(const int hint_col, const int W,
 // best diagonal runs through: 15 % of the row on 1 kbp blocks).  Rows are numbered within epochs of 65536; at an epoch's end the
 // wave folds its keys into a scalar 64-bit best.  The sweep returns the STRIP of the end cell (bj = -(strip + 1)); the
 // traceback reads the column out of the plane row it starts from.
-template <int W, bool CVX, bool SW, int CB = 4, int EXP = 0>
+// RP: the class may run with a plane that keeps every strip and read stored rows back from it (ring_plane below) -- the
+// one- and two-wave classes (TMAX = 128); the wider classes are compiled without that path (its three fetch sites and their
+// scalars cost the four-wave headline class SGPR spills in the row loop).
+template <int W, bool CVX, bool SW, int CB = 4, bool RP = false, int EXP = 0>
 __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R, const int N_,
                                              const uint8_t* seq, const int L_, const DpBuffers B,
                                              char* smem) {
@@ -295,7 +298,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     // produces --, the every-strip plane of a band-miss re-run) already holds what the row ring would: stored rows are not
     // written a second time, a stored predecessor is read back from its plane row and decoded.  (Cost map of 8000 x 16 x 1 kbp,
     // round 5: ring stores 14 % of the sweep, at the HBM write roof.)
-    const bool ring_plane = CB == 2 && BS == 2 * T;
+    const bool ring_plane = RP && CB == 2 && BS == 2 * T;
     // ---- wave pipeline.  The waves of a workgroup do NOT meet inside the row loop.  Wave w sweeps row i as soon as wave
     // w-1 has handed over, through a ring of P16_MBOX mailboxes in LDS, the three values that cross its left edge in row i:
     // E and Q entering its first column and H of the column left of it (one 16-byte word {E, Q, H, row}, written and read

@@ -38,8 +38,10 @@ inline size_t lay(size_t& cur, size_t bytes) {
 
 // band_strips > 0: packed sweep with strips of Lpad / (2 * threads) columns; cell_bytes: its plane cell format (2: delta
 // codes, W + 1 halfwords per strip; 4: one dword per cell)
+// spoa_scratch: the launch holds blocks that ask for spoa's depth-first order (S7'): stack and marks of the re-sort, ~30 bytes per
+// node of nodes_cap -- left out of every other arena
 inline SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int step_cap, int threads, int Lpad,
-                              int word_bytes, bool pairs, int band_strips = 0, int cell_bytes = 4) {
+                              int word_bytes, bool pairs, int band_strips = 0, int cell_bytes = 4, bool spoa_scratch = true) {
     SlotLayout L;
     memset(&L, 0, sizeof(L));
     L.nodes_cap = nodes_cap; L.rows_cap = rows_cap; L.pool_slots = pool_slots;
@@ -60,7 +62,8 @@ inline SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int s
     L.posnode = lay(cur, 4 * S); L.target = lay(cur, 4 * S); L.newidx = lay(cur, 4 * S);
     L.nexta = lay(cur, 4 * S); L.preva = lay(cur, 4 * S); L.slotadd = lay(cur, 4 * S); L.kind = lay(cur, S);
     L.xpos = lay(cur, 4 * C);
-    L.via = lay(cur, 4 * C); L.dfs_stack = lay(cur, 4 * (7 * C + 8)); L.dfs_marks = lay(cur, 2 * C + 8);
+    L.via = lay(cur, 4 * C);
+    L.dfs_stack = lay(cur, spoa_scratch ? 4 * (7 * C + 8) : 256); L.dfs_marks = lay(cur, spoa_scratch ? 2 * C + 8 : 256);
     L.r_code = lay(cur, Rr); L.r_flags = lay(cur, Rr); L.r_pred_off = lay(cur, 4 * Rr);
     L.r_preds = lay(cur, 4 * C); L.r_slot = lay(cur, 4 * Rr); L.r_tbx = lay(cur, 4 * Rr);
     L.r_sseq = lay(cur, 4 * Rr); L.r_row_node = lay(cur, 4 * Rr); L.r_meta = lay(cur, 32 * Rr);
@@ -225,8 +228,8 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                 const int band_mode = RM == 3 ? (int)A.params[A.per_block_params ? b : 0].banded : 0;   // 1 = B2, 2 = adaptive (B4)
                 // (workgroups of one and two waves take more elements per thread and step: see WgCtxT)
                 const int hinted_ = RM == 3 ? (band_mode == 2 ? 3 : 2) : (RM == 2 ? 1 : 0);
-                if (TMAX <= 256 && T <= 64) { WgCtxT<16> c16{ctx.lds}; status = prep_rows(c16, V.G, V.R, caps, hinted_); }
-                else if (TMAX <= 256 && T <= 128) { WgCtxT<8> c8{ctx.lds}; status = prep_rows(c8, V.G, V.R, caps, hinted_); }
+                if (TMAX <= 128 && T <= 64) { WgCtxT<16> c16{ctx.lds}; status = prep_rows(c16, V.G, V.R, caps, hinted_); }
+                else if (TMAX <= 128 && T <= 128) { WgCtxT<8> c8{ctx.lds}; status = prep_rows(c8, V.G, V.R, caps, hinted_); }
                 else status = prep_rows(ctx, V.G, V.R, caps, hinted_);
                 if (status != ST_OK) break;
                 PROF(1);
@@ -258,9 +261,9 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     for (int att = 0;; ++att) {
 #ifdef SXG_EXP
                         // (development: a sweep with parts switched off in front of the real one -- see dp_fill_p16's EXP)
-                        if (att == 0) { res = dp_fill_p16<W, CVX, SW, CB, SXG_EXP>(S, V.R, N, seq, len, V.B, smem); __syncthreads(); if (res.best == 0x7fffffff) break; }
+                        if (att == 0) { res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, SXG_EXP>(S, V.R, N, seq, len, V.B, smem); __syncthreads(); if (res.best == 0x7fffffff) break; }
 #endif
-                        res = dp_fill_p16<W, CVX, SW, CB>(S, V.R, N, seq, len, V.B, smem);
+                        res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128>(S, V.R, N, seq, len, V.B, smem);
                         __syncthreads();
                         PROF(2);
                         if (t == 0) { lds[TBM_FLAG] = 0; lds[TBM_RANGE] = 0; }
@@ -293,8 +296,8 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             }
             if (t == 0) { A.score[s] = score; if (RM != 3 || N == 0 || len == 0) A.cells[s] = RM == 3 ? 0ull : (unsigned long long)N * (unsigned long long)len; }
             done_cells += (unsigned long long)N * (unsigned long long)len;
-            if (TMAX <= 256 && T <= 64) { WgCtxT<16> c16{ctx.lds}; add_alignment(c16, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
-            else if (TMAX <= 256 && T <= 128) { WgCtxT<8> c8{ctx.lds}; add_alignment(c8, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
+            if (TMAX <= 128 && T <= 64) { WgCtxT<16> c16{ctx.lds}; add_alignment(c16, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
+            else if (TMAX <= 128 && T <= 128) { WgCtxT<8> c8{ctx.lds}; add_alignment(c8, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
             else add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
             if (A.params[A.per_block_params ? b : 0].mode & SXG_ORDER_SPOA) {   // S7': spoa's depth-first re-sort (one lane)
                 if (t == 0) spoa_resort(V.G);

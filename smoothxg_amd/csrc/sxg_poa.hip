@@ -158,7 +158,7 @@ static bool variant_for_len(int maxlen, int rm, Variant* v, bool sw = false) {
         if (const char* e = getenv("SXG_POA_FORCE_P16")) {
             int fw = 0, fnw = 0;
             if (sscanf(e, "%d,%d", &fw, &fnw) == 2 && 128L * fnw * fw >= maxlen + 1) {
-                *v = Variant{fw, fnw, fnw <= 4 ? 256 : (fnw <= 8 ? 512 : 1024), rm};
+                *v = Variant{fw, fnw, fnw <= 2 ? 128 : (fnw <= 4 ? 256 : (fnw <= 8 ? 512 : 1024)), rm};
                 return true;
             }
         }
@@ -181,7 +181,7 @@ static bool variant_for_len(int maxlen, int rm, Variant* v, bool sw = false) {
             if (wide && NW > 8 && !long_class) continue;
             if (best_cols < 0 || cols < best_cols) {
                 best_cols = cols;
-                *v = Variant{W, NW, NW <= 4 ? 256 : (NW <= 8 ? 512 : 1024), rm};
+                *v = Variant{W, NW, (rm == 2 && NW <= 2) ? 128 : (NW <= 4 ? 256 : (NW <= 8 ? 512 : 1024)), rm};   // (packed: one and two waves have classes of their own)
             }
             break;  // larger NW for this W only adds padding
         }
@@ -595,11 +595,13 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     const int Lpad = V.Lpad();
     int nodes_cap = 0, maxlen = 0;
     bool any_adaptive = false;   // banded blocks with the adaptive band (B4): a row's band may span the whole 128-strip window
+    bool any_spoa = false;       // blocks that ask for spoa's depth-first order: the only ones whose arena carries its scratch
     double rows_est = 0;  // graph rows a block is expected to reach: every further sequence adds ~1.5 % of its
                           // length in new nodes on pangenome-like input (measured on the synthetic blocks: 1.43 %)
     for (int b : P.work) {
         const BlockMeta& m = h->meta[b];
         any_adaptive = any_adaptive || h->h_params[h->per_block_params ? b : 0].banded == 2;
+        any_spoa = any_spoa || (h->h_params[h->per_block_params ? b : 0].mode & SXG_ORDER_SPOA) != 0;
         nodes_cap = (int)std::max<int64_t>(nodes_cap, m.sumlen);
         maxlen = std::max(maxlen, m.maxlen);
         rows_est = std::max(rows_est, (double)m.maxlen * std::max(2.0, 1.0 + 0.0165 * m.nseq));
@@ -631,7 +633,7 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     if (V.RM == 3) pool_slots = 1;   // (the banded sweep has no row ring: predecessors come from the plane)
     P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false,
                         V.RM == 3 ? (any_adaptive ? BAND_WIN : band_plane_strips(maxlen, V.W)) : (V.RM == 2 ? (P.wide_band ? 2 * V.T() : plane_strips_p16(V.T(), V.W)) : 0),
-                        V.RM == 2 ? V.CB : 4);
+                        V.RM == 2 ? V.CB : 4, any_spoa);
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
@@ -937,7 +939,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
                 Variant& v = pl.variant;
                 while (v.RM == 2 && v.NW <= 2 && v.W % 2 == 0 && v.W / 2 >= 4 && 2 * waves <= (uint64_t)h->num_cu * 16u) {
                     waves += (uint64_t)pl.work.size() * (uint64_t)v.NW;
-                    v = Variant{v.W / 2, 2 * v.NW, 256, 2, v.CB};
+                    v = Variant{v.W / 2, 2 * v.NW, 2 * v.NW <= 2 ? 128 : 256, 2, v.CB};
                 }
             }
         }
