@@ -232,7 +232,9 @@ static bool p16_safe(const Scoring& S, int maxlen, int rows, bool clamp_ok = fal
     // local alignment: every existing cell has 0 <= H <= m * L and F, O, E, Q >= -|q|; the range is one-sided
     if (S.sw) return (long)std::abs(S.m) * maxlen < 30000;
     if ((long)std::abs(S.m) * maxlen >= 15800) return false;
-    if (clamp_ok && !getenv("SXG_POA_NO_NW_CLAMP")) return (long)std::abs(S.m) * maxlen + std::abs(S.m) < 10000;   // (leaves the walk 6 000 below zero)
+    // (the walk may dip to -16 000 + m L + m before it is called clamped: 1 500 below zero at the limit -- a global alignment of
+    //  related sequences stays far above; one that does not is re-run on the 32-bit sweep while that sweep reaches it, 12 287 letters)
+    if (clamp_ok && !getenv("SXG_POA_NO_NW_CLAMP")) return (long)std::abs(S.m) * maxlen + std::abs(S.m) < 14500;
     return score_floor(S, maxlen, rows) < 15800;
 }
 // narrowest mode >= `at_least` (2 = packed < 0 = int16 row words < 1 = int32 row words)

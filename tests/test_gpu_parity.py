@@ -501,3 +501,14 @@ def test_per_block_device_time_is_reported(engine):
     assert abs(cyc[0] - cyc[3]) < 0.5 * cyc[0]
     ms = [c / (st["dom_clock_mhz"] * 1e3) for c in cyc]
     assert 0 < max(ms) <= st["kernel_ms"] * 1.05
+
+
+def test_global_alignment_beyond_the_32_bit_sweeps_reach_runs_packed(engine, oracle):
+    """13 kbp, global, affine 1,4,6,2: longer than the 32-bit sweeps reach (12 287 letters) and with an all-gap corner near
+    -52 000 -- rounds 1-4 answered TOO_LONG.  The clamped packed sweep aligns it (m L < 14 500) and equals the oracle."""
+    rng = np.random.default_rng(131)
+    seqs = random_block(rng, 3, 13000, div=0.02)
+    g, sc, cells = oracle.block_run(seqs, None, oparams("affine_4param", 1))
+    res = engine.run_blocks([seqs], gparams("affine_4param", 1))
+    assert engine.stats()["dom_row_mode"] == 2
+    assert_block_equal(res[0], g, sc, cells, label="global-13k")
