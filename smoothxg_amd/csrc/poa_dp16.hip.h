@@ -1000,6 +1000,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     // sweep (free during the walk).
     uint32_t* trans = (uint32_t*)(smem + LDS_CTL_BYTES + dp16_meta_bytes(T));   // [TBW_ROWS][TBW_COLS]
     uint32_t* chain = trans + TBW_ROWS * TBW_COLS;                               // [TBW_ROWS] cells of the current run
+    int* whint = (int*)(chain + TBW_ROWS);                                        // [TBW_ROWS] backbone hint of every window row (the last 256 of the area's 2 560 bytes)
     const int kmax_e = CVX ? 1 + (g - q) / (c - e) : 0x7fffffff;  // longest gap the first piece can win (poa_vtb.c)
 #define TBU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
     // H of the virtual row 0
@@ -1136,6 +1137,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
             }
             en[EO_PB] = (uint32_t)d0.x; en[EO_INFO] = (uint32_t)d0.y; en[EO_Q0] = (uint32_t)d0.z; en[EO_Q1] = (uint32_t)d1.x;
             en[EO_NODE] = (uint32_t)R_.node | (valid << 24);
+            whint[lane] = d1.w;
         }
         wlet[lane] = R_.let0;
         wlet[64 + lane] = R_.let1;
@@ -1264,7 +1266,13 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                     win_commit(cur);
                 }
                 // ... and ask for the next one right away: its loads travel while the walk crosses this window
+                // Where will the walk enter it?  Every row's descriptor carries the DP column its node is expected to align at (the
+                // backbone hint that centres the plane's band): the walk runs at a nearly constant offset from those -- it changes
+                // with this sequence's own indels only --, and the next window's top row is a row of this window.  (The adaptive
+                // band keeps another quantity in that word: there the running slope predicts.)
                 pf_top = wtop - (WR - 6); pf_slope = wslope; pf_j = max(wj - (((WR - 6) * wslope) >> 8), 0);
+                if (!ada && pf_top >= 1 && wtop - i >= 0 && wtop - i < WR)
+                    pf_j = min(max((int)TBU(whint[WR - 6]) + (j - (int)TBU(whint[wtop - i])), 0), L);
 #ifdef SXG_TB_NO_PREFETCH
                 pf_top = -1;   // (A/B builds: every window is fetched when the walk needs it, as in rounds 2-4)
 #endif
@@ -1272,7 +1280,9 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                 //  its path through rank space too irregular for a straight line eight columns wide -- which pays on one- and
                 //  two-wave workgroups, where nothing else hides the round trips (16 x 1 kbp: 43.2 -> 42.1 ms), and costs 1.6 % on the
                 //  four-wave headline class, whose other waves do: those keep fetching on demand.)
+#ifndef SXG_TB_PREFETCH_ALL
                 if (T > 128) pf_top = -1;
+#endif
                 if (pf_top >= 1) win_issue(pf_top, pf_j, pf_slope, pf); else pf_top = -1;
 #ifdef SXG_ROW_PROF
                 tb_ld += __builtin_readcyclecounter() - tl0;

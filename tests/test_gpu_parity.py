@@ -125,7 +125,7 @@ def test_too_long_is_reported_not_crashed(engine):
 
 def test_local_alignments_beyond_12_kbp_run_the_16_wave_packed_classes(engine, oracle):
     """smoothxg with -l 13k cuts ranges at 26 kbp (src/main.cpp:376): local alignments of 12-26 kbp run 1024-thread packed
-    classes (8, 10, 12, 13 columns per strip); a global alignment of such a length has no sweep and is reported."""
+    classes (8, 10, 12, 13 columns per strip); a global alignment beyond 14.5 kbp has no sweep and is reported."""
     rng = np.random.default_rng(1213)
     blocks = [random_block(rng, 3, L, div=0.02) for L in (14000, 18500, 23000, 26300)]
     res = engine.run_blocks(blocks, gparams("convex_default", 0))
@@ -134,7 +134,11 @@ def test_local_alignments_beyond_12_kbp_run_the_16_wave_packed_classes(engine, o
         g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
         assert_block_equal(res[b], g, sc, cells, label=f"long-local{len(seqs[0])}")
     assert st["dom_row_mode"] == 2
-    far = engine.run_blocks([blocks[0]], gparams("convex_default", 1), check=False)
+    # global: 14 kbp still fits the clamped packed sweep (m L < 14 500, round 5), 18.5 kbp has no sweep and is reported
+    g, sc, cells = oracle.block_run(blocks[0], None, oparams("convex_default", 1))
+    near = engine.run_blocks([blocks[0]], gparams("convex_default", 1))
+    assert_block_equal(near[0], g, sc, cells, label="long-global14000")
+    far = engine.run_blocks([blocks[1]], gparams("convex_default", 1), check=False)
     assert far[0].status == 5
 
 
