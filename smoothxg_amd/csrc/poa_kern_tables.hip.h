@@ -12,8 +12,9 @@
 //   part 4   packed sweep, block kernels, 4-byte plane cells (score sets whose deltas do not fit 16 bits), up to 4 waves
 //   part 5   ... 8 and 16 waves
 //   part 6   packed sweep, align-only kernels (4-byte cells)
-//   part 7   packed sweep, block kernels, 2-byte cells, one- and two-wave workgroups (TMAX = 128: the classes that may read
-//            stored rows back from a full-width plane and batch their graph phases 16 / 8 elements per thread)
+//   part 7   packed sweep, block kernels, 2-byte cells, two-wave workgroups (TMAX = 128: with part 8 the classes that may read
+//            stored rows back from a full-width plane and batch their graph phases 8 / 16 elements per thread)
+//   part 8   ... one-wave workgroups (TMAX = 64: no wave-to-wave hand-over compiled in)
 #pragma once
 #include "poa_kernels.hip.h"
 
@@ -36,6 +37,7 @@ KernelFn<BlockArgs> sxg_block_kernel_part4(const Variant& v, bool cvx, bool sw);
 KernelFn<BlockArgs> sxg_block_kernel_part5(const Variant& v, bool cvx, bool sw);
 KernelFn<AlignArgs> sxg_align_kernel_part6(const Variant& v, bool cvx, bool sw);
 KernelFn<BlockArgs> sxg_block_kernel_part7(const Variant& v, bool cvx, bool sw);
+KernelFn<BlockArgs> sxg_block_kernel_part8(const Variant& v, bool cvx, bool sw);
 
 #if defined(SXG_KERN_PART) || defined(SXG_DEV_ONLY_W)
 template <int TMAX, int W, int RM, int CB = 4> static KernelFn<BlockArgs> pick_block(bool cvx, bool sw) {
@@ -78,6 +80,7 @@ KernelFn<BlockArgs> sxg_block_kernel_part4(const Variant&, bool, bool) { return 
 KernelFn<BlockArgs> sxg_block_kernel_part5(const Variant&, bool, bool) { return nullptr; }
 KernelFn<AlignArgs> sxg_align_kernel_part6(const Variant&, bool, bool) { return nullptr; }
 KernelFn<BlockArgs> sxg_block_kernel_part7(const Variant& v, bool cvx, bool sw) { return sxg_block_kernel_part2(v, cvx, sw); }
+KernelFn<BlockArgs> sxg_block_kernel_part8(const Variant& v, bool cvx, bool sw) { return sxg_block_kernel_part2(v, cvx, sw); }
 #elif defined(SXG_KERN_PART)
 #if SXG_KERN_PART == 1
 KernelFn<BlockArgs> sxg_block_kernel_part1(const Variant& v, bool cvx, bool sw) {
@@ -131,6 +134,13 @@ KernelFn<BlockArgs> sxg_block_kernel_part7(const Variant& v, bool cvx, bool sw) 
     SXG_PICK16B(128, 11, 2); SXG_PICK16B(128, 12, 2);
     return nullptr;
 }
+#elif SXG_KERN_PART == 8
+KernelFn<BlockArgs> sxg_block_kernel_part8(const Variant& v, bool cvx, bool sw) {
+    SXG_PICK16B(64, 4, 2); SXG_PICK16B(64, 5, 2); SXG_PICK16B(64, 6, 2); SXG_PICK16B(64, 7, 2);
+    SXG_PICK16B(64, 8, 2); SXG_PICK16B(64, 9, 2); SXG_PICK16B(64, 10, 2);
+    SXG_PICK16B(64, 11, 2); SXG_PICK16B(64, 12, 2);
+    return nullptr;
+}
 #elif SXG_KERN_PART == 6
 KernelFn<AlignArgs> sxg_align_kernel_part6(const Variant& v, bool cvx, bool sw) {
     SXG_PICK16A(256, 4); SXG_PICK16A(256, 5); SXG_PICK16A(256, 6); SXG_PICK16A(256, 7);
@@ -148,7 +158,7 @@ KernelFn<AlignArgs> sxg_align_kernel_part6(const Variant& v, bool cvx, bool sw) 
 // the kernel class of a geometry (nullptr: none built)
 static inline KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
     if (v.RM != 2) return sxg_block_kernel_part1(v, cvx, sw);
-    if (v.CB == 2) return v.TMAX <= 128 ? sxg_block_kernel_part7(v, cvx, sw) : (v.TMAX <= 256 ? sxg_block_kernel_part2(v, cvx, sw) : sxg_block_kernel_part3(v, cvx, sw));
+    if (v.CB == 2) return v.TMAX <= 64 ? sxg_block_kernel_part8(v, cvx, sw) : v.TMAX <= 128 ? sxg_block_kernel_part7(v, cvx, sw) : (v.TMAX <= 256 ? sxg_block_kernel_part2(v, cvx, sw) : sxg_block_kernel_part3(v, cvx, sw));
     Variant u = v;
     if (u.TMAX < 256) u.TMAX = 256;   // (4-byte cells: no class of its own for one and two waves)
     return u.TMAX <= 256 ? sxg_block_kernel_part4(u, cvx, sw) : sxg_block_kernel_part5(u, cvx, sw);

@@ -228,8 +228,8 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                 const int band_mode = RM == 3 ? (int)A.params[A.per_block_params ? b : 0].banded : 0;   // 1 = B2, 2 = adaptive (B4)
                 // (workgroups of one and two waves take more elements per thread and step: see WgCtxT)
                 const int hinted_ = RM == 3 ? (band_mode == 2 ? 3 : 2) : (RM == 2 ? 1 : 0);
-                if (TMAX <= 128 && T <= 64) { WgCtxT<16> c16{ctx.lds}; status = prep_rows(c16, V.G, V.R, caps, hinted_); }
-                else if (TMAX <= 128 && T <= 128) { WgCtxT<8> c8{ctx.lds}; status = prep_rows(c8, V.G, V.R, caps, hinted_); }
+                if (TMAX == 64 || (TMAX <= 128 && T <= 64)) { WgCtxT<16> c16{ctx.lds}; status = prep_rows(c16, V.G, V.R, caps, hinted_); }
+                else if (TMAX == 128) { WgCtxT<8> c8{ctx.lds}; status = prep_rows(c8, V.G, V.R, caps, hinted_); }
                 else status = prep_rows(ctx, V.G, V.R, caps, hinted_);
                 if (status != ST_OK) break;
                 PROF(1);
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     for (int att = 0;; ++att) {
 #ifdef SXG_EXP
                         // (development: a sweep with parts switched off in front of the real one -- see dp_fill_p16's EXP)
-                        if (att == 0) { res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, SXG_EXP>(S, V.R, N, seq, len, V.B, smem); __syncthreads(); if (res.best == 0x7fffffff) break; }
+                        if (att == 0) { res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, RM == 2 && TMAX == 64, SXG_EXP>(S, V.R, N, seq, len, V.B, smem); __syncthreads(); if (res.best == 0x7fffffff) break; }
 #endif
-                        res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128>(S, V.R, N, seq, len, V.B, smem);
+                        res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, RM == 2 && TMAX == 64>(S, V.R, N, seq, len, V.B, smem);
                         __syncthreads();
                         PROF(2);
                         if (t == 0) { lds[TBM_FLAG] = 0; lds[TBM_RANGE] = 0; }
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             }
             if (t == 0) { A.score[s] = score; if (RM != 3 || N == 0 || len == 0) A.cells[s] = RM == 3 ? 0ull : (unsigned long long)N * (unsigned long long)len; }
             done_cells += (unsigned long long)N * (unsigned long long)len;
-            if (TMAX <= 128 && T <= 64) { WgCtxT<16> c16{ctx.lds}; add_alignment(c16, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
-            else if (TMAX <= 128 && T <= 128) { WgCtxT<8> c8{ctx.lds}; add_alignment(c8, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
+            if (TMAX == 64 || (TMAX <= 128 && T <= 64)) { WgCtxT<16> c16{ctx.lds}; add_alignment(c16, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
+            else if (TMAX == 128) { WgCtxT<8> c8{ctx.lds}; add_alignment(c8, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
             else add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
             if (A.params[A.per_block_params ? b : 0].mode & SXG_ORDER_SPOA) {   // S7': spoa's depth-first re-sort (one lane)
                 if (t == 0) spoa_resort(V.G);
