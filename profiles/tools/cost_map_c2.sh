@@ -7,7 +7,7 @@ if [ "$1" = build ]; then
   for w in 10 5; do
   for m in $MASKS; do
     X=""; [ $m != none ] && X="-DSXG_EXP=$m"
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSXG_DEV_ONLY_W=$w -DSXG_DEV_ONLY_TMAX=128 $X \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSXG_DEV_ONLY_W=$w -DSXG_DEV_ONLY_TMAX=$([ $w = 10 ] && echo 64 || echo 128) $X \
       -o smoothxg_amd/csrc/libsxgpoa_exp${w}_$m.so smoothxg_amd/csrc/sxg_poa.hip -ldl &
   done; wait; done; ls smoothxg_amd/csrc/libsxgpoa_exp*.so | wc -l
 else

@@ -7,7 +7,7 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libsxgpoa.so")
 # sxg_poa.hip: host side of the C ABI; kern_part*.hip: the kernel classes in parts (poa_kern_tables.hip.h), one translation
 # unit each so that they compile side by side
-SOURCES = ["sxg_poa.hip"] + ["kern_part%d.hip" % k for k in range(1, 9)]
+SOURCES = ["sxg_poa.hip"] + ["kern_part%d.hip" % k for k in range(1, 10)]
 DEPS = SOURCES + ["poa_kernels.hip.h", "poa_kern_tables.hip.h", "poa_dp.hip.h", "poa_dp16.hip.h", "poa_band16.hip.h", "poa_graph_dev.h",
                   "poa_bgraph_dev.h", "poa_types.h", os.path.join("..", "..", "include", "sxg_poa.h")]
 OBJ_DIR = os.path.join(CSRC, "build")

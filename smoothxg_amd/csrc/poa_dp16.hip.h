@@ -249,19 +249,21 @@ __device__ __forceinline__ int band_first_strip(const int hint_col, const int W,
 // RP: the class may run with a plane that keeps every strip and read stored rows back from it (ring_plane below) -- the
 // one- and two-wave classes (TMAX = 128); the wider classes are compiled without that path (its three fetch sites and their
 // scalars cost the four-wave headline class SGPR spills in the row loop).
-template <int W, bool CVX, bool SW, int CB = 4, bool RP = false, bool ONEW = false, int EXP = 0>
+template <int W, bool CVX, bool SW, int CB = 4, bool RP = false, int TFIX = 0, int EXP = 0>
 __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R, const int N_,
                                              const uint8_t* seq, const int L_, const DpBuffers B,
                                              char* smem) {
     DpResult res;
     const int N = __builtin_amdgcn_readfirstlane(N_), L = __builtin_amdgcn_readfirstlane(L_);
     static_assert(W >= 4 && W <= 15, "strip width");
-    const int T = (int)blockDim.x;
-    const int NW = ONEW ? 1 : T >> 6;
+    // (TFIX: the class runs at exactly this many threads -- everything derived from T folds into immediates: 1.2 % on the headline)
+    const int T = TFIX ? TFIX : (int)blockDim.x;
+    constexpr bool ONEW = TFIX == 64;
+    const int NW = T >> 6;
     const int TW = T * W;           // columns of one half
     const int MB = dp16_meta_bytes(T);   // (bytes of the LDS area the traceback window uses; the sweep keeps its mailboxes there)
     int* lds = (int*)smem;
-    // (ONEW: a one-wave class -- no left or right neighbour, the mailbox code folds away: 1.7 % on 8000 x 16 x 1 kbp)
+    // (TFIX = 64: a one-wave class -- no left or right neighbour, the mailbox code folds away: 1.7 % on 8000 x 16 x 1 kbp)
     const int t = threadIdx.x, lane = t & 63, wv = ONEW ? 0 : __builtin_amdgcn_readfirstlane(t >> 6);
     // Wave w owns the 128 strips [128 w, 128 w + 128): lane l its strips 128 w + l (low halves) and 128 w + 64 + l (high
     // halves).  A wave's columns are contiguous, so the ONLY thing that crosses a wave boundary inside a row is what crosses

@@ -15,6 +15,10 @@
 //   part 7   packed sweep, block kernels, 2-byte cells, two-wave workgroups (TMAX = 128: with part 8 the classes that may read
 //            stored rows back from a full-width plane and batch their graph phases 8 / 16 elements per thread)
 //   part 8   ... one-wave workgroups (TMAX = 64: no wave-to-wave hand-over compiled in)
+//   part 9   packed sweep, block kernels, 2-byte cells, three-wave workgroups (TMAX = 192)
+// The 2-byte classes of up to eight waves run at EXACTLY TMAX threads, and the sweep is compiled for that thread count (1.6 % on the
+// headline; the two-wave class measured 1 % slower that way and keeps reading it at run time); the 4-byte classes and the 16-wave
+// ones take their thread count at run time.
 #pragma once
 #include "poa_kernels.hip.h"
 
@@ -38,6 +42,7 @@ KernelFn<BlockArgs> sxg_block_kernel_part5(const Variant& v, bool cvx, bool sw);
 KernelFn<AlignArgs> sxg_align_kernel_part6(const Variant& v, bool cvx, bool sw);
 KernelFn<BlockArgs> sxg_block_kernel_part7(const Variant& v, bool cvx, bool sw);
 KernelFn<BlockArgs> sxg_block_kernel_part8(const Variant& v, bool cvx, bool sw);
+KernelFn<BlockArgs> sxg_block_kernel_part9(const Variant& v, bool cvx, bool sw);
 
 #if defined(SXG_KERN_PART) || defined(SXG_DEV_ONLY_W)
 template <int TMAX, int W, int RM, int CB = 4> static KernelFn<BlockArgs> pick_block(bool cvx, bool sw) {
@@ -81,6 +86,7 @@ KernelFn<BlockArgs> sxg_block_kernel_part5(const Variant&, bool, bool) { return 
 KernelFn<AlignArgs> sxg_align_kernel_part6(const Variant&, bool, bool) { return nullptr; }
 KernelFn<BlockArgs> sxg_block_kernel_part7(const Variant& v, bool cvx, bool sw) { return sxg_block_kernel_part2(v, cvx, sw); }
 KernelFn<BlockArgs> sxg_block_kernel_part8(const Variant& v, bool cvx, bool sw) { return sxg_block_kernel_part2(v, cvx, sw); }
+KernelFn<BlockArgs> sxg_block_kernel_part9(const Variant& v, bool cvx, bool sw) { return sxg_block_kernel_part2(v, cvx, sw); }
 #elif defined(SXG_KERN_PART)
 #if SXG_KERN_PART == 1
 KernelFn<BlockArgs> sxg_block_kernel_part1(const Variant& v, bool cvx, bool sw) {
@@ -141,6 +147,13 @@ KernelFn<BlockArgs> sxg_block_kernel_part8(const Variant& v, bool cvx, bool sw) 
     SXG_PICK16B(64, 11, 2); SXG_PICK16B(64, 12, 2);
     return nullptr;
 }
+#elif SXG_KERN_PART == 9
+KernelFn<BlockArgs> sxg_block_kernel_part9(const Variant& v, bool cvx, bool sw) {
+    SXG_PICK16B(192, 4, 2); SXG_PICK16B(192, 5, 2); SXG_PICK16B(192, 6, 2); SXG_PICK16B(192, 7, 2);
+    SXG_PICK16B(192, 8, 2); SXG_PICK16B(192, 9, 2); SXG_PICK16B(192, 10, 2);
+    SXG_PICK16B(192, 11, 2); SXG_PICK16B(192, 12, 2);
+    return nullptr;
+}
 #elif SXG_KERN_PART == 6
 KernelFn<AlignArgs> sxg_align_kernel_part6(const Variant& v, bool cvx, bool sw) {
     SXG_PICK16A(256, 4); SXG_PICK16A(256, 5); SXG_PICK16A(256, 6); SXG_PICK16A(256, 7);
@@ -158,7 +171,7 @@ KernelFn<AlignArgs> sxg_align_kernel_part6(const Variant& v, bool cvx, bool sw) 
 // the kernel class of a geometry (nullptr: none built)
 static inline KernelFn<BlockArgs> block_kernel(const Variant& v, bool cvx, bool sw) {
     if (v.RM != 2) return sxg_block_kernel_part1(v, cvx, sw);
-    if (v.CB == 2) return v.TMAX <= 64 ? sxg_block_kernel_part8(v, cvx, sw) : v.TMAX <= 128 ? sxg_block_kernel_part7(v, cvx, sw) : (v.TMAX <= 256 ? sxg_block_kernel_part2(v, cvx, sw) : sxg_block_kernel_part3(v, cvx, sw));
+    if (v.CB == 2) return v.TMAX <= 64 ? sxg_block_kernel_part8(v, cvx, sw) : v.TMAX <= 128 ? sxg_block_kernel_part7(v, cvx, sw) : v.TMAX <= 192 ? sxg_block_kernel_part9(v, cvx, sw) : (v.TMAX <= 256 ? sxg_block_kernel_part2(v, cvx, sw) : sxg_block_kernel_part3(v, cvx, sw));
     Variant u = v;
     if (u.TMAX < 256) u.TMAX = 256;   // (4-byte cells: no class of its own for one and two waves)
     return u.TMAX <= 256 ? sxg_block_kernel_part4(u, cvx, sw) : sxg_block_kernel_part5(u, cvx, sw);

@@ -157,8 +157,8 @@ static bool variant_for_len(int maxlen, int rm, Variant* v, bool sw = false) {
     if (rm == 2) {   // development knob: SXG_POA_FORCE_P16="W,NW" forces one packed geometry (A/B runs of a single-class build)
         if (const char* e = getenv("SXG_POA_FORCE_P16")) {
             int fw = 0, fnw = 0;
-            if (sscanf(e, "%d,%d", &fw, &fnw) == 2 && 128L * fnw * fw >= maxlen + 1) {
-                *v = Variant{fw, fnw, fnw <= 1 ? 64 : (fnw <= 2 ? 128 : (fnw <= 4 ? 256 : (fnw <= 8 ? 512 : 1024))), rm};
+            if (sscanf(e, "%d,%d", &fw, &fnw) == 2 && 128L * fnw * fw >= maxlen + 1 && (fnw <= 4 || fnw == 8 || fnw == 12 || fnw == 16)) {
+                *v = Variant{fw, fnw, fnw <= 4 ? 64 * fnw : (fnw <= 8 ? 512 : 1024), rm};
                 return true;
             }
         }
@@ -181,7 +181,7 @@ static bool variant_for_len(int maxlen, int rm, Variant* v, bool sw = false) {
             if (wide && NW > 8 && !long_class) continue;
             if (best_cols < 0 || cols < best_cols) {
                 best_cols = cols;
-                *v = Variant{W, NW, (rm == 2 && NW <= 2) ? 64 * NW : (NW <= 4 ? 256 : (NW <= 8 ? 512 : 1024)), rm};   // (packed: one and two waves have classes of their own)
+                *v = Variant{W, NW, (rm == 2 && NW <= 4) ? 64 * NW : (NW <= 4 ? 256 : (NW <= 8 ? 512 : 1024)), rm};   // (packed: one and two waves have classes of their own)
             }
             break;  // larger NW for this W only adds padding
         }
@@ -941,7 +941,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
                 Variant& v = pl.variant;
                 while (v.RM == 2 && v.NW <= 2 && v.W % 2 == 0 && v.W / 2 >= 4 && 2 * waves <= (uint64_t)h->num_cu * 16u) {
                     waves += (uint64_t)pl.work.size() * (uint64_t)v.NW;
-                    v = Variant{v.W / 2, 2 * v.NW, 2 * v.NW <= 2 ? 128 : 256, 2, v.CB};   // (NW 1 -> 2: the two-wave class; 2 -> 4: the four-wave class)
+                    v = Variant{v.W / 2, 2 * v.NW, 64 * 2 * v.NW, 2, v.CB};   // (NW 1 -> 2: the two-wave class; 2 -> 4: the four-wave class)
                 }
             }
         }
