@@ -521,6 +521,8 @@ def main():
     if rank == 0 and not a.no_verify:
         if strong and exchange == "cabi":
             verified_note = "strong scaling deals the blocks over the ranks: not checked here"
+        elif FIXTURE_CASE.get((a.workload, a.mode)) is None:
+            verified_note = "no committed full-shape fixture for this workload / mode"
         else:
             vres = eng.download()
             verified, verified_blocks, verified_note = verify_against_fixture(vres, a.workload, a.mode, 0, prm)
