@@ -48,6 +48,11 @@ constexpr int NEGP = -16384;  // "minus infinity" of the packed sweep
 // reports ST_RANGE_OVERFLOW and the block is re-run on the 32-bit sweep, as before.  (Rounds 1-4 sent every global
 // alignment whose corner did not fit down that ladder up front: 130 blocks/s instead of the packed sweep's rate.)
 constexpr int P16_NWFLOOR = -16000;
+// smoothxg's default scores in the engine's (spoa's) sign convention: the score set the DS kernel classes are compiled for
+constexpr int P16_DEF_M = 1, P16_DEF_N = -4, P16_DEF_G = -6, P16_DEF_E = -2, P16_DEF_Q = -26, P16_DEF_C = -1;
+__host__ __device__ inline bool p16_default_scores(const Scoring& S) {
+    return S.convex && S.m == P16_DEF_M && S.n == P16_DEF_N && S.g == P16_DEF_G && S.e == P16_DEF_E && S.q == P16_DEF_Q && S.c == P16_DEF_C;
+}
 // LOCAL alignments run the packed sweep on BIASED fields: a register half holds score + P16_BIAS, always inside
 // [P16_FLOOR, 32767].  Every reachable value of a local alignment is >= min(g, q) >= -120 (H >= 0, every gap state is
 // some H plus at most one opening) and the few "minus infinity" inputs (the column left of column 0, a carry that enters
@@ -249,7 +254,7 @@ __device__ __forceinline__ int band_first_strip(const int hint_col, const int W,
 // RP: the class may run with a plane that keeps every strip and read stored rows back from it (ring_plane below) -- the
 // one- and two-wave classes (TMAX = 128); the wider classes are compiled without that path (its three fetch sites and their
 // scalars cost the four-wave headline class SGPR spills in the row loop).
-template <int W, bool CVX, bool SW, int CB = 4, bool RP = false, int TFIX = 0, int EXP = 0>
+template <int W, bool CVX, bool SW, int CB = 4, bool RP = false, int TFIX = 0, bool DS = false, int EXP = 0>
 __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R, const int N_,
                                              const uint8_t* seq, const int L_, const DpBuffers B,
                                              char* smem) {
@@ -271,10 +276,13 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     const int s_lo = wv * 128 + lane, s_hi = s_lo + 64;
     const int j0 = s_lo * W, j0h = s_hi * W;   // first columns of my two strips
     // scoring values are block-uniform: keep them (and everything derived) in SGPRs
-    const int g = __builtin_amdgcn_readfirstlane(S.g), e = __builtin_amdgcn_readfirstlane(S.e);
-    const int q = __builtin_amdgcn_readfirstlane(S.q), c = __builtin_amdgcn_readfirstlane(S.c);
+    // DS: the class is compiled FOR smoothxg's default scores 1,4,6,2,26,1 (src/main.cpp:322-327) -- the six values and everything
+    // derived from them are immediates instead of ~16 loop-invariant scalar registers, which the row loop otherwise spills to
+    // VGPR lanes and reads back per use (headline, same box: 1 910 -> 1 848 ms).  Other score sets take the generic class.
+    const int g = DS ? P16_DEF_G : __builtin_amdgcn_readfirstlane(S.g), e = DS ? P16_DEF_E : __builtin_amdgcn_readfirstlane(S.e);
+    const int q = DS ? P16_DEF_Q : __builtin_amdgcn_readfirstlane(S.q), c = DS ? P16_DEF_C : __builtin_amdgcn_readfirstlane(S.c);
+    const int sm = DS ? P16_DEF_M : __builtin_amdgcn_readfirstlane(S.m), sn = DS ? P16_DEF_N : __builtin_amdgcn_readfirstlane(S.n);
     const int G2 = pk2(g, g), E2 = pk2(e, e), Q2 = pk2(q, q), C2 = pk2(c, c);
-    const int sm = __builtin_amdgcn_readfirstlane(S.m), sn = __builtin_amdgcn_readfirstlane(S.n);
     // local alignment: biased fields (see P16_BIAS); "x + K" for a penalty K <= 0 is then x - |K| * 0x10001 in 32 bits
     constexpr int BIAS = SW ? P16_BIAS : 0, FLOORV = SW ? P16_FLOOR : NEGP;
     const int NEG2 = pk2(FLOORV, FLOORV), B2 = pk2(BIAS, BIAS), NWF2 = pk2(P16_NWFLOOR, P16_NWFLOOR);
@@ -287,7 +295,9 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     const int BS = __builtin_amdgcn_readfirstlane(B.band_strips);
     constexpr int SD = p16_slot_dwords(W, CB);   // dwords of one strip in a plane row
     // (CB = 2) the multipliers that shift a cell's two distances into their fields of the code
-    const P16Delta DF = p16_delta_of(S);
+    Scoring SD_ = S;
+    if (DS) { SD_.m = P16_DEF_M; SD_.n = P16_DEF_N; SD_.g = P16_DEF_G; SD_.e = P16_DEF_E; SD_.q = P16_DEF_Q; SD_.c = P16_DEF_C; SD_.convex = 1; }
+    const P16Delta DF = p16_delta_of(SD_);
     const int KF2 = pk2(1 << __builtin_amdgcn_readfirstlane(DF.bH), 1 << __builtin_amdgcn_readfirstlane(DF.bH));
     const int KO2 = pk2(1 << __builtin_amdgcn_readfirstlane(DF.bH + DF.bF), 1 << __builtin_amdgcn_readfirstlane(DF.bH + DF.bF));
     // ... and what reading a row back out of the plane needs (full-width planes only, see ring_plane below)

@@ -27,6 +27,7 @@
 struct Variant {
     int W, NW, TMAX, RM;
     int CB = 4;
+    bool DS = false;   // the class compiled for smoothxg's default scores (packed sweep, 2-byte cells, convex)
     int T() const { return 64 * NW; }
     int Lpad() const { return 64 * NW * W * (RM >= 2 ? 2 : 1); }
 };
@@ -45,9 +46,18 @@ KernelFn<BlockArgs> sxg_block_kernel_part8(const Variant& v, bool cvx, bool sw);
 KernelFn<BlockArgs> sxg_block_kernel_part9(const Variant& v, bool cvx, bool sw);
 
 #if defined(SXG_KERN_PART) || defined(SXG_DEV_ONLY_W)
-template <int TMAX, int W, int RM, int CB = 4> static KernelFn<BlockArgs> pick_block(bool cvx, bool sw) {
+template <int TMAX, int W, int RM, int CB = 4> static KernelFn<BlockArgs> pick_block(bool cvx, bool sw, bool ds = false) {
+    if constexpr (RM == 2 && CB == 2) {
+        if (cvx && ds) return sw ? poa_block_kernel<TMAX, W, true, RM, true, CB, true> : poa_block_kernel<TMAX, W, true, RM, false, CB, true>;
+    }
     if (cvx) return sw ? poa_block_kernel<TMAX, W, true, RM, true, CB> : poa_block_kernel<TMAX, W, true, RM, false, CB>;
     return sw ? poa_block_kernel<TMAX, W, false, RM, true, CB> : poa_block_kernel<TMAX, W, false, RM, false, CB>;
+}
+template <int TMAX, int W, int CB> static KernelFn<BlockArgs> pick_block_sw(bool cvx, bool ds) {   // (packed, local alignment only)
+    if constexpr (CB == 2) {
+        if (cvx && ds) return poa_block_kernel<TMAX, W, true, 2, true, CB, true>;
+    }
+    return cvx ? poa_block_kernel<TMAX, W, true, 2, true, CB> : poa_block_kernel<TMAX, W, false, 2, true, CB>;
 }
 template <int TMAX, int W, int RM> static KernelFn<AlignArgs> pick_align(bool cvx, bool sw) {
     if (cvx) return sw ? poa_align_kernel<TMAX, W, true, RM, true> : poa_align_kernel<TMAX, W, true, RM, false>;
@@ -61,10 +71,10 @@ template <int TMAX, int W, int RM> static KernelFn<AlignArgs> pick_align(bool cv
         }                                                                \
     } while (0)
 #define SXG_PICK16B(TM, Wd, CBv) \
-    do { if (v.TMAX == TM && v.W == Wd && v.RM == 2 && v.CB == CBv) return pick_block<TM, Wd, 2, CBv>(cvx, sw); } while (0)
+    do { if (v.TMAX == TM && v.W == Wd && v.RM == 2 && v.CB == CBv) return pick_block<TM, Wd, 2, CBv>(cvx, sw, v.DS); } while (0)
 // (the long classes exist for local alignment only: a global score of such lengths does not fit int16)
 #define SXG_PICK16B_SW(TM, Wd, CBv) \
-    do { if (v.TMAX == TM && v.W == Wd && v.RM == 2 && v.CB == CBv && sw) return cvx ? poa_block_kernel<TM, Wd, true, 2, true, CBv> : poa_block_kernel<TM, Wd, false, 2, true, CBv>; } while (0)
+    do { if (v.TMAX == TM && v.W == Wd && v.RM == 2 && v.CB == CBv && sw) return pick_block_sw<TM, Wd, CBv>(cvx, v.DS); } while (0)
 #define SXG_PICK16A(TM, Wd) \
     do { if (v.TMAX == TM && v.W == Wd && v.RM == 2) return pick_align<TM, Wd, 2>(cvx, sw); } while (0)
 #define SXG_PICK16A_SW(TM, Wd) \

@@ -513,6 +513,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
         m.rm = row_mode(m.S, m.maxlen, m.maxlen, 2, h->h_params[in->per_block_params ? b : 0].banded == 0);
         m.fits = variant_for_len(m.maxlen, m.rm, &m.variant, m.S.sw);
         m.variant.CB = m.rm == 2 ? plane_cell_bytes(m.S) : 4;
+        m.variant.DS = m.rm == 2 && m.variant.CB == 2 && p16_default_scores(m.S) && !getenv("SXG_POA_NO_DEFAULT_CLASS");
         // A11: the reference's abPOA path is banded (wb=311, wf=0.03); local alignments whose scores fit the packed
         // sweep run the one-wave banded kernel, everything else asked to be banded runs the full matrix
         // (global alignment: the adaptive band only -- the band of a row without successors holds the end column by
@@ -910,7 +911,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
             const BlockMeta& m = h->meta[b];
             LaunchPlan* pl = nullptr;
             for (auto& q : plans)
-                if (q.variant.W == m.variant.W && q.variant.NW == m.variant.NW && q.variant.RM == m.variant.RM && q.variant.CB == m.variant.CB && q.cvx == m.cvx && q.sw == m.sw && q.tier == m.tier && q.wide_band == m.wide_band) { pl = &q; break; }
+                if (q.variant.W == m.variant.W && q.variant.NW == m.variant.NW && q.variant.RM == m.variant.RM && q.variant.CB == m.variant.CB && q.variant.DS == m.variant.DS && q.cvx == m.cvx && q.sw == m.sw && q.tier == m.tier && q.wide_band == m.wide_band) { pl = &q; break; }
             if (!pl) { plans.emplace_back(); pl = &plans.back(); pl->variant = m.variant; pl->cvx = m.cvx; pl->sw = m.sw; pl->tier = m.tier; pl->wide_band = m.wide_band; }
             pl->work.push_back(b);
         }
@@ -926,7 +927,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
         for (size_t i = 0; i < plans.size(); ++i)
             for (size_t j = i + 1; j < plans.size();) {
                 const LaunchPlan &a = plans[i], &b = plans[j];
-                if (a.variant.RM == b.variant.RM && a.variant.CB == b.variant.CB && a.variant.RM != 3 && a.cvx == b.cvx && a.sw == b.sw && a.tier == b.tier && a.wide_band == b.wide_band &&
+                if (a.variant.RM == b.variant.RM && a.variant.CB == b.variant.CB && a.variant.DS == b.variant.DS && a.variant.RM != 3 && a.cvx == b.cvx && a.sw == b.sw && a.tier == b.tier && a.wide_band == b.wide_band &&
                     (double)b.variant.Lpad() >= (merge_env > 0 ? merge_env : (a.variant.Lpad() >= 4096 ? 0.92 : 0.75)) * (double)a.variant.Lpad()) {
                     plans[i].work.insert(plans[i].work.end(), b.work.begin(), b.work.end());
                     plans.erase(plans.begin() + (long)j);
@@ -941,7 +942,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
                 Variant& v = pl.variant;
                 while (v.RM == 2 && v.NW <= 2 && v.W % 2 == 0 && v.W / 2 >= 4 && 2 * waves <= (uint64_t)h->num_cu * 16u) {
                     waves += (uint64_t)pl.work.size() * (uint64_t)v.NW;
-                    v = Variant{v.W / 2, 2 * v.NW, 64 * 2 * v.NW, 2, v.CB};   // (NW 1 -> 2: the two-wave class; 2 -> 4: the four-wave class)
+                    v = Variant{v.W / 2, 2 * v.NW, 64 * 2 * v.NW, 2, v.CB, v.DS};   // (NW 1 -> 2: the two-wave class; 2 -> 4: the four-wave class)
                 }
             }
         }
@@ -1085,6 +1086,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
                     m.rm = row_mode(m.S, m.maxlen, m.maxlen, m.rm >= 2 ? 0 : 1);
                     m.fits = variant_for_len(m.maxlen, m.rm, &m.variant, m.S.sw);
                     m.variant.CB = m.rm == 2 ? plane_cell_bytes(m.S) : 4;
+        m.variant.DS = m.rm == 2 && m.variant.CB == 2 && p16_default_scores(m.S) && !getenv("SXG_POA_NO_DEFAULT_CLASS");
                     if (m.fits) again.push_back(b);
                     else status[b] = ST_TOO_LONG;    // (a score range beyond int16 on a sequence beyond SXG_POA_MAX_SEQ_LEN_WIDE)
                 } else status[b] = ST_TOO_LONG;      // (unreachable: the int32 sweep reports neither)

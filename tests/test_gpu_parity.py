@@ -516,3 +516,22 @@ def test_global_alignment_beyond_the_32_bit_sweeps_reach_runs_packed(engine, ora
     res = engine.run_blocks([seqs], gparams("affine_4param", 1))
     assert engine.stats()["dom_row_mode"] == 2
     assert_block_equal(res[0], g, sc, cells, label="global-13k")
+
+
+def test_default_score_classes_equal_the_generic_ones(engine, oracle, monkeypatch):
+    """Blocks with smoothxg's default scores run kernel classes compiled FOR those scores (immediates instead of scalar
+    registers); SXG_POA_NO_DEFAULT_CLASS sends the same blocks through the generic classes.  One-, two- and four-wave
+    geometries, local and global: both equal the oracle."""
+    rng = np.random.default_rng(606)
+    blocks = [random_block(rng, 5, L, div=0.03) for L in (700, 1200, 3000)]
+    for mode in (0, 1):
+        want = [oracle.block_run(b, None, oparams("convex_default", mode)) for b in blocks]
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("SXG_POA_NO_DEFAULT_CLASS", env)
+            else:
+                monkeypatch.delenv("SXG_POA_NO_DEFAULT_CLASS", raising=False)
+            res = engine.run_blocks(blocks, gparams("convex_default", mode))
+            for r, (g, sc, cells) in zip(res, want):
+                assert_block_equal(r, g, sc, cells, label=f"default-class env={env} mode={mode}")
+    monkeypatch.delenv("SXG_POA_NO_DEFAULT_CLASS", raising=False)
