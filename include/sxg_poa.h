@@ -82,7 +82,10 @@ extern "C" {
 
 /* Longest sequence.  Local alignment (smoothxg's default) with m * length < 30000 runs the packed int16 sweep, whose
  * largest workgroup covers 2 * 1024 * 13 columns: enough for -l 13k cut at -q 2 * 13k (src/main.cpp:376) plus padding.
- * Global alignment and score sets outside the int16 range need the 32-bit sweep: 1024 lanes * 12 columns. */
+ * Global alignment runs the packed sweep with m * length < 14500 whatever its gap scores (round 5: the sweep clamps far below
+ * any score a related pair reaches and its traceback checks itself; a block whose walk does meet a clamped cell is re-run on
+ * the 32-bit sweep).  Longer global alignments and score sets outside the int16 range (|g| or |q| > 120) need the 32-bit sweep:
+ * 1024 lanes * 12 columns. */
 #define SXG_POA_MAX_SEQ_LEN 26623
 #define SXG_POA_MAX_SEQ_LEN_WIDE 12287
 
