@@ -118,10 +118,11 @@ SXG_HD int group_end(const GraphView& G, int leader, int n_old) {
 // path_out[0..len) receives the node id of every base (replaces spoa's per-edge labels /
 // Node::Successor walk used at src/smooth.cpp:2604-2610).
 template <class Ctx>
-SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G, const uint8_t* seq_, int len,
+SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G_, const uint8_t* seq_, int len,
                           uint32_t weight, int32_t* path_out_) {
-    SXG_GP const uint8_t* const seq = (SXG_GP const uint8_t*)seq_;   // both live in HBM
-    SXG_GP int32_t* const path_out = (SXG_GP int32_t*)path_out_;
+    const GraphView G = sxg_scalar_view(G_);   // (pointers through the scalar unit once: see poa_types.h)
+    SXG_GP const uint8_t* const seq = sxg_scalar_ptr((SXG_GP const uint8_t*)seq_);   // both live in HBM
+    SXG_GP int32_t* const path_out = sxg_scalar_ptr((SXG_GP int32_t*)path_out_);
     const int T = c.nthreads(), t = c.tid();
     const int n_old = *G.n_nodes, e_old = *G.n_edges;
     const int BIG = 0x3fffffff;
@@ -362,6 +363,8 @@ struct RowCaps {
 // 3 = banded sweep with the ADAPTIVE band (decree B4) -- R.tbx holds remain() of every row; the bands follow from the
 // sweep itself, which leaves every finished row's band and best-cell columns in words 6 and 7 of its descriptor.
 template <class Ctx>
+// (finish_rows keeps reading its view through the reference: with the scalar copy the 32-bit kernels trip the AMDGPU back-end
+//  assertion on the shared-aperture null check that WgCtx's comment in poa_dp.hip.h describes)
 SXG_HD_PHASE int finish_rows(Ctx& c, int N, const RowsView& R, const RowCaps& caps, const int hinted = 0) {
     const int T = c.nthreads(), t = c.tid();
     c.sync();
@@ -511,7 +514,9 @@ SXG_HD_PHASE void rows_remain(Ctx& c, const GraphView& G, int N, SXG_GP int32_t*
 // Rank-space CSR + per-row DP metadata of the current graph.  Returns a status code
 // (identical on every thread).
 template <class Ctx>
-SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G, const RowsView& R, const RowCaps& caps, const int hinted = 0) {
+SXG_HD_PHASE int prep_rows(Ctx& c, const GraphView& G_, const RowsView& R_, const RowCaps& caps, const int hinted = 0) {
+    const GraphView G = sxg_scalar_view(G_);
+    const RowsView R = sxg_scalar_view(R_);
     const int T = c.nthreads(), t = c.tid();
     c.sync();
     const int N = *G.n_nodes;

@@ -165,6 +165,11 @@ __host__ __device__ constexpr int sxg_min_waves(int TMAX, int W, int RM) {
 }
 
 // CB: bytes per cell of the packed sweep's traceback plane (poa_dp16.hip.h: 2 = delta codes, 4 = H and the two distances)
+#ifdef SXG_DEV_TFIX128
+#define SXG_TFIX_OK(tm) true
+#else
+#define SXG_TFIX_OK(tm) ((tm) != 128)   /* (the two-wave class measured 1 % slower with a compile-time thread count) */
+#endif
 // DS: packed sweep compiled for smoothxg's default scores (see dp_fill_p16); the host launches it only for blocks that have them
 template <int TMAX, int W, bool CVX, int RM, bool SW, int CB = 4, bool DS = false>
 __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_kernel(const BlockArgs A) {
@@ -262,9 +267,9 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     for (int att = 0;; ++att) {
 #ifdef SXG_EXP
                         // (development: a sweep with parts switched off in front of the real one -- see dp_fill_p16's EXP)
-                        if (att == 0) { res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, (RM == 2 && CB == 2 && TMAX <= 512 && TMAX != 128) ? TMAX : 0, DS, SXG_EXP>(S, V.R, N, seq, len, V.B, smem); __syncthreads(); if (res.best == 0x7fffffff) break; }
+                        if (att == 0) { res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, (RM == 2 && CB == 2 && TMAX <= 512 && SXG_TFIX_OK(TMAX)) ? TMAX : 0, DS, SXG_EXP>(S, V.R, N, seq, len, V.B, smem); __syncthreads(); if (res.best == 0x7fffffff) break; }
 #endif
-                        res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, (RM == 2 && CB == 2 && TMAX <= 512 && TMAX != 128) ? TMAX : 0, DS>(S, V.R, N, seq, len, V.B, smem);
+                        res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, (RM == 2 && CB == 2 && TMAX <= 512 && SXG_TFIX_OK(TMAX)) ? TMAX : 0, DS>(S, V.R, N, seq, len, V.B, smem);
                         __syncthreads();
                         PROF(2);
                         if (t == 0) { lds[TBM_FLAG] = 0; lds[TBM_RANGE] = 0; }

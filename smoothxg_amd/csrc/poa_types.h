@@ -123,4 +123,37 @@ struct RowMeta {
     int tbx;       // as RowsView::tbx (fold step / band hint)
 };
 
+// The views reach the out-of-line graph phases by reference to the kernel's private memory: read through that reference, every
+// array base is a FLAT load from scratch in front of the access it serves (72 of them in prep_rows alone, round 5's ISA) and a
+// 64-bit VGPR address behind it.  A phase therefore starts by copying the view it was handed into one whose pointers went
+// through the scalar unit once (readfirstlane: they are the same for every thread of the workgroup): the accesses become
+// "scalar base + lane offset", the pointers live in SGPRs.  (Host builds -- the CPU emulation harness -- copy plainly.)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class Tp> __device__ __forceinline__ Tp sxg_scalar_ptr(Tp p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (Tp)(((unsigned long long)hi << 32) | lo);
+}
+#else
+template <class Tp> inline Tp sxg_scalar_ptr(Tp p) { return p; }
+#endif
+SXG_HD GraphView sxg_scalar_view(const GraphView& G) {
+    GraphView U;
+#define SXG_U(f) U.f = sxg_scalar_ptr(G.f)
+    SXG_U(n_nodes); SXG_U(n_edges); SXG_U(code); SXG_U(rank); SXG_U(order); SXG_U(order_tmp); SXG_U(leader); SXG_U(gmem);
+    SXG_U(in_head); SXG_U(in_tail); SXG_U(out_head); SXG_U(out_tail); SXG_U(in_deg); SXG_U(out_deg);
+    SXG_U(e_tail); SXG_U(e_head); SXG_U(e_next_in); SXG_U(e_next_out); SXG_U(e_w);
+    SXG_U(posnode); SXG_U(target); SXG_U(newidx); SXG_U(nexta); SXG_U(preva); SXG_U(slotadd); SXG_U(kind);
+    SXG_U(xpos); SXG_U(via); SXG_U(dfs_stack); SXG_U(dfs_marks);
+#undef SXG_U
+    return U;
+}
+SXG_HD RowsView sxg_scalar_view(const RowsView& R) {
+    RowsView U;
+#define SXG_U(f) U.f = sxg_scalar_ptr(R.f)
+    SXG_U(code); SXG_U(flags); SXG_U(pred_off); SXG_U(preds); SXG_U(slot); SXG_U(tbx); SXG_U(sseq); SXG_U(row_node); SXG_U(meta);
+#undef SXG_U
+    return U;
+}
+
 }  // namespace sxg
