@@ -535,3 +535,17 @@ def test_default_score_classes_equal_the_generic_ones(engine, oracle, monkeypatc
             for r, (g, sc, cells) in zip(res, want):
                 assert_block_equal(r, g, sc, cells, label=f"default-class env={env} mode={mode}")
     monkeypatch.delenv("SXG_POA_NO_DEFAULT_CLASS", raising=False)
+
+
+def test_end_cell_keys_across_row_epochs_and_ties(engine, oracle):
+    """The packed sweep finds the end cell of a local alignment with one key per strip -- (greatest H) << 16 | 0xffff - (row &
+    0xffff) -- and folds the keys at every 65 536th row.  Four UNRELATED sequences of 18 kbp: the graph passes 65 536 rows for the
+    fourth (the epoch fold runs), the best local score is small and reached in many cells (greatest score, then smallest row, then
+    smallest column must pick the oracle's cell), and every alignment is short (most bases become new nodes)."""
+    rng = np.random.default_rng(65536)
+    seqs = [rng.integers(0, 4, n, dtype=np.uint8) for n in (18000, 17900, 17800, 17700, 600)]
+    g, sc, cells = oracle.block_run(seqs, None, oparams("convex_default", 0))
+    assert len(g.nodes()[0]) > 66000
+    res = engine.run_blocks([seqs], gparams("convex_default", 0))
+    assert engine.stats()["dom_row_mode"] == 2
+    assert_block_equal(res[0], g, sc, cells, label="epochs-and-ties")
