@@ -125,3 +125,23 @@ def heaviest_bundle_independent(code, rank, edge_tail, edge_head, edge_weight):
         path.append(v)
         v = back[v]
     return np.asarray(path[::-1], np.int32)
+
+
+def rerun_in_own_process(request):
+    """Tests that create a real RCCL communicator run in a pytest process of their own: a long-lived process that has
+    loaded librccl.so (rccl 2.27.7 of ROCm 7.2) and goes on allocating and freeing HIP memory afterwards aborts in the
+    library teardown AFTER the interpreter has finalised ("double free or corruption" with every test passed: exit code
+    134 for the whole session; a process that only runs the communicator test exits cleanly).  In the parent this starts
+    the child on the same test and returns True (the caller returns); in the child it returns False and the body runs.
+    The child's verdict is pytest's own summary line."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("SXG_TEST_OWN_PROCESS"):
+        return False
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    node = "%s::%s" % (str(request.node.fspath), request.node.name)
+    r = subprocess.run([sys.executable, "-m", "pytest", node, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root,
+                       env=dict(os.environ, SXG_TEST_OWN_PROCESS="1"), capture_output=True, text=True, timeout=1200)
+    assert "1 passed" in r.stdout and "failed" not in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
+    return True

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import PARAM_SETS, assert_block_equal, gparams, oparams, random_block
+from helpers import PARAM_SETS, assert_block_equal, gparams, oparams, random_block, rerun_in_own_process
 from smoothxg_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -373,11 +373,15 @@ def test_small_memory_budget_runs_blocks_through_few_slots(engine, oracle):
         assert_block_equal(res[b], g, sc, cells, label=f"budget {b}")
 
 
-def test_sharded_run_reassembles_in_block_order(engine, oracle):
+def test_sharded_run_reassembles_in_block_order(request):
     """sxg_poa_batch_run_sharded (the multi-GPU entry of the C ABI): LPT partition by cost, per-rank blobs, assembly on
     the root in the batch's block order.  Played here with 1, 2, 3 and 5 SIMULATED ranks on the one GPU of the box (the
     test entry of the ABI: everything but ncclSend/ncclRecv) and with a real one-rank communicator; mixed block sizes,
-    per-block scores, weights, consensus and MSA must all come back as from the single-GPU call."""
+    per-block scores, weights, consensus and MSA must all come back as from the single-GPU call.  (In a process of its
+    own: see helpers.rerun_in_own_process.)"""
+    if rerun_in_own_process(request):
+        return
+    engine = request.getfixturevalue("engine")
     rng = np.random.default_rng(202)
     blocks, gp = [], []
     names = list(PARAM_SETS)

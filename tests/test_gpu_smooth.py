@@ -253,15 +253,18 @@ def test_device_block_graphs_feed_the_same_gfa_as_host_built_ones(engine, monkey
         assert fast == legacy
 
 
-def test_sharded_runs_carry_block_graphs_built_by_the_owning_rank(engine):
+def test_sharded_runs_carry_block_graphs_built_by_the_owning_rank(request):
     """Multi-GPU: every rank builds the block graphs of ITS blocks on its device and sends compact graphs (not one node id
     per base) to the rank that laces.  Played with simulated ranks on the one GPU (partition, per-rank blobs with the bg
     sections, the root's assembly in batch order) and through a real one-rank communicator: the block graphs equal the
     single-GPU ones, mode 2 leaves the per-base paths out of the blobs, and sxg_smooth_gfa over the sharded entry gives the
-    single-GPU bytes."""
+    single-GPU bytes.  (In a process of its own: see helpers.rerun_in_own_process.)"""
     import numpy as np
     import smoothxg_amd as SX
-    from helpers import random_block
+    from helpers import random_block, rerun_in_own_process
+    if rerun_in_own_process(request):
+        return
+    engine = request.getfixturevalue("engine")
     rng = np.random.default_rng(311)
     blocks = [random_block(rng, int(rng.integers(1, 10)), int(rng.choice([40, 300, 900])), div=0.06) if b != 4 else [] for b in range(13)]
     trims = [int(rng.integers(0, 12)) for _ in blocks]
