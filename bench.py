@@ -383,6 +383,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ns", choices=list(WORKLOADS))
     ap.add_argument("--mode", default="sw", choices=["sw", "nw"])
+    ap.add_argument("--spoa-order", action="store_true",
+                    help="decree S7': re-sort every graph depth-first after every sequence (sxg_poa_params::mode | SXG_ORDER_SPOA); "
+                         "prices the option, the committed fixtures hold the default order only (implies --no-verify)")
     ap.add_argument("--blocks", type=int, default=0, help="override the number of blocks per rank")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: ONE batch of --blocks blocks for all ranks, dealt by cost (shard.shard_batch, LPT) -- config 4's mode")
@@ -419,7 +422,9 @@ def main():
     if a.blocks:
         nb = a.blocks
     mode = 0 if a.mode == "sw" else 1
-    params = S.Params(*prm, mode, {"c3b": 1, "c3a": 2}.get(a.workload, 0))
+    if a.spoa_order:
+        a.no_verify = True
+    params = S.Params(*prm, mode | (0x10 if a.spoa_order else 0), {"c3b": 1, "c3a": 2}.get(a.workload, 0))
     strong = a.scaling == "strong" and world > 1
     eng = S.PoaEngine(local_rank)
     # N > 1: the engine's own RCCL communicator (sxg_poa_comm_init): rank 0 draws the id, torch.distributed carries it
@@ -636,7 +641,7 @@ def main():
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "int16" if st["dom_row_mode"] >= 2 else "int32", "data": "synthetic",
-            "config": {"workload": desc, "blocks_per_gpu": nb, "mode": a.mode,
+            "config": {"workload": desc, "blocks_per_gpu": nb, "mode": a.mode, "order": "spoa (S7')" if a.spoa_order else "default (S7)",
                        "cells_per_step_per_gpu": cells / a.steps},
             "cells_per_sec": total_cells / dt,
             "verified": verified, "verified_blocks": verified_blocks, "verified_what": verified_note,

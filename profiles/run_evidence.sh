@@ -24,7 +24,10 @@ done
 python bench.py --workload c2 --steps 5 --warmup 2 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 python bench.py --workload c2x8 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_c2x8.json 2> $OUT/bench_c2x8.err
 python bench.py --workload drb1 --steps 3 --warmup 1 > $OUT/bench_drb1.json 2> $OUT/bench_drb1.err
+# the price of the spoa order (S7'): headline and small-block shapes with and without --spoa-order
+LIBS="libsxgpoa.so" WLS="ns c2x8" bash $R/profiles/tools/s7_ab.sh > $OUT/s7_price.txt 2>&1
 tail -3 $OUT/ev_collect.log
+cat $OUT/s7_price.txt
 for f in $OUT/bench_*.json; do python - "$f" <<'PY'
 import json, sys
 try:

@@ -95,6 +95,7 @@ struct GraphView {
     SXG_GP int32_t *via;
     SXG_GP int32_t *dfs_stack;   // [n_edges + 6 n_nodes + 8]
     SXG_GP uint8_t *dfs_marks;   // [2 (n_nodes + 1)]: marks, ignored
+    SXG_GP int32_t *dfs_rec;     // [16 n_nodes]: per-node records of the walk (poa_graph_dev.h::spoa_resort)
 };
 
 // Row structures of the current graph in rank space, rebuilt before every alignment.
@@ -144,7 +145,7 @@ SXG_HD GraphView sxg_scalar_view(const GraphView& G) {
     SXG_U(in_head); SXG_U(in_tail); SXG_U(out_head); SXG_U(out_tail); SXG_U(in_deg); SXG_U(out_deg);
     SXG_U(e_tail); SXG_U(e_head); SXG_U(e_next_in); SXG_U(e_next_out); SXG_U(e_w);
     SXG_U(posnode); SXG_U(target); SXG_U(newidx); SXG_U(nexta); SXG_U(preva); SXG_U(slotadd); SXG_U(kind);
-    SXG_U(xpos); SXG_U(via); SXG_U(dfs_stack); SXG_U(dfs_marks);
+    SXG_U(xpos); SXG_U(via); SXG_U(dfs_stack); SXG_U(dfs_marks); SXG_U(dfs_rec);
 #undef SXG_U
     return U;
 }

@@ -723,6 +723,7 @@ static int launch_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, const int p
     A.prio_base = prio_base;
     A.est = R.est.as<unsigned long long>();
     A.blk_cycles = h->d_blk_cycles.as<unsigned long long>();
+    A.lds_bytes = getenv("SXG_POA_RESORT_NO_LDS") ? 0 : P.smem;   // (test knob: the S7' re-sort keeps its states in the slot's scratch, as it does for graphs beyond its LDS)
     // every slot's header (counters, phase times, clock readings) starts a launch at zero: one strided memset
     HIPCHK(hipMemset2DAsync(R.arena.as<uint8_t>() + P.lay.hdr, P.lay.total, 0, 512, (size_t)P.n_slots, R.stream));
     HIPCHK(hipStreamWaitEvent(R.stream, h->ev0, 0));

@@ -40,15 +40,15 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
     const size_t C = (size_t)cap + 2;
     std::vector<int32_t> hdr(2, 0), rk(C), ord(C), ordt(C), ld(C), gm(5 * C), ih(C), it(C), oh(C), ot(C),
         id(C), od(C), et(C), eh(C), eni(C), eno(C), posn(C), tgt(C), nidx(C), nxa(C), pva(C), sla(C), xps(C);
-    std::vector<int32_t> via(C), dfs(8 * C + 8);
-    std::vector<uint8_t> dmarks(2 * C + 8);
+    std::vector<int32_t> via(C), dfs(8 * C + 8), drec(16 * C + 16);
+    std::vector<uint8_t> dmarks(2 * C + 8), lst(C + 8 + 512);
     std::vector<uint32_t> ew(C);
     std::vector<uint8_t> cd(C);
     std::vector<int8_t> kd(C);
     GraphView G{&hdr[0], &hdr[1], cd.data(), rk.data(), ord.data(), ordt.data(), ld.data(), gm.data(),
                 ih.data(), it.data(), oh.data(), ot.data(), id.data(), od.data(), et.data(), eh.data(),
                 eni.data(), eno.data(), ew.data(), posn.data(), tgt.data(), nidx.data(), nxa.data(),
-                pva.data(), sla.data(), kd.data(), xps.data(), via.data(), dfs.data(), dmarks.data()};
+                pva.data(), sla.data(), kd.data(), xps.data(), via.data(), dfs.data(), dmarks.data(), drec.data()};
     std::vector<uint8_t> rcode(C), rflags(C), sink(C);
     std::vector<int32_t> poff(C + 1), preds(C), slot(C), tbx(C), sseq(C + 1), rnode(C), meta(8 * C);
     RowsView R{rcode.data(), rflags.data(), poff.data(), preds.data(), slot.data(), tbx.data(), sseq.data(),
@@ -72,7 +72,7 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
         }
         if (scores) scores[s] = sc;
         add_alignment(c, G, seq, len, weights ? weights[s] : 1u, paths + seq_off[s]);
-        if (spoa_order) spoa_resort(G);   // S7'
+        if (spoa_order) spoa_resort(c, G, lst.data(), spoa_order == 2 ? (int)lst.size() : 64);   // S7' (2: states in the "LDS" copy whatever the graph's size; 1: only graphs below 64 nodes)
     }
     std::vector<int64_t> csc(C);
     std::vector<int32_t> cpr(C);

@@ -475,16 +475,20 @@ def test_packed_sweep_handles_the_block_itself(engine, oracle, n_seqs, length):
         assert_block_equal(res[b], g, sc, cells, f"block {b}")
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_spoa_order_option_on_the_device(engine, oracle, mode):
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_spoa_order_option_on_the_device(engine, oracle, mode, monkeypatch):
     """sxg_poa_params::mode | SXG_ORDER_SPOA (decree S7': the depth-first re-sort after every AddAlignment that spoa is
-    believed to do; restated from memory, unverified): one lane per block re-sorts the graph on the device; scores,
+    believed to do; restated from memory, unverified): one lane per block walks the graph on the device (records built by all threads, states in LDS); scores,
     graphs, ranks, paths, consensus and MSA equal the oracle run with the same option, on blocks of several shapes
     (packed sweep, banded sweep, deep bubbles), and mixed with default-order blocks in one batch."""
     import smoothxg_amd as S
+    if mode == 2:   # (the walk's states in the slot's scratch instead of LDS: what a graph beyond the workgroup's LDS gets)
+        monkeypatch.setenv("SXG_POA_RESORT_NO_LDS", "1")
+        mode = 0
     rng = np.random.default_rng(900 + mode)
     blocks = [random_block(rng, int(rng.integers(2, 12)), L, div=0.07) for L in (30, 200, 700, 1600)]
     blocks.append(random_block(rng, 24, 300, div=0.12))
+    blocks.append(random_block(rng, 20, 2500, div=0.05))     # ~5 000 nodes, a four-wave class: groups, insertions, in-degrees beyond three
     m, n, g, e, q, c = PARAM_SETS["convex_default"]
     prm = [S.Params(m, n, g, e, q, c, mode | (0x10 if b != 1 else 0), 2 if (b == 3 and mode == 0) else 0) for b in range(len(blocks))]
     res = engine.run_blocks(blocks, prm, want_consensus=True, want_msa=True)

@@ -175,7 +175,8 @@ def test_spoa_order_option_matches_its_restatement(emul, oracle):
                 [rng.integers(0, 5, int(rng.integers(1, 30)), dtype=np.uint8) for _ in range(S)]
             w = rng.integers(1, 4, len(seqs))
             g, sc, _ = oracle.block_run(seqs, w, p)
-            st, r = run_emul(emul, seqs, w, p, spoa_order=1)
+            # (1: per-node states on the chip only while the graph is below 64 nodes, then in the slot's scratch; 2: always on the chip)
+            st, r = run_emul(emul, seqs, w, p, spoa_order=1 + trial % 2)
             assert st == 0
             code, rank, grp = g.nodes()
             t, h, ww = g.edges()
