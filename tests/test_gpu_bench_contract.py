@@ -88,3 +88,13 @@ def test_drb1_workload_reports_wall_seconds_and_checks_every_iteration():
     assert d["unit"] == "s" and d["higher_is_better"] is False and d["verified"] is True
     assert len(d["iteration_seconds"]) == 3 and abs(sum(d["iteration_seconds"]) - d["value"]) < 0.05 * d["value"] + 0.05
     assert d["config"]["blocks_per_iteration"] == [2161, 2066, 2025]
+
+
+def test_spoa_order_flag_prices_the_option_without_claiming_verification():
+    """`--spoa-order` (decree S7': sxg_poa_params::mode | SXG_ORDER_SPOA on every block) runs the same batch with the depth-first
+    re-sort; the committed fixtures hold the default order only, so the line says which order it ran and does not say `verified`."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "1", "--warmup", "0", "--spoa-order",
+                          "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["order"].startswith("spoa") and d["verified"] is None and d["value"] > 0
