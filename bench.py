@@ -680,7 +680,15 @@ def main():
                                    "gpu_over_cpu": (total_cells / dt) / cb["cells_per_s"]}
         print(json.dumps(out))
     if world > 1:
+        # Every rank has printed / handed over what it had: give the communicators back explicitly and leave without the
+        # libraries' own teardown -- a process that created an RCCL communicator through the C ABI can abort in it after main
+        # has returned ("Observed with rccl 2.27.7"), which torchrun would report as a failed rank.
+        eng.close()
+        dist.barrier()
         dist.destroy_process_group()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
