@@ -72,7 +72,7 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
         }
         if (scores) scores[s] = sc;
         add_alignment(c, G, seq, len, weights ? weights[s] : 1u, paths + seq_off[s]);
-        if (spoa_order) spoa_resort(c, G, lst.data(), spoa_order == 2 ? (int)lst.size() : 64);   // S7' (2: states in the "LDS" copy whatever the graph's size; 1: only graphs below 64 nodes)
+        if (spoa_order) spoa_resort(c, G, lst.data(), spoa_order == 2 ? (int)lst.size() : spoa_order == 3 ? hdr[0] + 1 + 16 : 64);   // S7' (2: states in the "LDS" copy whatever the graph's size; 1: only graphs below 64 nodes)
     }
     std::vector<int64_t> csc(C);
     std::vector<int32_t> cpr(C);

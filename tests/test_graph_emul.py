@@ -175,8 +175,9 @@ def test_spoa_order_option_matches_its_restatement(emul, oracle):
                 [rng.integers(0, 5, int(rng.integers(1, 30)), dtype=np.uint8) for _ in range(S)]
             w = rng.integers(1, 4, len(seqs))
             g, sc, _ = oracle.block_run(seqs, w, p)
-            # (1: per-node states on the chip only while the graph is below 64 nodes, then in the slot's scratch; 2: always on the chip)
-            st, r = run_emul(emul, seqs, w, p, spoa_order=1 + trial % 2)
+            # (1: per-node states on the chip only while the graph is below 64 nodes, then in the slot's scratch; 2: always on the chip;
+            #  3: on the chip with room for four stack entries, the rest of the stack in the scratch)
+            st, r = run_emul(emul, seqs, w, p, spoa_order=1 + trial % 3)
             assert st == 0
             code, rank, grp = g.nodes()
             t, h, ww = g.edges()
@@ -213,3 +214,30 @@ def test_traceback_plane_layout_is_a_bijection_and_matches_the_wide_stores(emul)
                 assert (np.diff(grp, axis=1) == 1).all()
                 if gw == 4:
                     assert (grp[:, 0] % 4 == 0).all()
+
+
+def test_spoa_order_walk_on_bushy_graphs(emul, oracle):
+    """The re-sort's record paths that pangenome-like blocks hardly reach: nodes with more than three in-edges (the record holds
+    three tails, the walk then follows the list), aligned groups of four and five whose members' tails overflow the record's
+    eight (no one-visit finish), deep pushes (the stack beyond its on-chip entries).  40 short sequences over five letters, 12 %
+    substitutions, 3 % deletions."""
+    rng = np.random.default_rng(4242)
+    for trial in range(6):
+        L = int(rng.integers(30, 90))
+        base = rng.integers(0, 4, L).astype(np.uint8)
+        seqs = []
+        for _ in range(40):   # substitutions only (five letters: groups of up to five), a few deletions for the wide in-degrees
+            q = np.where(rng.random(L) < 0.12, rng.integers(0, 5, L), base).astype(np.uint8)
+            seqs.append(q[rng.random(L) > 0.03])
+        w = rng.integers(1, 4, len(seqs))
+        p = oparams("convex_default", trial % 2)
+        p.mode = (trial % 2) | 0x10
+        g, sc, _ = oracle.block_run(seqs, w, p)
+        code, rank, grp = g.nodes()
+        t, h, _ = g.edges()
+        indeg = np.bincount(h, minlength=len(code))
+        sizes = np.bincount(grp)
+        assert indeg.max() > 3 and sizes.max() >= 4, (indeg.max(), sizes.max())
+        for cap_mode in (1, 2, 3):
+            st, r = run_emul(emul, seqs, w, p, spoa_order=cap_mode)
+            assert st == 0 and (r[1] == rank).all() and (r[7] == sc).all() and (r[3] == t).all() and (r[4] == h).all()
