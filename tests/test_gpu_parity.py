@@ -489,6 +489,8 @@ def test_spoa_order_option_on_the_device(engine, oracle, mode, monkeypatch):
     blocks = [random_block(rng, int(rng.integers(2, 12)), L, div=0.07) for L in (30, 200, 700, 1600)]
     blocks.append(random_block(rng, 24, 300, div=0.12))
     blocks.append(random_block(rng, 20, 2500, div=0.05))     # ~5 000 nodes, a four-wave class: groups, insertions, in-degrees beyond three
+    base = rng.integers(0, 4, 80).astype(np.uint8)            # bushy: aligned groups of five, in-degrees of six and more (the record's overflow paths)
+    blocks.append([np.where(rng.random(80) < 0.12, rng.integers(0, 5, 80), base).astype(np.uint8)[rng.random(80) > 0.03] for _ in range(40)])
     m, n, g, e, q, c = PARAM_SETS["convex_default"]
     prm = [S.Params(m, n, g, e, q, c, mode | (0x10 if b != 1 else 0), 2 if (b == 3 and mode == 0) else 0) for b in range(len(blocks))]
     res = engine.run_blocks(blocks, prm, want_consensus=True, want_msa=True)
