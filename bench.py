@@ -135,7 +135,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workload, mode):
+def cpu_baseline(workload, mode, spoa_order=True):
     """The oracle ("port") timed on the host's physical cores on WHOLE blocks of the workload (all sequences of
     every sampled block), one block per thread per round, per-thread workspaces, OpenMP schedule(dynamic,1) as
     src/smooth.cpp:1931.  Quoted: the AVX2 int16 row sweep (oracle/poa_simd.c) -- the reference's spoa is an int16
@@ -147,7 +147,7 @@ def cpu_baseline(workload, mode):
     phys = physical_cores()
     quota = cgroup_cpu_limit()
     cores = min(phys, quota) if quota else phys
-    p = O.mkparams(*prm, mode=mode)
+    p = O.mkparams(*prm, mode=mode | (0x10 if spoa_order else 0))   # (the same node order as the timed GPU batch)
     impl = O.IMPL_AVX2 if O.simd_available() else O.IMPL_SCALAR
     # memory guard: the vectorised variant keeps H, oF, oO of every cell (6 B) of one alignment per thread
     rows = ln * max(2.0, 1.0 + 0.0165 * ns) + 1024
@@ -278,7 +278,9 @@ def profile_counters(key):
     return w
 
 # fixture names of the blocks tests/golden/fullshape_oracle.json holds for a bench workload: (workload, mode) -> case name
-FIXTURE_CASE = {("c2x8", "sw"): "c2", ("ns", "sw"): "ns_sw", ("ns", "nw"): "ns_nw", ("ns4", "nw"): "ns_nw_affine", ("c3", "sw"): "c3", ("c2", "sw"): "c2"}
+FIXTURE_CASE = {("c2x8", "sw"): "c2", ("ns", "sw"): "ns_sw", ("ns", "nw"): "ns_nw", ("ns4", "nw"): "ns_nw_affine", ("c3", "sw"): "c3", ("c2", "sw"): "c2",
+                ("c3a", "sw"): "c3a", ("c3b", "sw"): "c3b"}
+BANDED_OF = {"c3b": 1, "c3a": 2}   # the `-A` path's workloads: static band / abPOA's adaptive band (sxg_poa_params::banded)
 
 
 def digest_block(r):
@@ -292,7 +294,7 @@ def digest_block(r):
             "paths": sha(np.concatenate([np.asarray(q, np.int32) for q in r.paths]) if len(r.paths) else np.zeros(0, np.int32), np.int32)}
 
 
-def verify_against_fixture(res, workload, mode, first_block, prm):
+def verify_against_fixture(res, workload, mode, first_block, prm, order="spoa"):
     """The timed batch checked against COMMITTED oracle output (tests/golden/fullshape_oracle.json: scores of every sequence,
     node / edge counts, cells, SHA-256 of nodes, ranks, groups, edges, weights, per-base paths) for the blocks of the batch
     the fixture holds -- blocks 0 and 999 of the headline and of config 2, 0 and 4999 of config 3.  No oracle code runs.
@@ -301,7 +303,7 @@ def verify_against_fixture(res, workload, mode, first_block, prm):
     if name is None:
         return None, [], "no committed full-shape fixture for this workload / mode"
     cases = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "fullshape_oracle.json")))["cases"]
-             if c["name"] == name and list(c["params"]) == list(prm)]
+             if c["name"] == name and list(c["params"]) == list(prm) and c.get("order", "s7") == order and c.get("banded", 0) == BANDED_OF.get(workload, 0)]
     done = []
     for c in cases:
         k = c["block_id"] - first_block
@@ -383,9 +385,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ns", choices=list(WORKLOADS))
     ap.add_argument("--mode", default="sw", choices=["sw", "nw"])
-    ap.add_argument("--spoa-order", action="store_true",
-                    help="decree S7': re-sort every graph depth-first after every sequence (sxg_poa_params::mode | SXG_ORDER_SPOA); "
-                         "prices the option, the committed fixtures hold the default order only (implies --no-verify)")
+    ap.add_argument("--s7-order", action="store_true",
+                    help="the node order of rounds 1-5 (decree S7: kept incrementally) instead of spoa's depth-first re-sort after every "
+                         "sequence (decree S7', sxg_poa_params::mode | SXG_ORDER_SPOA: what src/smooth.cpp:764 does, the default since round 6); "
+                         "prices the default against the cheaper order.  The `-A` workloads (c3a, c3b) always keep S7: abPOA does not call spoa's sort")
     ap.add_argument("--blocks", type=int, default=0, help="override the number of blocks per rank")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: ONE batch of --blocks blocks for all ranks, dealt by cost (shard.shard_batch, LPT) -- config 4's mode")
@@ -422,9 +425,8 @@ def main():
     if a.blocks:
         nb = a.blocks
     mode = 0 if a.mode == "sw" else 1
-    if a.spoa_order:
-        a.no_verify = True
-    params = S.Params(*prm, mode | (0x10 if a.spoa_order else 0), {"c3b": 1, "c3a": 2}.get(a.workload, 0))
+    spoa_order = not a.s7_order and a.workload not in BANDED_OF
+    params = S.Params(*prm, mode | (0x10 if spoa_order else 0), BANDED_OF.get(a.workload, 0))
     strong = a.scaling == "strong" and world > 1
     eng = S.PoaEngine(local_rank)
     # N > 1: the engine's own RCCL communicator (sxg_poa_comm_init): rank 0 draws the id, torch.distributed carries it
@@ -530,14 +532,14 @@ def main():
             verified_note = "no committed full-shape fixture for this workload / mode"
         else:
             vres = eng.download()
-            verified, verified_blocks, verified_note = verify_against_fixture(vres, a.workload, a.mode, 0, prm)
+            verified, verified_blocks, verified_note = verify_against_fixture(vres, a.workload, a.mode, 0, prm, "spoa" if spoa_order else "s7")
             del vres
     if a.check and rank == 0:
         from oracle import oracle_py as O
         res = eng.download_sharded() if (strong and exchange == "cabi") else eng.download()
         for b in (0, len(res) - 1):
             seqs = [bases[seq_off[s]:seq_off[s + 1]] for s in range(blk_off[b], blk_off[b + 1])]
-            g, sc, _ = O.block_run(seqs, None, O.mkparams(*prm, mode=mode))
+            g, sc, _ = O.block_run(seqs, None, O.mkparams(*prm, mode=mode | (0x10 if spoa_order else 0), banded=BANDED_OF.get(a.workload, 0)))
             assert (res[b].scores == sc).all() and len(res[b].node_code) == g.n_nodes, "bench check failed"
 
     if rank == 0:
@@ -641,7 +643,7 @@ def main():
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "int16" if st["dom_row_mode"] >= 2 else "int32", "data": "synthetic",
-            "config": {"workload": desc, "blocks_per_gpu": nb, "mode": a.mode, "order": "spoa (S7')" if a.spoa_order else "default (S7)",
+            "config": {"workload": desc, "blocks_per_gpu": nb, "mode": a.mode, "order": "spoa (S7': depth-first re-sort after every sequence, src/smooth.cpp:764)" if spoa_order else "incremental (S7)",
                        "cells_per_step_per_gpu": cells / a.steps},
             "cells_per_sec": total_cells / dt,
             "verified": verified, "verified_blocks": verified_blocks, "verified_what": verified_note,
@@ -666,7 +668,7 @@ def main():
                                  "kernel_only_blocks_per_sec": nb * a.steps / (kernel_ms / 1e3),
                                  "ratio_to_kernel_only": (nb / e_s) / (nb * a.steps / (kernel_ms / 1e3))}
         if world == 1 and not a.no_cpu_baseline and a.workload not in ("c4", "c3b", "c3a"):  # (no fixed shape to sample for c4)
-            cb = cpu_baseline(a.workload, mode)
+            cb = cpu_baseline(a.workload, mode, spoa_order)
             cells_per_block = cells / a.steps / nb
             out["cpu_baseline"] = {"value": cb["cells_per_s"] / cells_per_block, "unit": "blocks/s",
                                    "cores": cb["cores"], "kind": "port", "sample": cb["sample"],

@@ -72,8 +72,11 @@ typedef struct sxg_smooth_params {
     int32_t poa_spoa_order;                           /* 1 = the engine re-sorts a block's graph after every alignment the way
                                                          spoa's TopologicalSort is believed to (SXG_ORDER_SPOA, include/sxg_poa.h:
                                                          decree S7', restated from memory, unverified) instead of keeping it in
-                                                         order incrementally (decree S7); one lane per block does it, see
-                                                         DESIGN.md for the price.  Default 0. */
+                                                         order incrementally (decree S7).  DEFAULT 1 since round 6: it is what
+                                                         graph.AddAlignment does at src/smooth.cpp:764, and the re-sort is a
+                                                         parallel, incremental device phase now (0.5-5 % of the kernel time,
+                                                         DESIGN.md).  Ignored with use_abpoa (abPOA does not call spoa's sort).
+                                                         0 = the order of rounds 1-5. */
 } sxg_smooth_params;
 
 void sxg_smooth_default_params(sxg_smooth_params *p);

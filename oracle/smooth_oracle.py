@@ -398,11 +398,11 @@ def collect_text(c):
 CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
 
 
-def engine_params(m, n, g, e, q, cc, local, abpoa, band_local=True, spoa_order=False):
+def engine_params(m, n, g, e, q, cc, local, abpoa, band_local=True, spoa_order=True):
     """CLI scores -> the POA engine's (spoa's) convention.  smooth_spoa negates them (src/smooth.cpp:2098-2106); smooth_abpoa
     hands them to abPOA as they are (:2079-2090): a gap of k costs min(g + k e, q + k cc), g = 0 linear, q = 0 affine, and the
     alignment runs with abPOA's adaptive band (banded = 2)."""
-    mode = (0 if local else 1) | (0x10 if spoa_order else 0)   # (0x10: POA_ORDER_SPOA, decree S7')
+    mode = (0 if local else 1) | (0x10 if spoa_order and not abpoa else 0)   # (0x10: POA_ORDER_SPOA, decree S7'; the spoa path only)
     if not abpoa:
         return O.mkparams(m, -n, -g, -e, -q, -cc, mode)
     band = 0 if (local and not band_local) else 2   # (sxg_smooth_params.abpoa_band_local: upstream abPOA may run local mode unbanded)
@@ -413,7 +413,7 @@ def engine_params(m, n, g, e, q, cc, local, abpoa, band_local=True, spoa_order=F
     return O.mkparams(m, -n, -(g + e), -e, -(q + cc), -cc, mode, banded=band)
 
 
-def poa(c, m=1, n=4, g=6, e=2, q=26, cc=1, local=True, abpoa=False, band_local=True, spoa_order=False):
+def poa(c, m=1, n=4, g=6, e=2, q=26, cc=1, local=True, abpoa=False, band_local=True, spoa_order=True):
     """The POA of one block through the C oracle -> (node letters, per-seq paths, consensus)."""
     seqs = [np.array([CODE.get(ch, 4) for ch in s], np.uint8) for s in c.seqs]
     G, _, _ = O.block_run(seqs, c.weights, engine_params(m, n, g, e, q, cc, local, abpoa, band_local, spoa_order))
@@ -597,7 +597,7 @@ def build_block_graph(c, node_code, seq_paths, cons, consensus_name, abpoa=False
 
 
 # ---- MSA -> MAF rows (src/smooth.cpp:782-905) and the MAF block text (src/maf.hpp:35-66)
-def poa_msa(c, add_consensus, m=1, n=4, g=6, e=2, q=26, cc=1, local=True, abpoa=False, band_local=True, spoa_order=False):
+def poa_msa(c, add_consensus, m=1, n=4, g=6, e=2, q=26, cc=1, local=True, abpoa=False, band_local=True, spoa_order=True):
     seqs = [np.array([CODE.get(ch, 4) for ch in s], np.uint8) for s in c.seqs]
     G, _, _ = O.block_run(seqs, c.weights, engine_params(m, n, g, e, q, cc, local, abpoa, band_local, spoa_order))
     return G.msa(add_consensus), len(G.consensus())
@@ -723,7 +723,7 @@ def block_scores(g, ranges, adaptive, k, max_depth, m=1, n=4, g_=6, e=2, q=26, c
 
 
 def smooth(graph, blocks, add_consensus=False, consensus_base="Consensus_", fraction=0.001, max_depth=1000, adaptive=False,
-           kmer_size=17, merge=None, abpoa=False, band_local=True, spoa_order=False, **scores):
+           kmer_size=17, merge=None, abpoa=False, band_local=True, spoa_order=True, **scores):
     """One smoothing iteration (src/main.cpp:599-1061 around the per-block POA) -> GFA text.
     merge: dict(merge_blocks, jaccard, preserve_unmerged, max_groups, header) -> runs the in-order MAF consumer as
     well (block merging, flips) and returns (GFA text, MAF text, flipped blocks).  scores: m, n, g, e, q, cc (CLI values), local."""

@@ -41,6 +41,8 @@ def build(force=False, verbose=False):
             objs.append(obj)
         if failed is not None:
             pending = []
+        if not running:   # (fewer jobs than sources and the only running one failed: nothing left to wait for)
+            break
         proc, cmd = running.pop(0)
         if proc.wait() != 0 and failed is None:
             failed = cmd

@@ -37,6 +37,7 @@ struct WgCtxT {
     __device__ __forceinline__ int nthreads() const { return (int)blockDim.x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int atomic_add(int32_t* p, int v) const { return atomicAdd(p, v); }
+    __device__ __forceinline__ int atomic_min(int32_t* p, int v) const { return atomicMin(p, v); }
     __device__ int scan_excl_add(int v, int* total) const {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
         int x = v;

@@ -307,17 +307,37 @@ SXG_HD int spoa_aligned_list(const GraphView& G, int v, int* out) {
         if (mem[k] == v) { for (int q = 0; q < ln[k]; ++q) out[q] = list[k][q]; return ln[k]; }
     return 0;
 }
-// Round 5: the walk no longer chases the graph's linked lists, and its marks live on the chip.
-//  * Every thread of the workgroup first writes, for its share of the nodes, what the walk needs of a node into ONE 32-byte
-//    record -- the number of in-edges and the first three tails (insertion order), the aligned-node list -- so that a visit
-//    loads the record and then the states of what it names, instead of a dozen dependent loads (in_head -> e_tail -> marks ->
-//    e_next_in ..., leader -> gmem -> via ...); a node with more than three in-edges walks its list as before.
-//  * The per-node state (mark, "ignored") is one byte in the workgroup's LDS -- the sweep's rows and windows are dead between
-//    two alignments -- when the graph fits (`lst_cap` nodes; else the slot's global scratch as before): ~100 ns a read instead
-//    of ~650 ns under load.
-//  * The records of four consecutive roots are requested together, before the first of them is looked at (they never change
-//    during a re-sort; only the states do).
-// The walk itself stays one lane's: same pushes, same order.  The ranks are written by all threads.
+// Round 5: the walk no longer chases the graph's linked lists.  Every thread of the workgroup first writes, for its share of
+// the nodes, what the walk needs of a node into ONE 64-byte record -- the number of in-edges and the first three tails
+// (insertion order), the aligned-node list, the in-edge tails of the aligned nodes -- so that a visit loads the record and
+// then the states of what it names, instead of a dozen dependent loads (in_head -> e_tail -> marks -> e_next_in ...,
+// leader -> gmem -> via ...); a node with more than three in-edges walks its list as before.  A node with aligned nodes
+// whose tails, and whose aligned nodes' tails, are all done finishes its whole group in the one visit -- what the walk
+// would reach by pushing every aligned node, finding each of them valid, popping back and looking at the node again.
+//
+// Round 6: THE WALK IS PARALLEL.  The sequential algorithm starts a depth-first walk at every node in id order that is
+// not done yet; the walk from root s finishes exactly the nodes of s's dependency closure (in-edge tails and aligned
+// nodes, transitively) that no earlier root finished.  So node x is finished by the root
+//     first(x) = the smallest id among the nodes that reach x through (tail | aligned node) links
+//              = the smallest id x reaches through (out-edge head | aligned node) links, x included,
+// the order is the concatenation, over the roots s with first(s) = s in ascending order, of the post-order of s's walk,
+// and inside that walk "done" is simply  first(x) < s  or finished by this very walk.  Nothing a walk reads is written by
+// another walk: the roots are independent.
+//   P1  all threads: the records; first(x) := x; jump(x) := head of x's oldest out-edge.
+//   P2  all threads, rounds until nothing changes: first(x) := min over x's out-edge heads, aligned nodes and jump(x);
+//       jump(x) := jump(jump(x)).  Values only fall and every one of them is the id of a node x reaches, so any
+//       interleaving of reads and writes converges to the same fixed point; along the run of nodes a sequence created
+//       the jump pointers double their reach per round.  (The nodes of the block's first sequence form the chain
+//       0 -> 1 -> ... and everything else has a greater id: their first() is their own id -- `n_static` of them are skipped.)
+//   P3  all threads: nodes and stack demand per root (atomic counts), two exclusive sums: where a root's piece of the
+//       order and its stack begin.
+//   P4  every thread walks ITS roots (t, t + T, ...): same pushes, same pops, same emissions as the sequential walk from
+//       that root -- most roots are a single backbone node whose tails are done: one record, one emission.
+//   P5  all threads: rank[order[r]] = r.
+// The per-node word (first | state << 28; state = mark | ignored << 2) lives in the workgroup's LDS when the graph fits
+// (the sweep's rows and windows are dead between two alignments), else in the slot's scratch.  64 x 5 kbp: the one-lane
+// walk of round 5 took ~7 ms per re-sort (1.25 x the kernel time for S7'); this one is bounded by the block's longest
+// piece -- the structural variant's branch, a few hundred nodes.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SXG_WAVE_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #else
@@ -327,130 +347,315 @@ SXG_HD int spoa_aligned_list(const GraphView& G, int v, int* out) {
 SXG_HD __attribute__((address_space(3))) int32_t* sxg_as_i32(__attribute__((address_space(3))) uint8_t* p) { return (__attribute__((address_space(3))) int32_t*)p; }
 #endif
 SXG_HD int32_t* sxg_as_i32(uint8_t* p) { return (int32_t*)p; }
-// A node with aligned nodes also records THEIR in-edge tails (up to eight): when all of those are done as well, the group is
-// finished in the one visit -- what the walk would reach by pushing every aligned node, finding each of them valid, popping back
-// and looking at the node again (a third of all visits on 64 x 5 kbp, each with a record to fetch first).
 constexpr int SPOA_REC = 16;   // int32 per record: n_in | n_aligned << 8 | n_member_tails << 16 (255: too many), tails[3], aligned[4], member tails[8]
+constexpr int SPOA_FMASK = 0x0fffffff;   // first() of a node in its state word; the state above it
 struct alignas(16) SpoaHalf { int x, y, z, w; };
-template <class StP, class SkP>
-SXG_HD int spoa_walk(const GraphView& G_, const int n, StP st, SkP lstack, const int lstack_cap) {
-    const GraphView G = G_;   // (a copy in registers: read through the reference, every pointer is re-fetched from the kernel's private memory after every global store)
-    SXG_GP int32_t* const gstack = G.dfs_stack;
+
+// P4: the depth-first walk from root s0 (first(s0) == s0), emitting into ord[0 ..) and using stk[0 ..) -- both private to the
+// root.  W: the per-node words.  Returns the number of nodes emitted.
+template <class WP>
+SXG_HD_PHASE int spoa_walk_root(const GraphView& G, WP W, const int s0, SXG_GP int32_t* const ord, SXG_GP int32_t* const stk,
+                          const SpoaHalf ra, const SpoaHalf rb) {
     SXG_GP const SpoaHalf* const rec = (SXG_GP const SpoaHalf*)G.dfs_rec;
-    int w = 0;
-    // the depth-first walk from root s0, whose record the caller already holds
-    // (the stack: its first lstack_cap entries next to the states, the rest -- hardly ever -- in the slot's scratch)
-    int sp = 0;
-    auto push = [&](const int x) { if (sp < lstack_cap) lstack[sp] = x; else gstack[sp] = x; ++sp; };
-    auto run = [&](const int s0, const SpoaHalf ra, const SpoaHalf rb, const SpoaHalf rc, const SpoaHalf rd) {
-        sp = 0;
-        push(s0);
-        int curr = s0;
-        bool fresh = true, at_root = true;   // fresh: curr is the node on top of the stack (just pushed)
-        while (sp > 0) {
-            if (!fresh) curr = sp - 1 < lstack_cap ? (int)lstack[sp - 1] : (int)gstack[sp - 1];
-            bool valid = true;
-            int last = curr;
-            const int sc = at_root ? 0 : (int)st[curr];   // (a root is entered with state 0: the caller has just read it)
-            at_root = false;
-            if ((sc & 3) != 2) {
-                SpoaHalf a = ra, b = rb, mc = rc, md = rd;
-                const bool ign = (sc & 4) != 0;
-                if (curr != s0) {
-                    a = rec[4 * (size_t)curr]; b = rec[4 * (size_t)curr + 1];
-                    if (!ign && ((a.x >> 8) & 0xff) != 0) { mc = rec[4 * (size_t)curr + 2]; md = rec[4 * (size_t)curr + 3]; }
-                }
-                const int ni = a.x & 0xff, na = ign ? 0 : (a.x >> 8) & 0xff, nmt = (a.x >> 16) & 0xff;
-                const int al[4] = {b.x, b.y, b.z, b.w};
-                if (ni <= 3) {
-                    const int m0 = ni > 0 ? (int)st[a.y] : 2, m1 = ni > 1 ? (int)st[a.z] : 2, m2 = ni > 2 ? (int)st[a.w] : 2;
-                    int ma[4];
-                    for (int q = 0; q < 4; ++q) ma[q] = q < na ? (int)st[al[q]] : 2;
-                    if (na > 0 && nmt <= 8 && (m0 & 3) == 2 && (m1 & 3) == 2 && (m2 & 3) == 2) {
-                        // the whole group at once: my tails are done -- are those of my aligned nodes?
-                        const int mt[8] = {mc.x, mc.y, mc.z, mc.w, md.x, md.y, md.z, md.w};
-                        bool all = true;
-                        for (int q = 0; q < 8; ++q) if (q < nmt && ((int)st[mt[q]] & 3) != 2) all = false;
-                        if (all) {
-                            for (int q = 0; q < 4; ++q) if (q < na && (ma[q] & 3) != 2) { st[al[q]] = (uint8_t)(ma[q] | 4 | 2); ma[q] = 2; }
-                        }
-                    }
-                    if ((m0 & 3) != 2) { push(a.y); last = a.y; valid = false; }
-                    if ((m1 & 3) != 2) { push(a.z); last = a.z; valid = false; }
-                    if ((m2 & 3) != 2) { push(a.w); last = a.w; valid = false; }
-                    for (int q = 0; q < 4; ++q)
-                        if ((ma[q] & 3) != 2) { push(al[q]); st[al[q]] = (uint8_t)(ma[q] | 4); last = al[q]; valid = false; }
-                } else {
-                    for (int e = G.in_head[curr]; e >= 0; e = G.e_next_in[e]) {
-                        const int tl = G.e_tail[e];
-                        if (((int)st[tl] & 3) != 2) { push(tl); last = tl; valid = false; }
-                    }
-                    for (int q = 0; q < na; ++q) {
-                        const int m = (int)st[al[q]];
-                        if ((m & 3) != 2) { push(al[q]); st[al[q]] = (uint8_t)(m | 4); last = al[q]; valid = false; }
+    // state of node x as this walk sees it: finished by an earlier root = done (2); else its own bits (mark | ignored << 2)
+    auto stt = [&](const int x) -> int { const int w = (int)W[x]; return (w & SPOA_FMASK) < s0 ? 2 : (w >> 28) & 7; };
+    auto set = [&](const int x, const int st) { W[x] = s0 | (st << 28); };   // (x belongs to this root: first(x) == s0)
+    int w = 0, sp = 0;
+    auto push = [&](const int x) { stk[sp++] = x; };
+    push(s0);
+    int curr = s0;
+    bool fresh = true, at_root = true;   // fresh: curr is the node on top of the stack (just pushed)
+    while (sp > 0) {
+        if (!fresh) curr = stk[sp - 1];
+        bool valid = true;
+        int last = curr;
+        const int sc = at_root ? 0 : stt(curr);   // (a root is entered with state 0)
+        if ((sc & 3) != 2) {
+            SpoaHalf a = ra, b = rb;
+            if (!at_root) { a = rec[4 * (size_t)curr]; b = rec[4 * (size_t)curr + 1]; }
+            const bool ign = (sc & 4) != 0;
+            const int ni = a.x & 0xff, na = ign ? 0 : (a.x >> 8) & 0xff, nmt = (a.x >> 16) & 0xff;
+            const int al[4] = {b.x, b.y, b.z, b.w};
+            if (ni <= 3) {
+                const int m0 = ni > 0 ? stt(a.y) : 2, m1 = ni > 1 ? stt(a.z) : 2, m2 = ni > 2 ? stt(a.w) : 2;
+                int ma[4];
+                for (int q = 0; q < 4; ++q) ma[q] = q < na ? stt(al[q]) : 2;
+                if (na > 0 && nmt <= 8 && (m0 & 3) == 2 && (m1 & 3) == 2 && (m2 & 3) == 2) {
+                    // the whole group at once: my tails are done -- are those of my aligned nodes?
+                    const SpoaHalf mc = rec[4 * (size_t)curr + 2], md = rec[4 * (size_t)curr + 3];
+                    const int mt[8] = {mc.x, mc.y, mc.z, mc.w, md.x, md.y, md.z, md.w};
+                    bool all = true;
+                    for (int q = 0; q < 8; ++q) if (q < nmt && (stt(mt[q]) & 3) != 2) all = false;
+                    if (all) {
+                        for (int q = 0; q < 4; ++q) if (q < na && (ma[q] & 3) != 2) { set(al[q], ma[q] | 4 | 2); ma[q] = 2; }
                     }
                 }
-                if (valid) {
-                    st[curr] = (uint8_t)((sc & 4) | 2);
-                    if (!ign) {
-                        G.order[w++] = curr;
-                        for (int q = 0; q < na; ++q) G.order[w++] = al[q];
-                    }
-                } else st[curr] = (uint8_t)((sc & 4) | 1);
+                if ((m0 & 3) != 2) { push(a.y); last = a.y; valid = false; }
+                if ((m1 & 3) != 2) { push(a.z); last = a.z; valid = false; }
+                if ((m2 & 3) != 2) { push(a.w); last = a.w; valid = false; }
+                for (int q = 0; q < 4; ++q)
+                    if ((ma[q] & 3) != 2) { push(al[q]); set(al[q], ma[q] | 4); last = al[q]; valid = false; }
+            } else {
+                for (int e = G.in_head[curr]; e >= 0; e = G.e_next_in[e]) {
+                    const int tl = G.e_tail[e];
+                    if ((stt(tl) & 3) != 2) { push(tl); last = tl; valid = false; }
+                }
+                for (int q = 0; q < na; ++q) {
+                    const int m = stt(al[q]);
+                    if ((m & 3) != 2) { push(al[q]); set(al[q], m | 4); last = al[q]; valid = false; }
+                }
             }
-            if (valid) { --sp; fresh = false; } else { curr = last; fresh = true; }
+            if (valid) {
+                set(curr, (sc & 4) | 2);
+                if (!ign) {
+                    ord[w++] = curr;
+                    for (int q = 0; q < na; ++q) ord[w++] = al[q];
+                }
+            } else set(curr, (sc & 4) | 1);
         }
-    };
-    for (int s0 = 0; s0 < n; s0 += 4) {
-        SpoaHalf ra[4], rb[4], rc[4], rd[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int v = s0 + k < n ? s0 + k : n - 1;
-            ra[k] = rec[4 * (size_t)v]; rb[k] = rec[4 * (size_t)v + 1]; rc[k] = rec[4 * (size_t)v + 2]; rd[k] = rec[4 * (size_t)v + 3];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (s0 + k < n && ((int)st[s0 + k] & 3) == 0) run(s0 + k, ra[k], rb[k], rc[k], rd[k]);
+        at_root = false;
+        if (valid) { --sp; fresh = false; } else { curr = last; fresh = true; }
     }
     return w;
 }
-template <class Ctx, class LdsP>
-SXG_HD_PHASE void spoa_resort(Ctx& c, const GraphView& G_, LdsP lst, const int lst_cap) {
-    const GraphView G = G_;
+
+#if defined(SXG_RESORT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define SXG_RSP(k) do { if (t == 0 && rprof) { const unsigned long long now_ = (unsigned long long)clock64(); rprof[k] += now_ - rt0_; rt0_ = now_; } } while (0)
+#define SXG_RSP_DECL unsigned long long rt0_ = (unsigned long long)clock64()
+#else
+#define SXG_RSP(k) ((void)0)
+#define SXG_RSP_DECL ((void)0)
+#endif
+// One record (see above) of node v, from the graph's lists.
+SXG_HD void spoa_build_record(const GraphView& G, const int v) {
+    int tl[3] = {-1, -1, -1}, ni = 0;
+    for (int e = G.in_head[v]; e >= 0; e = G.e_next_in[e]) { if (ni < 3) tl[ni] = G.e_tail[e]; ++ni; }
+    int al[5] = {-1, -1, -1, -1, -1};
+    const int na = spoa_aligned_list(G, v, al);
+    int mt[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, nmt = 0;
+    for (int q = 0; q < na; ++q)
+        for (int e = G.in_head[al[q]]; e >= 0; e = G.e_next_in[e]) { if (nmt < 8) mt[nmt] = G.e_tail[e]; ++nmt; }
+    SXG_GP int32_t* const r = G.dfs_rec + (size_t)SPOA_REC * v;
+    r[0] = (ni < 255 ? ni : 255) | (na << 8) | ((nmt <= 8 ? nmt : 255) << 16);
+    r[1] = tl[0]; r[2] = tl[1]; r[3] = tl[2];
+    r[4] = al[0]; r[5] = al[1]; r[6] = al[2]; r[7] = al[3];
+    for (int q = 0; q < 8; ++q) r[8 + q] = mt[q];
+}
+
+// Round 6, second step: ONLY WHAT THE ALIGNMENT TOUCHED IS SORTED AGAIN.  Inside a block the graph only grows, so first() of a
+// node never rises, and the piece of the order that root s's walk produces is a function of (a) the records of the nodes it
+// finishes and (b) which of their tails and aligned nodes belong to s and which to smaller roots.  A piece is therefore the
+// same as after the previous re-sort when
+//     no node of it is new, none has a new in-edge, a new aligned node or an aligned node with a new in-edge ("touched": their
+//     records are the only ones rebuilt), every node of it belonged to s before, and s finishes as many nodes as before
+// (a node that left went to a smaller root, which fails the second test there).  Such a piece is not walked: node x goes to
+// base(s) + (its previous spoa rank - the smallest previous rank of the piece) -- pieces are contiguous in the order.  What
+// is kept from re-sort to re-sort: the records, the spoa rank and first() of every node, the size of every root's piece.
+// After AddAlignment of a sequence of `len` letters G.target / G.kind / G.nexta still say, per letter, the node it went to,
+// whether that node is new and whether the edge into it is new; `n_prev` nodes existed before it.  `full`: nothing is kept
+// (the block's first re-sort).
+template <class Ctx, class WP>
+SXG_HD void spoa_resort_par(Ctx& c, const GraphView& G, WP W, const int n, const int n_static, const int len, const int n_prev_,
+                            const bool full, unsigned long long* rprof) {
     const int T = c.nthreads(), t = c.tid();
-    const int n = *G.n_nodes;
-    SXG_GP uint8_t* const gst = G.dfs_marks;
+    SXG_RSP_DECL;
+    const int n_prev = full ? 0 : n_prev_;
+    const int BIG = 0x3fffffff;
     SXG_GP int32_t* const rec = G.dfs_rec;
-    const bool on_chip = lst_cap >= n + 1;
-    if (on_chip) { for (int v = t; v < n + 1; v += T) lst[v] = 0; }
-    else { for (int v = t; v < n + 1; v += T) gst[v] = 0; }
-    for (int v = t; v < n; v += T) {
-        int tl[3] = {-1, -1, -1}, ni = 0;
-        for (int e = G.in_head[v]; e >= 0; e = G.e_next_in[e]) { if (ni < 3) tl[ni] = G.e_tail[e]; ++ni; }
-        int al[5] = {-1, -1, -1, -1, -1};
-        const int na = spoa_aligned_list(G, v, al);
-        int mt[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, nmt = 0;
-        for (int q = 0; q < na; ++q)
-            for (int e = G.in_head[al[q]]; e >= 0; e = G.e_next_in[e]) { if (nmt < 8) mt[nmt] = G.e_tail[e]; ++nmt; }
-        SXG_GP int32_t* const r = rec + (size_t)SPOA_REC * v;
-        r[0] = (ni < 255 ? ni : 255) | (na << 8) | ((nmt <= 8 ? nmt : 255) << 16);
-        r[1] = tl[0]; r[2] = tl[1]; r[3] = tl[2];
-        r[4] = al[0]; r[5] = al[1]; r[6] = al[2]; r[7] = al[3];
-        for (int q = 0; q < 8; ++q) r[8 + q] = mt[q];
+    SXG_GP int32_t* const touched = G.posnode;   // [n] the node's record has to be rebuilt (free until the next alignment starts)
+    SXG_GP int32_t* const jump = G.nexta;
+    SXG_GP int32_t* const cnt = G.preva;      // nodes a root finishes -> where its piece of the order begins
+    SXG_GP int32_t* const sdem = G.slotadd;   // stack entries a root can need -> where its stack begins
+    SXG_GP int32_t* const pmin = G.target;    // smallest previous spoa rank of a root's piece
+    SXG_GP int8_t* const walk = G.kind;       // the root's piece has to be walked again
+    // ---- P1: records of the touched nodes (listed first: rebuilt where they stand in the loop over all nodes, a wave would run
+    //      one record's chain of dependent loads after the other for nearly every node it holds)
+    constexpr int GB = Ctx::GB;   // (nodes per thread and step, every stage of dependent loads issued for all of them before the next)
+    SXG_GP int32_t* const list = G.order_tmp;
+    for (int v = t; v < n; v += T) touched[v] = v >= n_prev ? 1 : 0;
+    if (t == 0) { sdem[n] = 0; sdem[n + 1] = 0; sdem[n + 2] = 0; }   // (the walks' stacks are handed out from [n]; [n + 1]: touched nodes; [n + 2]: roots to walk)
+    c.sync();
+    if (!full) {
+        for (int i0 = t; i0 < len; i0 += GB * T) {
+            int kd[GB], nw[GB], tg[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int i = i0 + u * T < len ? i0 + u * T : len - 1;
+                kd[u] = G.kind[i]; nw[u] = i > 0 ? G.nexta[i] : 0; tg[u] = G.target[i];
+            }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                if (i0 + u * T >= len || (kd[u] == 0 && nw[u] == 0)) continue;
+                const int ld = G.leader[tg[u]];   // (a sequence passes through a group once: no two letters list the same nodes)
+                for (int x = 0; x < 5; ++x) {
+                    const int mbr = G.gmem[5 * ld + x];
+                    if (mbr >= 0) { touched[mbr] = 1; list[c.atomic_add((int32_t*)(sdem + n + 1), 1)] = mbr; }
+                }
+            }
+        }
+        c.sync();
+        const int nt = sdem[n + 1];
+        for (int k = t; k < nt; k += T) spoa_build_record(G, list[k]);
+    } else {
+        for (int v = t; v < n; v += T) spoa_build_record(G, v);
+    }
+    for (int v0 = t; v0 < n; v0 += GB * T) {
+        int eo[GB], f0[GB], hd[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int v = v0 + u * T < n ? v0 + u * T : n - 1;
+            eo[u] = G.out_head[v];
+            f0[u] = v >= n_prev ? v : G.sp_first[v];   // (still the id of a node v reaches)
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) { const int v = v0 + u * T < n ? v0 + u * T : n - 1; hd[u] = eo[u] >= 0 ? G.e_head[eo[u]] : v; }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int v = v0 + u * T;
+            if (v >= n) continue;
+            W[v] = f0[u];
+            jump[v] = hd[u];
+            cnt[v] = 0; sdem[v] = 0; pmin[v] = BIG; walk[v] = full ? 1 : 0;
+        }
     }
     c.sync();
-    if (t == 0) {
-        // One lane's chain of short dependent instructions: with the co-resident workgroups in their sweeps its wave would get
-        // every fourth issue slot of its SIMD -- at top priority it issues whenever it is ready, and takes next to nothing from them.
-        SXG_WAVE_PRIO(3);
-        // (on the chip: states in bytes [0, n], then the stack's first entries in what is left)
-        const int soff = (n + 1 + 3) & ~3;
-        if (on_chip) spoa_walk(G, n, lst, sxg_as_i32(lst + soff), (lst_cap - soff) / 4);
-        else spoa_walk(G, n, gst, G.dfs_stack, 0);
-        SXG_WAVE_PRIO(0);
+    SXG_RSP(0);
+    // ---- P2: first()
+    for (int round = 0; round < n + 2; ++round) {
+        int changed = 0;
+        for (int x0 = n_static + t; x0 < n; x0 += GB * T) {
+            int old[GB], eo[GB], r0[GB], j[GB], h0[GB], ne[GB], jj[GB], v[GB];
+            SpoaHalf al[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int x = x0 + u * T < n ? x0 + u * T : n - 1;
+                old[u] = (int)W[x]; eo[u] = G.out_head[x]; r0[u] = rec[(size_t)SPOA_REC * x]; j[u] = jump[x];
+            }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int x = x0 + u * T < n ? x0 + u * T : n - 1;
+                h0[u] = eo[u] >= 0 ? G.e_head[eo[u]] : x;
+                ne[u] = eo[u] >= 0 ? G.e_next_out[eo[u]] : -1;
+                jj[u] = jump[j[u]];
+                if ((r0[u] >> 8) & 0xff) al[u] = ((SXG_GP const SpoaHalf*)rec)[4 * (size_t)x + 1];
+                else al[u] = SpoaHalf{x, x, x, x};
+            }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int x = x0 + u * T < n ? x0 + u * T : n - 1;
+                const int na = (r0[u] >> 8) & 0xff;
+                int m = old[u];
+                { const int f = (int)W[h0[u]]; m = f < m ? f : m; }
+                { const int f = (int)W[j[u]]; m = f < m ? f : m; }
+                { const int f = (int)W[na > 0 ? al[u].x : x]; m = f < m ? f : m; }
+                { const int f = (int)W[na > 1 ? al[u].y : x]; m = f < m ? f : m; }
+                { const int f = (int)W[na > 2 ? al[u].z : x]; m = f < m ? f : m; }
+                { const int f = (int)W[na > 3 ? al[u].w : x]; m = f < m ? f : m; }
+                v[u] = m;
+            }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int x = x0 + u * T;
+                if (x >= n) continue;
+                int m = v[u];
+                for (int e = ne[u]; e >= 0; e = G.e_next_out[e]) { const int f = (int)W[G.e_head[e]]; m = f < m ? f : m; }
+                jump[x] = jj[u];
+                if (m < old[u]) { W[x] = m; changed = 1; }
+            }
+        }
+        changed = c.reduce_max(changed);   // (also the barrier between the rounds)
+#if defined(SXG_RESORT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+        if (t == 0 && rprof) rprof[5] += 1;
+#endif
+        if (!changed) break;
+    }
+    SXG_RSP(1);
+    // ---- P3: the roots' pieces
+    for (int x0 = t; x0 < n; x0 += GB * T) {
+        int s[GB], idg[GB], tch[GB], spf[GB], spr[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int x = x0 + u * T < n ? x0 + u * T : n - 1;
+            s[u] = (int)W[x]; idg[u] = G.in_deg[x]; tch[u] = touched[x];
+            spf[u] = full ? 0 : G.sp_first[x]; spr[u] = full ? 0 : G.sp_rank[x];
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            if (x0 + u * T >= n) continue;
+            c.atomic_add((int32_t*)(cnt + s[u]), 1);
+            c.atomic_add((int32_t*)(sdem + s[u]), idg[u] + 6);
+            if (!full) {
+                if (tch[u] || spf[u] != s[u]) walk[s[u]] = 1;
+                else c.atomic_min((int32_t*)(pmin + s[u]), spr[u]);
+            }
+        }
     }
     c.sync();
-    for (int r = t; r < n; r += T) G.rank[G.order[r]] = r;
+    for (int s0 = t; s0 < n; s0 += GB * T) {   // (the roots whose pieces are walked again, listed: a handful of several thousand)
+        int k[GB], ko[GB], wk[GB], ws[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int s = s0 + u * T < n ? s0 + u * T : n - 1;
+            k[u] = cnt[s]; ko[u] = full ? 0 : G.sp_cnt[s]; wk[u] = walk[s]; ws[u] = (int)W[s];
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int s = s0 + u * T;
+            if (s >= n) continue;
+            const bool again = wk[u] != 0 || (!full && k[u] != ko[u]);
+            if (again && !wk[u]) walk[s] = 1;
+            G.sp_cnt[s] = k[u];
+            if (again && ws[u] == s) list[c.atomic_add((int32_t*)(sdem + n + 2), 1)] = s;
+        }
+    }
+    array_excl_sum(c, n, [&](int s) { return cnt[s]; }, cnt);
+    c.sync();
+    SXG_RSP(2);
+    // ---- P4: kept pieces are placed, the others walked
+    if (!full) {
+        for (int x0 = t; x0 < n; x0 += GB * T) {
+            int s[GB], rk[GB], wk[GB], b0[GB], p0[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) { const int x = x0 + u * T < n ? x0 + u * T : n - 1; s[u] = (int)W[x] & SPOA_FMASK; rk[u] = G.sp_rank[x]; }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) { wk[u] = walk[s[u]]; b0[u] = cnt[s[u]]; p0[u] = pmin[s[u]]; }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) { const int x = x0 + u * T; if (x < n && !wk[u]) G.order[b0[u] + rk[u] - p0[u]] = x; }
+        }
+    }
+    {
+        SXG_GP const SpoaHalf* const rh = (SXG_GP const SpoaHalf*)rec;
+        const int nw = sdem[n + 2];
+        for (int k = t; k < nw; k += T) {
+            const int v = list[k];
+            const SpoaHalf ra = rh[4 * (size_t)v], rb = rh[4 * (size_t)v + 1];
+            const int ob = cnt[v], sb = sdem[v];
+            spoa_walk_root(G, W, v, G.order + ob, G.dfs_stack + c.atomic_add((int32_t*)(sdem + n), sb), ra, rb);
+        }
+    }
+    c.sync();
+    SXG_RSP(3);
+    for (int r0 = t; r0 < n; r0 += GB * T) {
+        int v[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) v[u] = r0 + u * T < n ? G.order[r0 + u * T] : 0;
+#pragma unroll
+        for (int u = 0; u < GB; ++u) { const int r = r0 + u * T; if (r < n) { G.rank[v[u]] = r; G.sp_rank[v[u]] = r; } }
+    }
+    for (int x = t; x < n; x += T) G.sp_first[x] = (int)W[x] & SPOA_FMASK;
+    SXG_RSP(4);
+}
+
+// lst / lst_cap: bytes of the workgroup's LDS the re-sort may use (the per-node words); n_static: ids below it are the
+// block's first sequence (a chain) -- 0 when the caller does not know; len, n_prev, full: see spoa_resort_par.
+template <class Ctx, class LdsP>
+SXG_HD_PHASE void spoa_resort(Ctx& c, const GraphView& G_, LdsP lst, const int lst_cap, const int n_static, const int len, const int n_prev,
+                              const bool full, unsigned long long* rprof = nullptr) {
+    const GraphView G = sxg_scalar_view(G_);
+    const int n = *G.n_nodes;
+    const int ns = n_static < n ? (n_static > 0 ? n_static : 0) : n;
+    if (lst_cap >= 4 * (n + 1)) spoa_resort_par(c, G, sxg_as_i32(lst), n, ns, len, n_prev, full, rprof);
+    else spoa_resort_par(c, G, G.newidx, n, ns, len, n_prev, full, rprof);
 }
 
 struct RowCaps {

@@ -23,7 +23,7 @@ using namespace sxg;
 struct SlotLayout {  // byte offsets inside one slot arena (all 16-byte aligned)
     size_t hdr, code, rank, order, order_tmp, leader, gmem, in_head, in_tail, out_head, out_tail, in_deg,
         out_deg, e_tail, e_head, e_next_in, e_next_out, e_w, posnode, target, newidx, nexta, preva, slotadd,
-        kind, xpos, via, dfs_stack, dfs_marks, dfs_rec, r_code, r_flags, r_pred_off, r_preds, r_slot, r_tbx, r_sseq, r_row_node, r_meta, tb, steps, pool,
+        kind, xpos, via, dfs_stack, dfs_rec, sp_rank, sp_first, sp_cnt, r_code, r_flags, r_pred_off, r_preds, r_slot, r_tbx, r_sseq, r_row_node, r_meta, tb, steps, pool,
         row0, park, cons_sc, cons_pr, pair_row, pair_pos, total;
     int nodes_cap, rows_cap, pool_slots, step_cap, scratch_len, Lpad, word_bytes, threads;
     int band_strips;  // packed sweep: strips per row in the traceback plane (0 = not the packed sweep)
@@ -38,10 +38,10 @@ inline size_t lay(size_t& cur, size_t bytes) {
 
 // band_strips > 0: packed sweep with strips of Lpad / (2 * threads) columns; cell_bytes: its plane cell format (2: delta
 // codes, W + 1 halfwords per strip; 4: one dword per cell)
-// spoa_scratch: the launch holds blocks that ask for spoa's depth-first order (S7'): stack and marks of the re-sort, ~30 bytes per
-// node of nodes_cap -- left out of every other arena
+// spoa_scratch: the launch holds blocks that ask for spoa's depth-first order (S7'): stacks, records and the kept state of the
+// re-sort, ~104 bytes per node of nodes_cap -- left out of every other arena
 inline SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int step_cap, int threads, int Lpad,
-                              int word_bytes, bool pairs, int band_strips = 0, int cell_bytes = 4, bool spoa_scratch = true) {
+                              int word_bytes, bool pairs, int band_strips = 0, int cell_bytes = 4, bool spoa_scratch = false) {
     SlotLayout L;
     memset(&L, 0, sizeof(L));
     L.nodes_cap = nodes_cap; L.rows_cap = rows_cap; L.pool_slots = pool_slots;
@@ -63,8 +63,9 @@ inline SlotLayout make_layout(int nodes_cap, int rows_cap, int pool_slots, int s
     L.nexta = lay(cur, 4 * S); L.preva = lay(cur, 4 * S); L.slotadd = lay(cur, 4 * S); L.kind = lay(cur, S);
     L.xpos = lay(cur, 4 * C);
     L.via = lay(cur, 4 * C);
-    L.dfs_stack = lay(cur, spoa_scratch ? 4 * (7 * C + 8) : 256); L.dfs_marks = lay(cur, spoa_scratch ? 2 * C + 8 : 256);
+    L.dfs_stack = lay(cur, spoa_scratch ? 4 * (7 * C + 8) : 256);
     L.dfs_rec = lay(cur, spoa_scratch ? 64 * C : 256);
+    L.sp_rank = lay(cur, spoa_scratch ? 4 * C : 256); L.sp_first = lay(cur, spoa_scratch ? 4 * C : 256); L.sp_cnt = lay(cur, spoa_scratch ? 4 * C : 256);
     L.r_code = lay(cur, Rr); L.r_flags = lay(cur, Rr); L.r_pred_off = lay(cur, 4 * Rr);
     L.r_preds = lay(cur, 4 * C); L.r_slot = lay(cur, 4 * Rr); L.r_tbx = lay(cur, 4 * Rr);
     L.r_sseq = lay(cur, 4 * Rr); L.r_row_node = lay(cur, 4 * Rr); L.r_meta = lay(cur, 32 * Rr);
@@ -103,7 +104,8 @@ __device__ static SlotViews slot_views(uint8_t* base, const SlotLayout& L) {
     V.G.e_next_out = P32(e_next_out); V.G.e_w = (SXG_GP uint32_t*)(base + L.e_w);
     V.G.posnode = P32(posnode); V.G.target = P32(target); V.G.newidx = P32(newidx); V.G.nexta = P32(nexta);
     V.G.preva = P32(preva); V.G.slotadd = P32(slotadd); V.G.kind = (SXG_GP int8_t*)(base + L.kind);
-    V.G.xpos = P32(xpos); V.G.via = P32(via); V.G.dfs_stack = P32(dfs_stack); V.G.dfs_marks = (SXG_GP uint8_t*)(base + L.dfs_marks); V.G.dfs_rec = P32(dfs_rec);
+    V.G.xpos = P32(xpos); V.G.via = P32(via); V.G.dfs_stack = P32(dfs_stack); V.G.dfs_rec = P32(dfs_rec);
+    V.G.sp_rank = P32(sp_rank); V.G.sp_first = P32(sp_first); V.G.sp_cnt = P32(sp_cnt);
     V.R.code = (SXG_GP uint8_t*)(base + L.r_code); V.R.flags = (SXG_GP uint8_t*)(base + L.r_flags); V.R.pred_off = P32(r_pred_off);
     V.R.preds = P32(r_preds); V.R.slot = P32(r_slot); V.R.tbx = P32(r_tbx); V.R.sseq = P32(r_sseq);
     V.R.row_node = P32(r_row_node); V.R.meta = P32(r_meta);
@@ -307,9 +309,11 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             if (TMAX == 64 || (TMAX <= 128 && T <= 64)) { WgCtxT<16> c16{ctx.lds}; add_alignment(c16, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
             else if (TMAX == 128) { WgCtxT<8> c8{ctx.lds}; add_alignment(c8, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
             else add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
-            if (A.params[A.per_block_params ? b : 0].mode & SXG_ORDER_SPOA) {   // S7': spoa's depth-first re-sort (one lane walks)
+            if (A.params[A.per_block_params ? b : 0].mode & SXG_ORDER_SPOA) {   // S7': spoa's depth-first re-sort (every thread walks its roots: poa_graph_dev.h)
                 typedef __attribute__((address_space(3))) uint8_t lds_u8;
-                spoa_resort(ctx, V.G, (lds_u8*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)LDS_CTL_BYTES), A.lds_bytes - LDS_CTL_BYTES);
+                // (N nodes before this alignment; the block's first re-sort builds everything, the later ones what the alignment touched)
+                spoa_resort(ctx, V.G, (lds_u8*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)LDS_CTL_BYTES), A.lds_bytes - LDS_CTL_BYTES,
+                            (int)(A.seq_off[s0 + 1] - A.seq_off[s0]), len, N, s == s0, prof + 41);
                 __syncthreads();
             }
             PROF(4);

@@ -93,9 +93,12 @@ struct GraphView {
     // S7' (spoa's depth-first re-sort, sxg_poa_params::mode | SXG_ORDER_SPOA): the node a node was created aligned to (-1:
     // created unaligned) -- it fixes the order of spoa's aligned-node lists --, and the scratch of the re-sort
     SXG_GP int32_t *via;
-    SXG_GP int32_t *dfs_stack;   // [n_edges + 6 n_nodes + 8]
-    SXG_GP uint8_t *dfs_marks;   // [2 (n_nodes + 1)]: marks, ignored
-    SXG_GP int32_t *dfs_rec;     // [16 n_nodes]: per-node records of the walk (poa_graph_dev.h::spoa_resort)
+    SXG_GP int32_t *dfs_stack;   // [n_edges + 6 n_nodes + 8]: the walks' stacks, one piece per root
+    SXG_GP int32_t *dfs_rec;     // [16 n_nodes]: per-node records of the walk (poa_graph_dev.h::spoa_resort); kept from re-sort to re-sort
+    // what the previous re-sort of this block left for the next one (round 6: only what an alignment touched is sorted again)
+    SXG_GP int32_t *sp_rank;     // [n_nodes] spoa rank of every node
+    SXG_GP int32_t *sp_first;    // [n_nodes] first() of every node: the root whose walk finished it
+    SXG_GP int32_t *sp_cnt;      // [n_nodes] nodes the walk from root s finished (at roots)
 };
 
 // Row structures of the current graph in rank space, rebuilt before every alignment.
@@ -145,7 +148,7 @@ SXG_HD GraphView sxg_scalar_view(const GraphView& G) {
     SXG_U(in_head); SXG_U(in_tail); SXG_U(out_head); SXG_U(out_tail); SXG_U(in_deg); SXG_U(out_deg);
     SXG_U(e_tail); SXG_U(e_head); SXG_U(e_next_in); SXG_U(e_next_out); SXG_U(e_w);
     SXG_U(posnode); SXG_U(target); SXG_U(newidx); SXG_U(nexta); SXG_U(preva); SXG_U(slotadd); SXG_U(kind);
-    SXG_U(xpos); SXG_U(via); SXG_U(dfs_stack); SXG_U(dfs_marks); SXG_U(dfs_rec);
+    SXG_U(xpos); SXG_U(via); SXG_U(dfs_stack); SXG_U(dfs_rec); SXG_U(sp_rank); SXG_U(sp_first); SXG_U(sp_cnt);
 #undef SXG_U
     return U;
 }

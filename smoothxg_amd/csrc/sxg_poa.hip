@@ -779,6 +779,20 @@ static int debug_plan(sxg_poa_handle* h, LaunchPlan& P, PlanRes& R, int attempt)
                 (double)ra[10] / std::max<double>((double)ra[8], 1), (double)ra[11] / std::max<double>((double)ra[8], 1));
     }
 #endif
+#ifdef SXG_RESORT_PROF
+    {   // phases of the S7' re-sort (poa_graph_dev.h::spoa_resort_par), thread 0's clock
+        unsigned long long ra[6] = {0};
+        for (int64_t sl = 0; sl < P.n_slots; ++sl) {
+            unsigned long long one[6];
+            HIPCHK(hipMemcpy(one, R.arena.as<uint8_t>() + (size_t)sl * P.lay.total + P.lay.hdr + 64 + 41 * 8, sizeof(one), hipMemcpyDeviceToHost));
+            for (int k = 0; k < 6; ++k) ra[k] += one[k];
+        }
+        double rt = 1e-9;
+        for (int k = 0; k < 5; ++k) rt += (double)ra[k];
+        fprintf(stderr, "[sxg]   re-sort: records %.1f%% first() %.1f%% counts %.1f%% walks %.1f%% ranks %.1f%%; %.3g cycles per slot, %.1f rounds per slot\n",
+                100 * ra[0] / rt, 100 * ra[1] / rt, 100 * ra[2] / rt, 100 * ra[3] / rt, 100 * ra[4] / rt, rt / (double)P.n_slots, (double)ra[5] / (double)P.n_slots);
+    }
+#endif
     double tot = 1e-9;
     for (int k = 0; k < 6; ++k) tot += (double)acc[k];
     size_t fr = 0, tt = 0;

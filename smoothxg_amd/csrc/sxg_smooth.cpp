@@ -675,7 +675,8 @@ void add_to_batch(batch_t& B, const collected_t& c) {
 }
 sxg_poa_params poa_params(const sxg_smooth_params& p) {  // src/smooth.cpp:2098-2106
     sxg_poa_params q;
-    q.mode = (uint8_t)((p.local_alignment ? SXG_MODE_LOCAL : SXG_MODE_GLOBAL) | (p.poa_spoa_order ? SXG_ORDER_SPOA : 0)); q.banded = 0;
+    // (spoa's node order belongs to the spoa path: smooth_abpoa never calls spoa's sort, the `-A` path keeps the engine's own order)
+    q.mode = (uint8_t)((p.local_alignment ? SXG_MODE_LOCAL : SXG_MODE_GLOBAL) | (p.poa_spoa_order && !p.use_abpoa ? SXG_ORDER_SPOA : 0)); q.banded = 0;
     if (!p.use_abpoa) {
         q.m = (int8_t)p.poa_m; q.n = (int8_t)-p.poa_n; q.g = (int8_t)-p.poa_g; q.e = (int8_t)-p.poa_e; q.q = (int8_t)-p.poa_q; q.c = (int8_t)-p.poa_c;
         return q;
@@ -1905,7 +1906,7 @@ void sxg_smooth_default_params(sxg_smooth_params* p) {
     if (!p) return;
     p->struct_size = (uint32_t)sizeof(sxg_smooth_params);
     p->abpoa_band_local = 1;
-    p->poa_spoa_order = 0;
+    p->poa_spoa_order = 1;   // (round 6: what smooth_spoa's graph.AddAlignment does, src/smooth.cpp:764 -- spoa re-sorts the graph every time)
     p->poa_m = 1; p->poa_n = 4; p->poa_g = 6; p->poa_e = 2; p->poa_q = 26; p->poa_c = 1;  // src/main.cpp:322-327
     p->local_alignment = 1;                                                              // src/main.cpp:487
     p->poa_padding_fraction = 0.001f; p->max_block_depth_for_padding_more = 1000;         // src/main.cpp:293-295

@@ -20,6 +20,7 @@ struct SerialCtx {
     int scan_excl_max(int v, int* total) { *total = v; return -0x7fffffff; }
     int reduce_max(int v) { return v; }
     int atomic_add(int32_t* p, int v) { int o = *p; *p += v; return o; }
+    int atomic_min(int32_t* p, int v) { int o = *p; if (v < o) *p = v; return o; }
     int load_fresh(const int32_t* p) { return *p; }
     std::vector<int> hp = std::vector<int>(4);   // (tiny on purpose: the ordering phase's spill to HBM gets exercised)
     int* heap() { return hp.data(); }
@@ -40,15 +41,15 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
     const size_t C = (size_t)cap + 2;
     std::vector<int32_t> hdr(2, 0), rk(C), ord(C), ordt(C), ld(C), gm(5 * C), ih(C), it(C), oh(C), ot(C),
         id(C), od(C), et(C), eh(C), eni(C), eno(C), posn(C), tgt(C), nidx(C), nxa(C), pva(C), sla(C), xps(C);
-    std::vector<int32_t> via(C), dfs(8 * C + 8), drec(16 * C + 16);
-    std::vector<uint8_t> dmarks(2 * C + 8), lst(C + 8 + 512);
+    std::vector<int32_t> via(C), dfs(8 * C + 8), drec(16 * C + 16), sprank(C), spfirst(C), spcnt(C);
+    std::vector<uint8_t> lst(4 * C + 64);
     std::vector<uint32_t> ew(C);
     std::vector<uint8_t> cd(C);
     std::vector<int8_t> kd(C);
     GraphView G{&hdr[0], &hdr[1], cd.data(), rk.data(), ord.data(), ordt.data(), ld.data(), gm.data(),
                 ih.data(), it.data(), oh.data(), ot.data(), id.data(), od.data(), et.data(), eh.data(),
                 eni.data(), eno.data(), ew.data(), posn.data(), tgt.data(), nidx.data(), nxa.data(),
-                pva.data(), sla.data(), kd.data(), xps.data(), via.data(), dfs.data(), dmarks.data(), drec.data()};
+                pva.data(), sla.data(), kd.data(), xps.data(), via.data(), dfs.data(), drec.data(), sprank.data(), spfirst.data(), spcnt.data()};
     std::vector<uint8_t> rcode(C), rflags(C), sink(C);
     std::vector<int32_t> poff(C + 1), preds(C), slot(C), tbx(C), sseq(C + 1), rnode(C), meta(8 * C);
     RowsView R{rcode.data(), rflags.data(), poff.data(), preds.data(), slot.data(), tbx.data(), sseq.data(),
@@ -71,8 +72,13 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
                 if (an[k] >= 0 && ap[k] >= 0) posn[ap[k]] = rnode[an[k]];
         }
         if (scores) scores[s] = sc;
+        const int n_before = hdr[0];
         add_alignment(c, G, seq, len, weights ? weights[s] : 1u, paths + seq_off[s]);
-        if (spoa_order) spoa_resort(c, G, lst.data(), spoa_order == 2 ? (int)lst.size() : spoa_order == 3 ? hdr[0] + 1 + 16 : 64);   // S7' (2: states in the "LDS" copy whatever the graph's size; 1: only graphs below 64 nodes)
+        // S7' (2: the per-node words in the "LDS" copy whatever the graph's size, and the first sequence named as the static chain;
+        //      3: in the "LDS" copy, no static chain; 1: only graphs below 16 nodes on the chip, the others in the slot's scratch)
+        //      4: as 2, but every re-sort builds everything (nothing kept from the previous one)
+        if (spoa_order) spoa_resort(c, G, lst.data(), spoa_order == 1 ? 64 : (int)lst.size(), (spoa_order & 1) ? 0 : seq_off[1] - seq_off[0], len, n_before,
+                                    s == 0 || spoa_order == 4);
     }
     std::vector<int64_t> csc(C);
     std::vector<int32_t> cpr(C);

@@ -90,11 +90,25 @@ def test_drb1_workload_reports_wall_seconds_and_checks_every_iteration():
     assert d["config"]["blocks_per_iteration"] == [2161, 2066, 2025]
 
 
-def test_spoa_order_flag_prices_the_option_without_claiming_verification():
-    """`--spoa-order` (decree S7': sxg_poa_params::mode | SXG_ORDER_SPOA on every block) runs the same batch with the depth-first
-    re-sort; the committed fixtures hold the default order only, so the line says which order it ran and does not say `verified`."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "1", "--warmup", "0", "--spoa-order",
-                          "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["config"]["order"].startswith("spoa") and d["verified"] is None and d["value"] > 0
+def test_the_default_order_is_spoas_and_the_old_one_is_an_option():
+    """Round 6: the bench runs spoa's node order (decree S7': sxg_poa_params::mode | SXG_ORDER_SPOA, what src/smooth.cpp:764 does) by
+    default and verifies itself against committed fixtures IN THAT ORDER; `--s7-order` runs the incrementally kept order of
+    rounds 1-5 against its own fixtures."""
+    for flag, want in ((None, "spoa"), ("--s7-order", "incremental")):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e"]
+        out = subprocess.run(cmd + ([flag] if flag else []), capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["config"]["order"].startswith(want) and d["verified"] is True and d["verified_blocks"] == [0, 999] and d["value"] > 0, d["config"]
+
+
+def test_the_banded_workloads_verify_themselves():
+    """Round 6: config 3 on the `-A` path (c3b: static band, c3a: abPOA's adaptive band) carries committed fixtures -- blocks 0 and
+    4999 of the 5000 -- so those lines say `verified: true` too (order s7: abPOA does not call spoa's sort)."""
+    for wl in ("c3b", "c3a"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--blocks", "48", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e"],
+                             capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        # (48 of the 5000 blocks here: block 0 is in the batch, block 4999 only in the full run)
+        assert d["verified"] is True and d["verified_blocks"] == [0] and d["config"]["order"].startswith("incremental"), (wl, d["verified_what"])

@@ -1,4 +1,4 @@
-"""MI355X: randomized parity -- every block of a batch brings its own random score set, alignment mode and band flag
+"""MI355X: randomized parity -- every block of a batch brings its own random score set, alignment mode, node order and band flag
 (the engine's per_block_params), lengths from 1 to 3 kbp, 1-20 sequences, N letters, weights.  HIP == oracle, bit for bit."""
 import os
 
@@ -46,6 +46,9 @@ def test_random_blocks_random_scores_per_block(engine, seed):
         banded = int(rng.integers(0, 3)) if mode == 0 else 0
         if mode == 1 and L <= 300 and trial % 2 == 1:
             banded = 2   # abPOA's band in global mode (round 4); short enough for every score set to stay in the packed range
+        # round 6: the node order is drawn per block as well -- spoa's depth-first re-sort after every sequence (0x10, decree S7': the
+        # parallel, incremental re-sort of the device against the oracle's one sequential walk) for two blocks out of three
+        mode |= 0x10 if int(rng.integers(0, 3)) else 0
         blocks.append(seqs)
         weights.append(rng.integers(1, 6, len(seqs)).astype(np.uint32))
         gp.append(Params(m, n, g, e, q, c, mode, banded))
@@ -81,8 +84,9 @@ def test_random_long_banded_blocks(engine, seed):
         m = min(m, 29999 // max(len(x) for x in seqs))
         banded = 1 + trial % 2
         blocks.append(seqs)
-        gp.append(Params(m, n, g, e, q, c, 0, banded))
-        op.append(O.mkparams(m, n, g, e, q, c, mode=0, banded=banded))
+        omode = 0x10 if trial % 3 == 0 else 0   # (round 6: spoa's order on the banded kernel as well)
+        gp.append(Params(m, n, g, e, q, c, omode, banded))
+        op.append(O.mkparams(m, n, g, e, q, c, mode=omode, banded=banded))
     res = engine.run_blocks(blocks, gp, want_consensus=True)
     for b, seqs in enumerate(blocks):
         g_, sc, cells = O.block_run(seqs, None, op[b])

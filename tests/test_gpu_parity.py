@@ -478,7 +478,8 @@ def test_packed_sweep_handles_the_block_itself(engine, oracle, n_seqs, length):
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_spoa_order_option_on_the_device(engine, oracle, mode, monkeypatch):
     """sxg_poa_params::mode | SXG_ORDER_SPOA (decree S7': the depth-first re-sort after every AddAlignment that spoa is
-    believed to do; restated from memory, unverified): one lane per block walks the graph on the device (records built by all threads, states in LDS); scores,
+    believed to do; restated from memory, unverified): on the device a walk per root, every thread its own roots, and only the pieces of the order
+    the last alignment touched walked again (poa_graph_dev.h::spoa_resort_par; per-node words in LDS); scores,
     graphs, ranks, paths, consensus and MSA equal the oracle run with the same option, on blocks of several shapes
     (packed sweep, banded sweep, deep bubbles), and mixed with default-order blocks in one batch."""
     import smoothxg_amd as S

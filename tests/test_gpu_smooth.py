@@ -161,23 +161,25 @@ def test_drb1_abpoa_path_global_and_unbanded_local_on_gpu(engine):
     sm.close()
 
 
-def test_drb1_three_chained_iterations_as_the_reference_ctest_runs_them(engine):
+@pytest.mark.parametrize("spoa_order", [1, 0])
+def test_drb1_three_chained_iterations_as_the_reference_ctest_runs_them(engine, spoa_order):
     """The reference's own test configuration (CMakeLists.txt:565: -l 700,900,1100 -j 5k -e 5k -r 12) is THREE smoothing
     iterations, each on the graph the one before wrote (src/main.cpp:374-1065); consensus paths only in the last
     (src/main.cpp:404).  Every iteration: real block discovery on the previous GFA, one batched GPU POA call, lacing.
     After each one the 12 paths still spell their sequences and the path count is kept (src/main.cpp:770-810); the GFA
     of every iteration is byte-identical to the oracle stack's, pinned by size and SHA-256 in
-    tests/golden/drb1_chain.json (made by tests/golden/make_drb1_chain.py; the oracle chain takes minutes on a CPU)."""
+    tests/golden/drb1_chain.json (made by tests/golden/make_drb1_chain.py; the oracle chain takes minutes on a CPU) -- in spoa's node
+    order (poa_spoa_order = 1, the default since round 6: "iterations") and in the incrementally kept one ("iterations_s7")."""
     import hashlib
     import json
-    gold = json.load(open(os.path.join(HERE, "golden", "drb1_chain.json")))["iterations"]
+    gold = json.load(open(os.path.join(HERE, "golden", "drb1_chain.json")))["iterations" if spoa_order else "iterations_s7"]
     text = open(DRB1).read()
     g0 = SO.Graph(text)
     for it, tl in enumerate((700, 900, 1100)):
         last = it == 2
         sm = S.Smoother(text, discover=dict(target_poa_length=tl, n_haps=12, max_path_jump=5000, max_edge_jump=5000))
         assert sm.n_blocks == gold[it]["blocks"]
-        text = sm.smooth_gfa(S.default_params(add_consensus=1 if last else 0), S.gpu_provider(engine))
+        text = sm.smooth_gfa(S.default_params(add_consensus=1 if last else 0, poa_spoa_order=spoa_order), S.gpu_provider(engine))
         sm.close()
         assert len(text) == gold[it]["gfa_bytes"], f"iteration {it} (-l {tl})"
         assert hashlib.sha256(text.encode()).hexdigest() == gold[it]["sha256"], f"iteration {it} (-l {tl})"

@@ -160,8 +160,9 @@ def test_block_graph_phase_matches_the_restatement(emul, oracle, cons_mode):
 
 def test_spoa_order_option_matches_its_restatement(emul, oracle):
     """Decree S7' (sxg_poa_params::mode | SXG_ORDER_SPOA): the depth-first re-sort after every AddAlignment, restated from
-    memory of spoa's Graph::TopologicalSort (unverified: the library is absent) -- the product's one-lane walk
-    (poa_graph_dev.h::spoa_resort) against the oracle's (poa_oracle.c::spoa_resort): same ranks, hence same alignments,
+    memory of spoa's Graph::TopologicalSort (unverified: the library is absent) -- the product's re-sort
+    (poa_graph_dev.h::spoa_resort: round 6 -- one walk per root, only the pieces an alignment touched are walked again) against the
+    oracle's one sequential walk (poa_oracle.c::spoa_resort): same ranks, hence same alignments,
     graphs, paths, consensus.  Both give valid topological orders with contiguous aligned groups, and on divergent blocks
     the order DIFFERS from the incremental one (S7)."""
     rng = np.random.default_rng(77)
@@ -169,15 +170,15 @@ def test_spoa_order_option_matches_its_restatement(emul, oracle):
     for mode in (0, 1):
         p = oparams("convex_default", mode)
         p.mode = mode | 0x10
-        for trial in range(20):
+        for trial in range(40):
             S = int(rng.integers(2, 14))
             seqs = random_block(rng, S, int(rng.integers(5, 300)), div=0.09) if trial % 4 else \
                 [rng.integers(0, 5, int(rng.integers(1, 30)), dtype=np.uint8) for _ in range(S)]
             w = rng.integers(1, 4, len(seqs))
             g, sc, _ = oracle.block_run(seqs, w, p)
-            # (1: per-node states on the chip only while the graph is below 64 nodes, then in the slot's scratch; 2: always on the chip;
-            #  3: on the chip with room for four stack entries, the rest of the stack in the scratch)
-            st, r = run_emul(emul, seqs, w, p, spoa_order=1 + trial % 3)
+            # (1: per-node words on the chip only while the graph is below 16 nodes, then in the slot's scratch; 2: always on the chip,
+            #  the first sequence named as the static chain; 3: on the chip, no static chain; 4: as 2, every re-sort from scratch)
+            st, r = run_emul(emul, seqs, w, p, spoa_order=1 + trial % 4)
             assert st == 0
             code, rank, grp = g.nodes()
             t, h, ww = g.edges()
@@ -219,7 +220,7 @@ def test_traceback_plane_layout_is_a_bijection_and_matches_the_wide_stores(emul)
 def test_spoa_order_walk_on_bushy_graphs(emul, oracle):
     """The re-sort's record paths that pangenome-like blocks hardly reach: nodes with more than three in-edges (the record holds
     three tails, the walk then follows the list), aligned groups of four and five whose members' tails overflow the record's
-    eight (no one-visit finish), deep pushes (the stack beyond its on-chip entries).  40 short sequences over five letters, 12 %
+    eight (no one-visit finish), deep pushes; kept pieces against pieces walked again (mode 4 walks everything every time).  40 short sequences over five letters, 12 %
     substitutions, 3 % deletions."""
     rng = np.random.default_rng(4242)
     for trial in range(6):
@@ -238,6 +239,27 @@ def test_spoa_order_walk_on_bushy_graphs(emul, oracle):
         indeg = np.bincount(h, minlength=len(code))
         sizes = np.bincount(grp)
         assert indeg.max() > 3 and sizes.max() >= 4, (indeg.max(), sizes.max())
-        for cap_mode in (1, 2, 3):
+        for cap_mode in (1, 2, 3, 4):
             st, r = run_emul(emul, seqs, w, p, spoa_order=cap_mode)
             assert st == 0 and (r[1] == rank).all() and (r[7] == sc).all() and (r[3] == t).all() and (r[4] == h).all()
+
+
+def test_spoa_order_kept_pieces_on_blocks_with_a_structural_variant(emul, oracle):
+    """The re-sort keeps the pieces of the order an alignment did not touch (poa_graph_dev.h::spoa_resort_par) -- on the bench's own
+    block generator (1 % substitutions, indels, one shared 50-300 base structural variant carried by a quarter of the sequences:
+    a piece of a few hundred nodes that most alignments leave alone) the ranks equal the oracle's sequential walk, with kept
+    pieces (modes 1, 2) and with everything walked again (mode 4)."""
+    from smoothxg_amd import synth
+    for blk, (S, L) in enumerate(((24, 700), (16, 1200), (40, 420), (12, 2000))):
+        seqs = synth.make_block(1000 + blk, S, L)
+        w = np.ones(len(seqs), np.int64)
+        for mode in (0, 1):
+            p = oparams("convex_default", mode)
+            p.mode = mode | 0x10
+            g, sc, _ = oracle.block_run(seqs, w, p)
+            code, rank, grp = g.nodes()
+            t, h, ww = g.edges()
+            for cap_mode in (1, 2, 4):
+                st, r = run_emul(emul, seqs, w, p, spoa_order=cap_mode)
+                assert st == 0 and (r[1] == rank).all() and (r[7] == sc).all() and (r[3] == t).all() and (r[4] == h).all() and (r[5] == ww).all()
+                assert (r[8] == g.consensus()).all()
