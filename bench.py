@@ -199,7 +199,7 @@ def cpu_baseline(workload, mode, spoa_order=True):
                       % (n_blk, ns, threads, rounds, name, dt, cells, rate_one, cells / dt / threads, s_one, s_all, threads)}
 
 
-def end_to_end(eng, bases, seq_off, blk_off, prm, mode):
+def end_to_end(eng, bases, seq_off, blk_off, prm, mode, spoa_order=True):
     """One whole smoothing iteration through sxg_smooth_gfa (include/sxg_smooth.h) on the SAME blocks the kernel
     bench runs: host collection (A2-A4) -> upload -> POA kernels -> download -> block graphs (A9/A10) -> lacing ->
     validation -> unchop -> GFA text.  The input graph has one node per (block, sequence) and one path per
@@ -224,7 +224,7 @@ def end_to_end(eng, bases, seq_off, blk_off, prm, mode):
     sm = SM.Smoother(gfa, blocks=blocks)
     del gfa, lines, text
     p = SM.default_params(poa_m=prm[0], poa_n=-prm[1], poa_g=-prm[2], poa_e=-prm[3], poa_q=-prm[4], poa_c=-prm[5],
-                          local_alignment=1 if mode == 0 else 0, poa_padding_fraction=0.0)
+                          local_alignment=1 if mode == 0 else 0, poa_padding_fraction=0.0, poa_spoa_order=1 if spoa_order else 0)
     run, fre, ctx = SM.gpu_provider(eng)
     libc = C.CDLL("libc.so.6")
     libc.strlen.restype = C.c_size_t
@@ -400,17 +400,42 @@ def main():
                     help="N > 1: the hand-off of every step's results to rank 0 -- cabi: sxg_poa_batch_execute_sharded (the C ABI's own RCCL "
                          "communicator: counts all-gathered, one grouped ncclSend/ncclRecv per peer); torch: shard.RootGather "
                          "(torch.distributed batch_isend_irecv on zero-copy views of the results)")
+    ap.add_argument("--launch", action="store_true",
+                    help="start the ranks through torch.distributed.run even for --gpus 1 (what --gpus N > 1 does by itself when no launcher "
+                         "started this process): the one-rank job then runs the multi-rank path -- RCCL communicator on the engine handle, "
+                         "sxg_poa_batch_execute_sharded per step, `exchange` on the line")
     a = ap.parse_args()
 
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # --gpus N is a PROMISE about what the line measures (round 5 parsed it and never read it: `python bench.py --gpus 8` timed one
+    # GPU and said n_gpus 1).  Started without a launcher, N > 1 starts its own N ranks (one process per GPU, rendezvous on 127.0.0.1);
+    # started by one (the driver: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N), the world must be N.
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.launch):
+        n_dev = torch.cuda.device_count()
+        if a.gpus > n_dev:
+            raise SystemExit("bench.py --gpus %d: this box has %d GPU(s) visible -- refusing to time fewer GPUs than the line would claim" % (a.gpus, n_dev))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, SXG_BENCH_LAUNCHED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + [x for x in sys.argv[1:] if x != "--launch"]
+        sys.stdout.flush()
+        os.execvpe(cmd[0], cmd, env)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
+    if world != a.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: the line would not measure what it says (start it as "
+                         "python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d, or without a launcher)" % (a.gpus, world, a.gpus, a.gpus))
+    # multi: the multi-rank path (process group, communicator, sharded steps) -- also a ONE-rank job that came through the launcher
+    multi = world > 1 or os.environ.get("SXG_BENCH_LAUNCHED") == "1"
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if multi:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import smoothxg_amd as S
@@ -418,7 +443,7 @@ def main():
     from smoothxg_amd import shard
 
     if a.workload == "drb1":
-        if world > 1:
+        if multi:
             raise SystemExit("--workload drb1 is a single-GPU measurement (2000 small blocks per iteration)")
         return bench_drb1(a, local_rank)
     nb, ns, ln, prm, desc = WORKLOADS[a.workload]
@@ -431,7 +456,7 @@ def main():
     eng = S.PoaEngine(local_rank)
     # N > 1: the engine's own RCCL communicator (sxg_poa_comm_init): rank 0 draws the id, torch.distributed carries it
     exchange = "none"
-    if world > 1:
+    if multi:
         exchange = a.exchange
         if exchange == "cabi":
             os.environ.setdefault("SXG_POA_COMM_TIMEOUT_S", "180")
@@ -477,7 +502,7 @@ def main():
         if int(flag.item()) == 0:
             exchange = "torch (the C-ABI exchange failed in the probe step)"
             a.check = False
-    to_root = shard.RootGather() if world > 1 and exchange != "cabi" else None
+    to_root = shard.RootGather() if multi and exchange != "cabi" else None
 
     def step():
         if exchange == "cabi":
@@ -486,14 +511,14 @@ def main():
             eng.execute_sharded()
             return
         eng.execute()
-        if world > 1:
+        if multi:
             # the same hand-off through torch.distributed: device to device, one exact-size message per peer over its
             # own xGMI link; nothing is all-gathered
             to_root(shard.engine_result_tensors(eng))
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -511,7 +536,7 @@ def main():
         launches += st["dp_launches"]
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -542,6 +567,31 @@ def main():
             g, sc, _ = O.block_run(seqs, None, O.mkparams(*prm, mode=mode | (0x10 if spoa_order else 0), banded=BANDED_OF.get(a.workload, 0)))
             assert (res[b].scores == sc).all() and len(res[b].node_code) == g.n_nodes, "bench check failed"
 
+    # What rank 0 does with a step's exchange before it can lace: the blobs of all ranks reassembled in batch order
+    # (sxg_poa_batch_download_sharded).  Outside the timed region; only while the reassembled batch stays below ~12 GB of host memory.
+    root_ms, root_note = None, "not measured"
+    if multi and exchange == "cabi" and not strong:
+        root_note = "weak scaling: every rank brought its own blocks, there is no common batch to put back in order (--scaling strong measures it)"
+    elif multi and exchange == "cabi":
+        est_bytes = 5.0 * float(len(bases))
+        if est_bytes > 12e9 and not os.environ.get("SXG_BENCH_ROOT_DOWNLOAD"):
+            root_note = "skipped: ~%.0f GB of reassembled results on rank 0 (SXG_BENCH_ROOT_DOWNLOAD=1 forces it)" % (est_bytes / 1e9)
+        else:
+            try:
+                t_r = time.perf_counter()
+                rres = eng.download_sharded()
+                if rank == 0:
+                    root_ms = (time.perf_counter() - t_r) * 1e3
+                    root_note = "sxg_poa_batch_download_sharded of one step's results: %d blocks of %d ranks in batch order" % (len(rres), world)
+                del rres
+            except Exception as e:   # (a measurement beside the headline: never fails the line)
+                root_note = "failed: %s" % e
+    copy_gbps = None
+    if rank == 0:
+        try:
+            copy_gbps = eng.measure_copy(1 << 30, 5)
+        except Exception as e:   # (a figure beside the roofline: never fails the line)
+            print("[bench] copy bandwidth not measured: %s" % e, file=sys.stderr)
     if rank == 0:
         blocks_total = (nb if strong else nb * world) * a.steps
         value = blocks_total / dt
@@ -563,7 +613,10 @@ def main():
         simd_cycles_per_s = VALU_SIMDS * clock_ghz * 1e9
         traffic = valu_frac = valu_rate = None
         hbm = {"model": "SURVEY 8(d): 2*n_cross*sizeof(score)+1 bytes per cell", "algo_bytes_per_cell": algo_bytes / max(cells, 1),
-               "algo_GBps": algo_gbs, "algo_frac_of_peak": algo_gbs / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS}
+               "algo_GBps": algo_gbs, "algo_frac_of_peak": algo_gbs / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS,
+               # what a plain streaming copy reaches on THIS box (sxg_poa_measure_copy: 1 GiB read + 1 GiB written per launch, HIP events)
+               "copy_GBps_measured": copy_gbps,
+               "copy_what": "device-to-device streaming copy kernel of the engine (16 B per lane, non-temporal), bytes read + written / HIP-event time"}
         valu = {"simds": VALU_SIMDS, "clock_GHz": clock_ghz,
                 "clock_source": "measured in the launch (s_memtime cycles / s_memrealtime ticks)" if st.get("dom_clock_mhz", 0) > 0 else "nominal",
                 "issue_cycles_half_rate": VALU_CYCLES_HALF_RATE, "issue_cycles_full_rate": VALU_CYCLES_FULL_RATE,
@@ -598,11 +651,17 @@ def main():
         # max), pass 2 9 (max with E, Q and 0; E and Q updates of two adds + max), outgoing candidates 6, the wave scans
         # 40 per row / W columns -- against the wave instructions executed per cell (a packed wave instruction touches
         # 128 cells, so "instructions per cell" = wave instructions x 128 / cells, the unit of the counters above).
+        # Round 6: the floor follows the GAP MODEL of the score set (spoa's Create rule, poa_kernels.hip.h::normalise): an affine
+        # recurrence has no O / Q states -- pass 1 5.5 (look-up 1.5, diagonal add, max with F, one carry step), pass 2 5 (max with
+        # E and 0, E update), outgoing candidate 3, one wave scan of 20 per row / W --, a linear one (g = e) also folds its gap
+        # states into H + g: pass 2 4, outgoing candidate 1.  (Rounds 1-5 priced every model with the convex count.)
         if pc and st["dom_row_mode"] == 2:
             wl_w = max(st["dom_cols_per_lane"] // 2, 1)
-            min_ipc = 23.5 + 40.0 / wl_w
+            g_, e_, q_, c_ = prm[2], prm[3], prm[4], prm[5]
+            gap_model = "linear" if g_ >= e_ else ("affine" if (g_ <= q_ or e_ >= c_) else "convex")
+            min_ipc = {"convex": 23.5 + 40.0 / wl_w, "affine": 13.5 + 20.0 / wl_w, "linear": 10.5 + 20.0 / wl_w}[gap_model]
             exe_ipc = valu["wave_insts_per_cell"] * 128.0
-            valu.update({"min_insts_per_cell": min_ipc, "executed_insts_per_cell": exe_ipc,
+            valu.update({"gap_model": gap_model, "min_insts_per_cell": min_ipc, "executed_insts_per_cell": exe_ipc,
                          "algorithmic_frac": (min_ipc / exe_ipc) * valu_frac if exe_ipc else None,
                          "insts_per_cell_unit": "wave instructions x 128 cells / cells of the step"})
         valu_peak = simd_cycles_per_s
@@ -653,12 +712,15 @@ def main():
             # VALU instructions executed per second / SIMD cycles per second (1024 SIMDs x measured clock);
             # hbm.counter_* is what FETCH_SIZE/WRITE_SIZE measured.
             "roofline": roof,
-            "engine": {"slots": st["n_slots"], "retries": st["retries"], "arena_bytes": st["device_bytes"]},
+            "engine": {"slots": st["n_slots"], "retries": st["retries"], "arena_bytes": st["device_bytes"],
+                       "roctx_ranges": bool(eng.roctx_available())},
             "exchange": ({"path": "C ABI: sxg_poa_batch_execute_sharded (RCCL all-gather of sizes + grouped ncclSend/ncclRecv to rank 0)"
-                          if exchange == "cabi" else exchange, **(eng.sharded_info() if exchange == "cabi" else {})} if world > 1 else None),
+                          if exchange == "cabi" else exchange, **(eng.sharded_info() if exchange == "cabi" else {}),
+                          "rank0_reassembly_ms": root_ms, "rank0_reassembly_what": root_note,
+                          "launcher": "bench.py started its own ranks" if os.environ.get("SXG_BENCH_LAUNCHED") == "1" else "started by a launcher"} if multi else None),
         }
         if world == 1 and not a.no_e2e and a.workload in ("ns", "c2", "c2x8", "tiny"):
-            e_s, e_bytes, e_first = end_to_end(eng, bases, seq_off, blk_off, prm, mode)
+            e_s, e_bytes, e_first = end_to_end(eng, bases, seq_off, blk_off, prm, mode, spoa_order)
             out["end_to_end"] = {"what": "sxg_smooth_gfa on the same %d blocks: host collection + upload + POA kernels + "
                                          "download + block graphs + lacing + validation + unchop + GFA text (padding off)" % nb,
                                  "seconds": e_s, "first_call_seconds": e_first,
@@ -681,7 +743,7 @@ def main():
                                    "scalar_all_threads_cells_per_sec": cb["scalar_all_threads_cells_per_s"],
                                    "gpu_over_cpu": (total_cells / dt) / cb["cells_per_s"]}
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         # Every rank has printed / handed over what it had: give the communicators back explicitly and leave without the
         # libraries' own teardown -- a process that created an RCCL communicator through the C ABI can abort in it after main
         # has returned ("Observed with rccl 2.27.7"), which torchrun would report as a failed rank.

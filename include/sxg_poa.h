@@ -242,6 +242,13 @@ typedef struct sxg_poa_stats {
 } sxg_poa_stats;
 
 int sxg_poa_abi_version(void);
+/* Measurement aids (no counterpart in the reference; SURVEY sections 5 and 8d).
+ * _measure_copy: a streaming device-to-device copy of `bytes` bytes on this engine's device and stream, timed with HIP events over
+ *   `reps` launches: *gbps = (bytes read + bytes written) / time.  The figure bench.py prints beside the data sheet's HBM peak.
+ * _roctx_available: 1 when a ROCTx marker library was found -- _upload / _execute / _download and the pack / exchange halves of
+ *   _execute_sharded then run inside named ranges (rocprofv3 --marker-trace); 0: the ranges are no-ops. */
+int sxg_poa_measure_copy(sxg_poa_handle *h, uint64_t bytes, int reps, double *gbps);
+int sxg_poa_roctx_available(void);
 int sxg_poa_device_count(void);
 const char *sxg_poa_last_error(void);
 

@@ -931,7 +931,9 @@ enum : int { TBM_FLAG = 208, TBM_ROW = 209, TBM_DELTA = 210, TBM_RANGE = 211 /* 
 // strip's steps from its left end -- in the round-4 word format (H | H - oF | H - oO), so the walk itself is the same code.
 // j < 0 on entry: the sweep of a local alignment names the STRIP of the end cell, -(strip + 1); the column is the first
 // of that strip's cells in row i that holds the best score.
-template <bool PAIRS, int W, bool CVX, bool BANDED = false, int CB = 4>
+// STRICT: the caller admitted the alignment under the strict range rule (every cell above P16_NWFLOOR: nothing is ever clamped,
+// sxg_poa.hip::p16_safe without clamp_ok -- the align-only kernel, which has no wider re-run): the walk takes every cell at its word.
+template <bool PAIRS, int W, bool CVX, bool BANDED = false, int CB = 4, bool STRICT = false>
 // (views by value: a reference to the kernel's private copy trips an AMDGPU back-end assertion on
 // the private-aperture null check for some strip widths)
 __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, const Scoring S_, const uint8_t* seq, const int L_,
@@ -1024,7 +1026,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
     };
     // global alignment on the full matrix: cells at or below `thr` may be clamped ones (see P16_NWFLOOR); the walk must not
     // take a decision in one
-    const int thr = (!BANDED && !sw) ? P16_NWFLOOR + sm * L + sm : -0x40000000;
+    const int thr = (!BANDED && !STRICT && !sw) ? P16_NWFLOOR + sm * L + sm : -0x40000000;
     bool range = false;
     int wtop = -1, wj = 0;
     bool miss = false;

@@ -358,7 +358,8 @@ SXG_HD_PHASE int spoa_walk_root(const GraphView& G, WP W, const int s0, SXG_GP i
                           const SpoaHalf ra, const SpoaHalf rb) {
     SXG_GP const SpoaHalf* const rec = (SXG_GP const SpoaHalf*)G.dfs_rec;
     // state of node x as this walk sees it: finished by an earlier root = done (2); else its own bits (mark | ignored << 2)
-    auto stt = [&](const int x) -> int { const int w = (int)W[x]; return (w & SPOA_FMASK) < s0 ? 2 : (w >> 28) & 7; };
+    // (bit 3 of the state: the node has no aligned nodes to emit behind it -- what coming back to it needs to know)
+    auto stt = [&](const int x) -> int { const int w = (int)W[x]; return (w & SPOA_FMASK) < s0 ? 2 : (w >> 28) & 15; };
     auto set = [&](const int x, const int st) { W[x] = s0 | (st << 28); };   // (x belongs to this root: first(x) == s0)
     int w = 0, sp = 0;
     auto push = [&](const int x) { stk[sp++] = x; };
@@ -370,7 +371,21 @@ SXG_HD_PHASE int spoa_walk_root(const GraphView& G, WP W, const int s0, SXG_GP i
         bool valid = true;
         int last = curr;
         const int sc = at_root ? 0 : stt(curr);   // (a root is entered with state 0)
-        if ((sc & 3) != 2) {
+        if ((sc & 3) == 1) {
+            // Back on top of the stack: whatever this node pushed was popped above it, i.e. finished (a node is only popped when it
+            // is), and what it did not push was finished before -- it is valid without looking at its tails again (the sequential
+            // walk re-reads them and finds the same).  Only its aligned-node list has to be read again, when it has one.
+            set(curr, (sc & 4) | 2);
+            if (!(sc & 4)) {
+                ord[w++] = curr;
+                if (!(sc & 8)) {
+                    const SpoaHalf a = rec[4 * (size_t)curr], b = rec[4 * (size_t)curr + 1];
+                    const int na = (a.x >> 8) & 0xff;
+                    const int al[4] = {b.x, b.y, b.z, b.w};
+                    for (int q = 0; q < na; ++q) ord[w++] = al[q];
+                }
+            }
+        } else if ((sc & 3) != 2) {
             SpoaHalf a = ra, b = rb;
             if (!at_root) { a = rec[4 * (size_t)curr]; b = rec[4 * (size_t)curr + 1]; }
             const bool ign = (sc & 4) != 0;
@@ -411,7 +426,7 @@ SXG_HD_PHASE int spoa_walk_root(const GraphView& G, WP W, const int s0, SXG_GP i
                     ord[w++] = curr;
                     for (int q = 0; q < na; ++q) ord[w++] = al[q];
                 }
-            } else set(curr, (sc & 4) | 1);
+            } else set(curr, (sc & 4) | 1 | (na == 0 ? 8 : 0));
         }
         at_root = false;
         if (valid) { --sp; fresh = false; } else { curr = last; fresh = true; }
@@ -426,15 +441,33 @@ SXG_HD_PHASE int spoa_walk_root(const GraphView& G, WP W, const int s0, SXG_GP i
 #define SXG_RSP(k) ((void)0)
 #define SXG_RSP_DECL ((void)0)
 #endif
-// One record (see above) of node v, from the graph's lists.
+// One record (see above) of node v, from the graph's lists.  The loads are laid out in stages -- (first in-edge, group) ->
+// (its tail and successor, the group's members) -> (the other member's in-list) -> ... -- so that a record is four round trips,
+// not the ten of "own list, then the aligned-node list, then every aligned node's list"; groups of one and two (all but a
+// handful) take their aligned-node list from the members at hand.
 SXG_HD void spoa_build_record(const GraphView& G, const int v) {
-    int tl[3] = {-1, -1, -1}, ni = 0;
-    for (int e = G.in_head[v]; e >= 0; e = G.e_next_in[e]) { if (ni < 3) tl[ni] = G.e_tail[e]; ++ni; }
+    const int e0 = G.in_head[v], ld = G.leader[v];
+    int m[5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) m[x] = G.gmem[5 * ld + x];
+    int t0 = -1, e1 = -1;
+    if (e0 >= 0) { t0 = G.e_tail[e0]; e1 = G.e_next_in[e0]; }
+    int nm = 0, other = -1;
+#pragma unroll
+    for (int x = 0; x < 5; ++x) if (m[x] >= 0) { ++nm; if (m[x] != v) other = m[x]; }
     int al[5] = {-1, -1, -1, -1, -1};
-    const int na = spoa_aligned_list(G, v, al);
+    int na;
+    if (nm <= 2) { na = nm - 1; al[0] = nm == 2 ? other : -1; }
+    else na = spoa_aligned_list(G, v, al);
+    const int oe0 = na > 0 ? G.in_head[al[0]] : -1;
+    int tl[3] = {-1, -1, -1}, ni = 0;
+    if (e0 >= 0) {
+        tl[0] = t0; ni = 1;
+        for (int e = e1; e >= 0; e = G.e_next_in[e]) { if (ni < 3) tl[ni] = G.e_tail[e]; ++ni; }
+    }
     int mt[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, nmt = 0;
     for (int q = 0; q < na; ++q)
-        for (int e = G.in_head[al[q]]; e >= 0; e = G.e_next_in[e]) { if (nmt < 8) mt[nmt] = G.e_tail[e]; ++nmt; }
+        for (int e = q == 0 ? oe0 : G.in_head[al[q]]; e >= 0; e = G.e_next_in[e]) { if (nmt < 8) mt[nmt] = G.e_tail[e]; ++nmt; }
     SXG_GP int32_t* const r = G.dfs_rec + (size_t)SPOA_REC * v;
     r[0] = (ni < 255 ? ni : 255) | (na << 8) | ((nmt <= 8 ? nmt : 255) << 16);
     r[1] = tl[0]; r[2] = tl[1]; r[3] = tl[2];
@@ -495,6 +528,9 @@ SXG_HD void spoa_resort_par(Ctx& c, const GraphView& G, WP W, const int n, const
         }
         c.sync();
         const int nt = sdem[n + 1];
+        // (an alignment that added neither a node nor an edge -- a sequence some earlier one spelt -- leaves the order as it is:
+        //  AddAlignment's own bookkeeping moved nothing either)
+        if (nt == 0 && n == n_prev) return;
         for (int k = t; k < nt; k += T) spoa_build_record(G, list[k]);
     } else {
         for (int v = t; v < n; v += T) spoa_build_record(G, v);

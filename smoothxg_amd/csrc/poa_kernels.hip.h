@@ -421,11 +421,15 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_align_ke
                 else dp_fill<W, CVX, H16, SW>(S, V.R, N, A.bases + so, len, V.B, smem, A.park_in_lds != 0, A.pf_off, res);
                 __syncthreads();
                 if constexpr (RM == 2) {
-                    if (t == 0) lds[TBM_FLAG] = 0;
+                    if (t == 0) { lds[TBM_FLAG] = 0; lds[TBM_RANGE] = 0; }
                     __syncthreads();
-                    if (t < 64 && res.bi >= 0) npairs = traceback_p16<true, W, CVX>(V.R, V.B, S, A.bases + so, len, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj, nullptr, V.pair_row, V.pair_pos, smem);
+                    // (STRICT: these alignments were admitted under the strict range rule -- no cell is clamped, and there is no wider
+                    //  re-run behind this kernel: the walk must not stop at a legitimately low score; round 5 returned a truncated
+                    //  pair list with status OK for global alignments scoring below -16 000 + m L)
+                    if (t < 64 && res.bi >= 0) npairs = traceback_p16<true, W, CVX, false, 4, true>(V.R, V.B, S, A.bases + so, len, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj, nullptr, V.pair_row, V.pair_pos, smem);
                     __syncthreads();
                     if (lds[TBM_FLAG]) status = ST_BAND_MISS;  // (cannot happen: these arenas keep every strip)
+                    else if (lds[TBM_RANGE]) status = ST_RANGE_OVERFLOW;  // (cannot happen under STRICT)
                 } else if (t == 0 && res.bi >= 0) npairs = traceback<true>(V.R, V.B, T, W, S.sw, res.bi, res.bj, nullptr, V.pair_row, V.pair_pos);
                 if (t == 0 && res.bi >= 0 && status == ST_OK) {
                     score = res.best;

@@ -369,6 +369,73 @@ struct sxg_poa_handle {
     double sh_pack_ms = 0, sh_exchange_ms = 0;   // last sxg_poa_batch_execute_sharded: packing the blob; size all-gathers + blob exchange (waits for the slowest rank)
 };
 
+// ---------------------------------------------------------------------------------------
+// ROCTx ranges around the phases of the C ABI (the reference brackets its phases with timers on stderr;
+// here `rocprofv3 --marker-trace` shows upload / execute / pack / exchange / download next to the kernels).  The marker
+// library is looked up at first use -- rocprofiler-sdk's, then roctracer's -- and the ranges are no-ops without it: the
+// engine does not link against a profiler.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        if (getenv("SXG_POA_NO_ROCTX")) return;
+        void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+        pop = (int (*)())dlsym(lib, "roctxRangePop");
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+static Roctx& roctx() { static Roctx r; return r; }
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~RoctxRange() { if (on) roctx().pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+}  // namespace
+extern "C" int sxg_poa_roctx_available(void) { return roctx().push != nullptr ? 1 : 0; }
+
+// A streaming copy on this device, timed with HIP events on the engine's stream: what SURVEY 8(d) asks to be printed beside the
+// 8 TB/s of the data sheet (bench.py: roofline.hbm.copy_GBps_measured).  16 bytes per lane and step, grid-stride, non-temporal
+// both ways; bytes read + bytes written over the mean of `reps` launches after one warm-up.
+__global__ __launch_bounds__(256) void sxg_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, const size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+extern "C" int sxg_poa_measure_copy(sxg_poa_handle* h, uint64_t bytes, int reps, double* gbps) {
+    if (!h || !gbps) return fail(SXG_E_INVALID, "NULL argument");
+    *gbps = 0;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n16 = (size_t)std::max<uint64_t>(bytes, 1u << 20) / 16;
+    DevBuf a, b;
+    if (int rc = a.ensure(n16 * 16)) return rc;
+    if (int rc = b.ensure(n16 * 16)) return rc;
+    HIPCHK(hipMemsetAsync(a.p, 1, n16 * 16, h->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const int grid = std::max(h->num_cu, 1) * 16;
+    reps = std::max(reps, 1);
+    hipLaunchKernelGGL(sxg_copy_kernel, dim3((unsigned)grid), dim3(256), 0, h->stream, a.as<u32x4>(), b.as<u32x4>(), n16);
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(sxg_copy_kernel, dim3((unsigned)grid), dim3(256), 0, h->stream, a.as<u32x4>(), b.as<u32x4>(), n16);
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    a.release(); b.release();
+    if (ms > 0) *gbps = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;
+    return SXG_OK;
+}
+
 extern "C" int sxg_poa_abi_version(void) { return SXG_POA_ABI_VERSION; }
 extern "C" const char* sxg_poa_last_error(void) {
     if (!g_err.empty()) return g_err.c_str();
@@ -465,6 +532,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
     if (in->n_blocks < 0 || (in->n_blocks > 0 && (!in->blk_off || !in->seq_off || !in->params)))
         return fail(SXG_E_INVALID, "batch_in has NULL arrays");
     HIPCHK(hipSetDevice(h->device));
+    const RoctxRange range_("sxg_poa_batch_upload");
     HostLaps laps;
     h->have_batch = false; h->executed = false;
     const int nb = in->n_blocks;
@@ -886,6 +954,7 @@ extern "C" int sxg_poa_batch_execute(sxg_poa_handle* h) {
     if (!h) return fail(SXG_E_INVALID, "handle is NULL");
     if (!h->have_batch) return fail(SXG_E_INVALID, "no batch uploaded");
     HIPCHK(hipSetDevice(h->device));
+    const RoctxRange range_("sxg_poa_batch_execute");
     h->stats = sxg_poa_stats{};
     const bool dbg = getenv("SXG_POA_DEBUG") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
@@ -1219,6 +1288,7 @@ extern "C" int sxg_poa_batch_download(sxg_poa_handle* h, sxg_poa_batch_out* out)
     memset(out, 0, sizeof(*out));
     if (!h->have_batch || !h->executed) return fail(SXG_E_INVALID, "no executed batch to download");
     HIPCHK(hipSetDevice(h->device));
+    const RoctxRange range_("sxg_poa_batch_download");
     HostLaps laps;
     const int nb = h->n_blocks;
     const int64_t ns = h->n_seqs;
@@ -1946,8 +2016,9 @@ extern "C" int sxg_poa_batch_execute_sharded(sxg_poa_handle* h) {
     int64_t* mine = counts.data() + (size_t)rank * BC_N;
     int rc = h->have_batch ? sxg_poa_batch_execute(h) : fail(SXG_E_INVALID, "no batch uploaded");
     const auto t_pack = std::chrono::steady_clock::now();
-    if (!rc || rc == SXG_E_BLOCK) rc = pack_blob(h, mine);   // (per-block failures travel in the status array)
+    { const RoctxRange range_("sxg_poa sharded: pack"); if (!rc || rc == SXG_E_BLOCK) rc = pack_blob(h, mine); }   // (per-block failures travel in the status array)
     const auto t_xch = std::chrono::steady_clock::now();
+    const RoctxRange range_("sxg_poa sharded: exchange");
     h->sh_pack_ms = std::chrono::duration<double, std::milli>(t_xch - t_pack).count();
     h->sh_exchange_ms = 0;
     if (!h->comm) {

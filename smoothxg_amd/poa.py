@@ -83,7 +83,7 @@ EXPORTS = ["sxg_poa_batch_device_view", "sxg_poa_abi_version", "sxg_poa_device_c
            "sxg_poa_get_stats", "sxg_poa_set_memory_budget", "sxg_xxh64", "sxg_poa_comm_unique_id", "sxg_poa_comm_init",
            "sxg_poa_comm_attach", "sxg_poa_comm_destroy", "sxg_poa_batch_run_sharded", "sxg_poa_batch_run_sharded_local",
            "sxg_poa_batch_upload_sharded", "sxg_poa_batch_execute_sharded", "sxg_poa_batch_download_sharded", "sxg_poa_sharded_info",
-           "sxg_poa_sharded_timing"]
+           "sxg_poa_sharded_timing", "sxg_poa_measure_copy", "sxg_poa_roctx_available"]
 COMM_ID_BYTES = 128
 NOT_ROOT = 1
 
@@ -115,6 +115,7 @@ def load_library(build_if_missing=True):
     L.sxg_poa_align_free.argtypes = [C.POINTER(AlignOut)]
     L.sxg_poa_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sxg_poa_set_memory_budget.argtypes = [vp, C.c_uint64]
+    L.sxg_poa_measure_copy.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.sxg_poa_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.sxg_poa_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
     L.sxg_poa_comm_attach.argtypes = [vp, vp, C.c_int, C.c_int]
@@ -404,6 +405,16 @@ class PoaEngine:
             return self._unpack(out)
         finally:
             self.lib.sxg_poa_batch_free(C.byref(out))
+
+    def measure_copy(self, nbytes=1 << 30, reps=5):
+        """GB/s (read + written) of a streaming device-to-device copy on this engine's device (sxg_poa_measure_copy)."""
+        g = C.c_double()
+        if self.lib.sxg_poa_measure_copy(self.h, C.c_uint64(int(nbytes)), int(reps), C.byref(g)):
+            raise self._err("sxg_poa_measure_copy")
+        return g.value
+
+    def roctx_available(self):
+        return int(self.lib.sxg_poa_roctx_available())
 
     def sharded_info(self):
         n, b = C.c_int32(), C.c_uint64()

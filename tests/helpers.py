@@ -143,5 +143,11 @@ def rerun_in_own_process(request):
     node = "%s::%s" % (str(request.node.fspath), request.node.name)
     r = subprocess.run([sys.executable, "-m", "pytest", node, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root,
                        env=dict(os.environ, SXG_TEST_OWN_PROCESS="1"), capture_output=True, text=True, timeout=1200)
+    if "1 skipped" in r.stdout and "passed" not in r.stdout:   # (no GPU / no RCCL in the child's environment: say so, do not fail)
+        import pytest
+        pytest.skip("the test skipped in its own process: " + r.stdout[-400:])
+    # the child's return code counts: 0, or 134 (SIGABRT in rccl's teardown AFTER pytest printed its summary -- the reason this
+    # helper exists); any other abort or crash behind the summary line is a failure
+    assert r.returncode in (0, 134, -6), "child exited with %d\n" % r.returncode + r.stdout[-4000:] + r.stderr[-4000:]
     assert "1 passed" in r.stdout and "failed" not in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
     return True

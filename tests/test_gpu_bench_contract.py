@@ -58,6 +58,11 @@ def test_headline_line_takes_the_valu_roof_from_the_committed_counters():
     if v["counters_match_build"]:
         assert r["traffic"] and r["traffic"] > 0
     assert r["hbm"]["algo_bytes_per_cell"] == 13.0
+    # round 6: the copy bandwidth of THIS box beside the data sheet's peak, the gap model's own instruction floor,
+    # and whether the ABI's phases run inside ROCTx ranges
+    assert 1000.0 < r["hbm"]["copy_GBps_measured"] < r["hbm"]["peak_GBps"], r["hbm"]["copy_GBps_measured"]
+    assert v["gap_model"] == "convex" and 23.5 + 40.0 / 13 <= v["min_insts_per_cell"] <= 23.5 + 40.0 / 4
+    assert d["engine"]["roctx_ranges"] in (True, False)
     assert d["dtype"] == "int16" and d["config"]["blocks_per_gpu"] == 1000
     # the line certifies itself: blocks 0 and 999 of the timed batch against the committed oracle output
     assert d["verified"] is True and d["verified_blocks"] == [0, 999]
@@ -112,3 +117,34 @@ def test_the_banded_workloads_verify_themselves():
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         # (48 of the 5000 blocks here: block 0 is in the batch, block 4999 only in the full run)
         assert d["verified"] is True and d["verified_blocks"] == [0] and d["config"]["order"].startswith("incremental"), (wl, d["verified_what"])
+
+
+def test_gpus_flag_refuses_to_time_fewer_gpus_than_it_claims():
+    """Round 6: `python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run on 127.0.0.1) -- and on a
+    box with fewer GPUs it says so and stops, instead of timing one GPU under `n_gpus: 1` (what round 5 did: --gpus was never
+    read).  Started by a launcher with another world size it stops as well."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_dev + 1), "--workload", "tiny", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "refusing to time fewer GPUs" in out.stderr, out.stderr[-1500:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr, out.stderr[-1500:]
+
+
+def test_one_rank_through_the_launcher_runs_the_multi_rank_path():
+    """`--gpus 1 --launch`: bench.py starts its one rank through torch.distributed.run, the rank puts a (one-rank) RCCL communicator
+    on the engine handle and every step is sxg_poa_batch_execute_sharded -- size all-gather, grouped send/recv (empty), rank-0
+    bookkeeping: the path an N-GPU job takes, as far as one GPU can walk it.  The line says who it saw."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch", "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["verified"] is None or d["verified"] is True
+    ex = d["exchange"]
+    assert ex is not None and ex["path"].startswith("C ABI") and ex["ranks_seen"] == 1 and ex["launcher"].startswith("bench.py started"), ex
+    assert ex["pack_ms"] >= 0 and ex["exchange_ms"] >= 0 and "bytes_received" in ex

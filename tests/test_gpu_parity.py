@@ -40,6 +40,31 @@ def test_align_only_matches_oracle(engine, oracle, mode, pname):
         assert (pr == an).all() and (pp == ap).all(), f"problem {k}: alignment differs"
 
 
+def test_align_only_global_alignment_with_a_strongly_negative_score(engine, oracle):
+    """the align-only kernel admits packed global alignments under the strict range rule (all-gap corner above
+    -15 800) and has no wider re-run; the packed walk's clamp threshold (-16 000 + m L + m, made for whole blocks that CAN be re-run)
+    must not stop it at a legitimately low score.  Two homopolymers of different letters (3 900 / 3 000 letters), linear gaps of 2,
+    mismatch 10: the optimum is all gaps (-15 526 / -11 926, below the thresholds -12 099 / -12 999 from the first cell on or soon
+    after) -- pairs and score equal the oracle's."""
+    import smoothxg_amd as S
+    rng = np.random.default_rng(4711)
+    problems, expect = [], []
+    for L in (3900, 3000):
+        a, b = np.zeros(L, np.uint8), np.ones(L - 37, np.uint8)
+        b[::97] = rng.integers(0, 4, len(b[::97]), dtype=np.uint8)   # (a few chance matches, so that the walk has decisions to take)
+        p = oracle.mkparams(1, -10, -2, -2, -2, -2, mode=1)
+        g, _, _ = oracle.block_run([a], None, p)
+        codes, off, pred, sink, _ = g.rows()
+        an, ap, sc = oracle.align_csr(codes, off, pred, sink, b, p)
+        assert sc < -11000, sc              # (a walk through cells at and below the threshold)
+        problems.append((codes, off, pred, sink, b))
+        expect.append((an, ap, sc))
+    got = engine.align(problems, S.Params(1, -10, -2, -2, -2, -2, 1, 0))
+    for k, ((pr, pp, sc, st), (an, ap, esc)) in enumerate(zip(got, expect)):
+        assert st == 0 and sc == esc, (k, st, sc, esc)
+        assert len(pr) == len(an) and (pr == an).all() and (pp == ap).all(), f"problem {k}: alignment differs"
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("pname", list(PARAM_SETS))
 def test_blocks_match_oracle_small(engine, oracle, mode, pname):
