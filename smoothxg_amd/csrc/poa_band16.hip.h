@@ -363,7 +363,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             rowmax = pk_max(rowmax, h);
             E = pk_max(pk_add(h, G2), pk_add(E, E2));
             if (CVX) Q = pk_max(pk_add(h, Q2), pk_add(Q, C2));
-            SXG_PIN("+v"(Hc[k]), "+v"(E), "+v"(Q), "+v"(rowmax));
+            if constexpr (W >= 11) SXG_PIN("+v"(Hc[k]), "+v"(E), "+v"(Q), "+v"(rowmax));   // (round 6: no pin below W = 11, see dp_fill_p16's pass 2)
         }
         // the column left of my strips in THIS row (the next row's diagonal): my left neighbour's last column, the
         // lo half's last lane feeds lane 0's hi strip; a strip outside the band hands over -inf
@@ -468,12 +468,12 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
 // whose records overwrite the hints.)
 #define BAND_STORE(CF, CO)                                                                                  \
     do {                                                                                                    \
-        if (in_lo)                                                                                          \
-            plane_store_strip<W>(rs_plane, so_lo, BS, [&](const int k) -> unsigned {                        \
+        /* (round 6: a strip outside the band goes to a slot beyond the row's descriptor -- dropped by the hardware -- instead of \
+            a lane-divergent branch around the stores: see P16_SLOT_OOB in poa_dp16.hip.h) */                  \
+            plane_store_strip<W>(rs_plane, in_lo ? so_lo : P16_SLOT_OOB, BS, [&](const int k) -> unsigned { \
                 const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                           \
                 return __builtin_amdgcn_perm(w.y, w.x, 0x05040100u); });                                    \
-        if (in_hi)                                                                                          \
-            plane_store_strip<W>(rs_plane, so_hi, BS, [&](const int k) -> unsigned {                        \
+            plane_store_strip<W>(rs_plane, in_hi ? so_hi : P16_SLOT_OOB, BS, [&](const int k) -> unsigned { \
                 const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                           \
                 return __builtin_amdgcn_perm(w.y, w.x, 0x07060302u); });                                    \
     } while (0)

@@ -162,6 +162,8 @@ __device__ __forceinline__ unsigned plane_cell_byte(const int BS, const unsigned
 #ifndef SXG_PLANE_AUX
 #define SXG_PLANE_AUX 2
 #endif
+// a slot no row has: slot * (bytes of a group) lies beyond every row's buffer descriptor and stays below 2^32 (see P16_STORES)
+#define P16_SLOT_OOB 0x04000000u
 // one strip of a row: cell(k) -> the dword of column k; rs = the row's descriptor
 template <int W, int GI, class F>
 __device__ __forceinline__ void plane_store_group(const __amdgpu_buffer_rsrc_t rs, const unsigned slot, const int BS, F& cell) {
@@ -718,7 +720,11 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             rowmax = pk_max(rowmax, h);
             E = pk_max(P16_DEC(h, Gm, G2), P16_DEC(E, Em, E2));
             if (CVX) Q = pk_max(P16_DEC(h, Qm, Q2), P16_DEC(Q, Cm, C2));
-            SXG_PIN("+v"(Hc[k]), "+v"(E), "+v"(Q), "+v"(rowmax));
+            // (round 6: no register pin behind a column below W = 12.  The empty asm made the hazard recogniser pad every column
+            //  with three s_nop and kept the compiler from reusing h + g and h + q -- computed here for E and Q -- as the opening
+            //  halves of the row's outgoing candidates: 15 + 21 VALU instructions and 18 s_nop per row of the W = 11 headline
+            //  class, 124 VGPRs instead of 120, no scratch.  The 16-wave classes W = 12, 13 spill without it.)
+            if constexpr (W >= 12) SXG_PIN("+v"(Hc[k]), "+v"(E), "+v"(Q), "+v"(rowmax));
         }
         // hand my last column to the right neighbour: inside the wave by a lane shift (lane 0's hi strip begins where lane
         // 63's lo strip ends; the column left of its lo strip came in through the mailbox); lane 63's hi strip is the wave's
@@ -778,6 +784,9 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         // whose step is then 0
         int lhs = lh;
         if (CB == 2 && t == 0) lhs = (int)(((unsigned)lh & 0xffff0000u) | ((unsigned)Hc[0] & 0x0000ffffu));
+// (round 6) a lane whose strip lies outside the row's band stores to a slot beyond the row's buffer descriptor -- the hardware
+// drops the access -- instead of sitting out a lane-divergent branch around the stores: the structurised branch made the
+// compiler keep two sets of the 2 W gap-state registers and copy between them on every row (22 to 66 v_mov per row).
 // ring row + band cells of this row; CF(k) / CO(k) = the row's outgoing candidates of column k
 #define P16_STORES(CF, CO)                                                                                  \
     do {                                                                                                    \
@@ -805,23 +814,21 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
                     prev_ = h_;                                                                             \
                 }                                                                                           \
                 /* dword x of a strip: halfwords 2x, 2x + 1 of (left H, code 0, ..., code W-1) */            \
-                if (band_lo && in_lo)                                                                       \
-                    plane_store_strip<SD>(rs_plane, sl_lo, BS, [&](const int x) -> unsigned {               \
+                if (band_lo)                                                                                \
+                    plane_store_strip<SD>(rs_plane, in_lo ? sl_lo : P16_SLOT_OOB, BS, [&](const int x) -> unsigned { \
                         return __builtin_amdgcn_perm((unsigned)(2 * x < W ? code_[2 * x < W ? 2 * x : 0] : 0), (unsigned)(x ? code_[x ? 2 * x - 1 : 0] : lhs), 0x05040100u); }); \
-                if (band_hi && in_hi)                                                                       \
-                    plane_store_strip<SD>(rs_plane, sl_hi, BS, [&](const int x) -> unsigned {               \
+                if (band_hi)                                                                                \
+                    plane_store_strip<SD>(rs_plane, in_hi ? sl_hi : P16_SLOT_OOB, BS, [&](const int x) -> unsigned { \
                         return __builtin_amdgcn_perm((unsigned)(2 * x < W ? code_[2 * x < W ? 2 * x : 0] : 0), (unsigned)(x ? code_[x ? 2 * x - 1 : 0] : lhs), 0x07060302u); }); \
             }                                                                                               \
         } else {                                                                                            \
         if (band_lo) {                                                                                      \
-            if (in_lo)                                                                                      \
-                plane_store_strip<W>(rs_plane, sl_lo, BS, [&](const int k) -> unsigned {                    \
+                plane_store_strip<W>(rs_plane, in_lo ? sl_lo : P16_SLOT_OOB, BS, [&](const int k) -> unsigned { \
                     const u32x2 w = p16_pack_row<CVX, SW>(Hc[k], CF, CO);                                   \
                     return __builtin_amdgcn_perm(w.y, w.x, 0x05040100u); });                                \
         }                                                                                                   \
         if (band_hi) {                                                                                      \
-            if (in_hi)                                                                                      \
-                plane_store_strip<W>(rs_plane, sl_hi, BS, [&](const int k) -> unsigned {                    \
+                plane_store_strip<W>(rs_plane, in_hi ? sl_hi : P16_SLOT_OOB, BS, [&](const int k) -> unsigned { \
                     const u32x2 w = p16_pack_row<CVX, SW>(Hc[k], CF, CO);                                   \
                     return __builtin_amdgcn_perm(w.y, w.x, 0x07060302u); });                                \
         }                                                                                                   \

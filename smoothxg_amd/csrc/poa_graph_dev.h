@@ -117,9 +117,12 @@ SXG_HD int group_end(const GraphView& G, int leader, int n_old) {
 // S6 + S7.  G.posnode[0..len) holds the aligned node id of every sequence position or -1.
 // path_out[0..len) receives the node id of every base (replaces spoa's per-edge labels /
 // Node::Successor walk used at src/smooth.cpp:2604-2610).
+// keep_order = false (round 6): the caller re-sorts the graph right behind this call (decree S7', spoa_resort below, which
+// neither reads nor keeps the incrementally kept order): the slots of the new nodes, the shift of the old ones and the copy of
+// the order -- the gathers through the groups' ranks and two passes over all nodes -- are left out.
 template <class Ctx>
 SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G_, const uint8_t* seq_, int len,
-                          uint32_t weight, int32_t* path_out_) {
+                          uint32_t weight, int32_t* path_out_, const bool keep_order = true) {
     const GraphView G = sxg_scalar_view(G_);   // (pointers through the scalar unit once: see poa_types.h)
     SXG_GP const uint8_t* const seq = sxg_scalar_ptr((SXG_GP const uint8_t*)seq_);   // both live in HBM
     SXG_GP int32_t* const path_out = sxg_scalar_ptr((SXG_GP int32_t*)path_out_);
@@ -153,7 +156,7 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G_, const uint8_t* seq_
     const int n_new = array_excl_sum(c, len, [&](int i) { return G.kind[i] != 0 ? 1 : 0; }, G.newidx);
     array_incl_max(c, len, [&](int i) { return G.kind[i] != 2 ? i : -1; }, G.preva);
     array_suffix_min(c, len, [&](int i) { return G.kind[i] != 2 ? i : BIG; }, G.nexta);
-    for (int r = t; r <= n_old; r += T) G.slotadd[r] = 0;
+    if (keep_order) for (int r = t; r <= n_old; r += T) G.slotadd[r] = 0;
     c.sync();
     // P2: create the new nodes, hand out slots (S7) and final ranks of the new nodes
     for (int i = t; i < len; i += T) {
@@ -166,12 +169,12 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G_, const uint8_t* seq_
         G.in_head[v] = G.in_tail[v] = G.out_head[v] = G.out_tail[v] = -1;
         G.in_deg[v] = G.out_deg[v] = 0;
         for (int x = 0; x < 5; ++x) G.gmem[5 * v + x] = -1;
-        int slot;
+        int slot = 0;
         G.via[v] = kind == 1 ? G.posnode[i] : -1;
         if (kind == 1) {
             const int ld = G.leader[G.posnode[i]];
             G.leader[v] = ld;
-            slot = group_end(G, ld, n_old) + 1;
+            if (keep_order) slot = group_end(G, ld, n_old) + 1;
             G.xpos[v] = G.xpos[G.posnode[i]];
         } else {
             G.leader[v] = v;
@@ -179,7 +182,8 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G_, const uint8_t* seq_
             const int s = G.nexta[i], p = G.preva[i];
             // band hint: continue the backbone coordinate of the nearest aligned neighbour
             G.xpos[v] = p >= 0 ? G.xpos[G.posnode[p]] + (i - p) : (s < len ? G.xpos[G.posnode[s]] - (s - i) : i + 1);
-            if (s < len) {
+            if (!keep_order) slot = 0;
+            else if (s < len) {
                 const int anchor = G.kind[s] == 0 ? G.target[s] : G.posnode[s];
                 slot = group_start(G, G.leader[anchor], n_old);
             } else if (p >= 0) {
@@ -188,9 +192,11 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G_, const uint8_t* seq_
             } else slot = n_old;
         }
         path_out[i] = v;
-        G.rank[v] = slot + k;
-        G.order_tmp[slot + k] = v;
-        c.atomic_add(&G.slotadd[slot], 1);
+        if (keep_order) {
+            G.rank[v] = slot + k;
+            G.order_tmp[slot + k] = v;
+            c.atomic_add(&G.slotadd[slot], 1);
+        }
     }
     c.sync();
     for (int i = t; i < len; i += T) {
@@ -200,6 +206,7 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G_, const uint8_t* seq_
         G.target[i] = v;
     }
     // P3: shift the old nodes.  preva is free again: reuse as exclusive slot counts.
+    if (keep_order) {
     array_excl_sum(c, n_old, [&](int r) { return G.slotadd[r]; }, G.preva);
     c.sync();
     for (int r0 = t; r0 < n_old; r0 += GB * T) {
@@ -224,6 +231,7 @@ SXG_HD_PHASE void add_alignment(Ctx& c, const GraphView& G_, const uint8_t* seq_
         for (int u = 0; u < GB; ++u) v[u] = r0 + u * T < n_old + n_new ? G.order_tmp[r0 + u * T] : 0;
 #pragma unroll
         for (int u = 0; u < GB; ++u) if (r0 + u * T < n_old + n_new) G.order[r0 + u * T] = v[u];
+    }
     }
     // P4: edges between consecutive path nodes, weight += 2*w (S6)
     for (int i0 = t; i0 < len; i0 += GB * T) {

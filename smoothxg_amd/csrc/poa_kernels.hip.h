@@ -306,10 +306,12 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
             }
             if (t == 0) { A.score[s] = score; if (RM != 3 || N == 0 || len == 0) A.cells[s] = RM == 3 ? 0ull : (unsigned long long)N * (unsigned long long)len; }
             done_cells += (unsigned long long)N * (unsigned long long)len;
-            if (TMAX == 64 || (TMAX <= 128 && T <= 64)) { WgCtxT<16> c16{ctx.lds}; add_alignment(c16, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
-            else if (TMAX == 128) { WgCtxT<8> c8{ctx.lds}; add_alignment(c8, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so); }
-            else add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so);
-            if (A.params[A.per_block_params ? b : 0].mode & SXG_ORDER_SPOA) {   // S7': spoa's depth-first re-sort (every thread walks its roots: poa_graph_dev.h)
+            // (spoa's order: the re-sort below rebuilds order and ranks; AddAlignment leaves its own bookkeeping of them out)
+            const bool spoa_order = (A.params[A.per_block_params ? b : 0].mode & SXG_ORDER_SPOA) != 0;
+            if (TMAX == 64 || (TMAX <= 128 && T <= 64)) { WgCtxT<16> c16{ctx.lds}; add_alignment(c16, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so, !spoa_order); }
+            else if (TMAX == 128) { WgCtxT<8> c8{ctx.lds}; add_alignment(c8, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so, !spoa_order); }
+            else add_alignment(ctx, V.G, seq, len, A.weights ? A.weights[s] : 1u, A.paths + so, !spoa_order);
+            if (spoa_order) {   // S7': spoa's depth-first re-sort (every thread walks its roots: poa_graph_dev.h)
                 typedef __attribute__((address_space(3))) uint8_t lds_u8;
                 // (N nodes before this alignment; the block's first re-sort builds everything, the later ones what the alignment touched)
                 spoa_resort(ctx, V.G, (lds_u8*)(size_t)((unsigned)__builtin_amdgcn_groupstaticsize() + (unsigned)LDS_CTL_BYTES), A.lds_bytes - LDS_CTL_BYTES,

@@ -73,7 +73,7 @@ extern "C" int emul_block_run(const uint8_t* bases, const int32_t* seq_off, int 
         }
         if (scores) scores[s] = sc;
         const int n_before = hdr[0];
-        add_alignment(c, G, seq, len, weights ? weights[s] : 1u, paths + seq_off[s]);
+        add_alignment(c, G, seq, len, weights ? weights[s] : 1u, paths + seq_off[s], spoa_order == 0 || spoa_order == 3);   // (3: the kept order maintained as well)
         // S7' (2: the per-node words in the "LDS" copy whatever the graph's size, and the first sequence named as the static chain;
         //      3: in the "LDS" copy, no static chain; 1: only graphs below 16 nodes on the chip, the others in the slot's scratch)
         //      4: as 2, but every re-sort builds everything (nothing kept from the previous one)
