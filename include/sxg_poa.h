@@ -27,12 +27,13 @@
  * checked against independent implementations; node ids, topological ranks, tie-breaks between equally good
  * alignments, the consensus and the MSA column order follow the tie rules written down in oracle/poa_oracle.c
  * (S1-S8, B1-B4), NOT necessarily spoa's / abPOA's: both are absent from the reference snapshot, so their
- * choices could not be pinned ("PARITY UNPINNED").  One divergence is KNOWN: after every
- * AddAlignment spoa re-sorts the whole graph depth-first (node-id order, in-edge tails first, aligned siblings
- * together), this engine keeps the order incrementally (decree S7: new nodes are slotted next to their aligned
- * group) -- any such order is a legal POA order, but it decides ties between equally good alignments, the end cell of
- * a local alignment and the MSA column order.  Graphs are valid POA graphs of the same sequences either way -- every
- * path spells its sequence -- but need not be byte-identical to the reference's.
+ * choices could not be pinned ("PARITY UNPINNED").  One divergence is KNOWN and is a switch: after
+ * every AddAlignment spoa re-sorts the whole graph depth-first (node-id order, in-edge tails first, aligned siblings
+ * together); with mode | SXG_ORDER_SPOA (what libsxgsmooth.so and bench.py ask for by default since round 6) the engine
+ * does the same, as recollected; without it the order is kept incrementally (decree S7: new nodes are slotted next to
+ * their aligned group).  Any such order is a legal POA order, but it decides ties between equally good alignments, the
+ * end cell of a local alignment and the MSA column order.  Graphs are valid POA graphs of the same sequences either way --
+ * every path spells its sequence -- but need not be byte-identical to the reference's.
  */
 #ifndef SXG_POA_H
 #define SXG_POA_H
@@ -57,8 +58,9 @@ extern "C" {
 /* OR-ed into sxg_poa_params::mode: after every AddAlignment the block's graph is re-sorted depth-first the way spoa's
  * Graph::TopologicalSort is BELIEVED to do it (node-id order, in-edge tails first, aligned nodes together; restated from
  * memory -- the library is absent from the reference snapshot -- as decree S7' of oracle/poa_oracle.c) instead of being kept
- * in order incrementally (decree S7, the default).  Both are valid POA orders; they differ in how ties between equally good
- * alignments fall.  One lane per block walks the graph: measured cost in DESIGN.md section 5. */
+ * in order incrementally (decree S7).  Both are valid POA orders; they differ in how ties between equally good alignments
+ * fall.  Round 6: every thread of the block's workgroup walks its own roots and only the pieces of the order the last alignment
+ * touched are walked again -- 1.02-1.05 x the kernel time; the host library sets the flag by default. */
 #define SXG_ORDER_SPOA 0x10
 
 /* return codes */

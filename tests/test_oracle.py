@@ -263,12 +263,14 @@ def test_fullshape_fixture_is_reproducible_on_its_small_cases(oracle):
     with open(os.path.join(here, "golden", "fullshape_oracle.json")) as f:
         cases = json.load(f)["cases"]
     names = {c["name"] for c in cases}
-    assert {"ns_sw", "ns_nw", "c3", "c2", "c4_max", "c4_min"} <= names
+    assert {"ns_sw", "ns_nw", "c3", "c2", "c4_max", "c4_min", "c3a", "c3b"} <= names
+    assert {c["name"] for c in cases if c.get("order") == "spoa"} >= {"ns_sw", "ns_nw", "ns_nw_affine", "c3", "c2", "c4_min"}
     for c in cases:
         assert len(c["scores"]) == c["n_seqs"] and len(c["seq_lens"]) == c["n_seqs"]
         if c["name"] not in ("c2", "c4_min"):
             continue
-        again = MF.run_case((c["name"], c["block_id"], c["n_seqs"], c["length"], tuple(c["params"]), c["mode"]))
+        # (round 6: a case also names its node order -- "spoa" = decree S7', "s7" = the incrementally kept one -- and its band mode)
+        again = MF.run_case((c["name"], c["block_id"], c["n_seqs"], c["length"], tuple(c["params"]), c["mode"], c.get("order", "s7"), c.get("banded", 0)))
         for k in ("scores", "cells", "n_nodes", "n_edges", "digests", "seq_lens"):
             assert again[k] == c[k], (c["name"], k)
 
