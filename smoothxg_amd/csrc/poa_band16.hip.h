@@ -260,18 +260,12 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
                                                  (unsigned)(LDS_CTL_BYTES + MB) + (unsigned)(tp_ * W) * 8u)
 
         int Hc[W];
-        const bool sib = next_sib && regs_ok;
+        // (no sibling rule since round 6 -- see dp_fill_p16: a row whose predecessor is the previous row's predecessor fetches and
+        //  unpacks that row like any other; next_sib only feeds the band look-ahead below)
         if (np <= 1 && p0 == i - 1 && regs_ok) {
             // register predecessor: its outgoing candidates ARE this row's F and O
 #pragma unroll
             for (int k = 0; k < W; ++k) Hc[k] = k ? Hp[k - 1] : Hleft;
-        } else if (sib) {
-            u32x2 wr[W];
-            int hl;
-            BAND_FETCH(p0, hp0, wr, hl);
-            Hc[0] = hl;
-#pragma unroll
-            for (int k = 1; k < W; ++k) Hc[k] = (int)wr[k - 1].x;
         } else {
             // general case: maxima over all predecessors; the register row (if it lines up) is folded from LDS
             BAND_LROW(lrow_t);
@@ -477,17 +471,13 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
                 const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                           \
                 return __builtin_amdgcn_perm(w.y, w.x, 0x07060302u); });                                    \
     } while (0)
-        if (!next_sib) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) {
-                Fp[k] = pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2));
-                if (CVX) Op[k] = pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2));
-                SXG_PIN("+v"(Fp[k]), "+v"(Op[k]));
-            }
-            BAND_STORE(Fp[k], Op[k]);
-        } else {
-            BAND_STORE(pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2)), (CVX ? pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2)) : NEG2));
+        for (int k = 0; k < W; ++k) {
+            Fp[k] = pk_max(pk_add(Hc[k], G2), pk_add(Fp[k], E2));
+            if (CVX) Op[k] = pk_max(pk_add(Hc[k], Q2), pk_add(Op[k], C2));
+            SXG_PIN("+v"(Fp[k]), "+v"(Op[k]));
         }
+        BAND_STORE(Fp[k], Op[k]);
 #undef BAND_STORE
         // what the next row takes from registers must not exist outside this row's band: forced to -inf only when
         // the band is about to change (or the next band is unknown) -- otherwise those lanes are never read

@@ -441,7 +441,6 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         key_lo = 0u; key_hi = 0u;
     };
 
-    bool next_sib = false;      // decided at the end of a row for its successor
     // (An L2 warm-up for the next row's stored predecessor -- one load per wave touching its 44 cache lines a row ahead,
     // retired before the stores -- measured 0-5 % SLOWER in round 2: returns are in order, so whatever is in front of the
     // demand loads holds them back, and a wait behind it stalls.)
@@ -503,10 +502,12 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         unsigned long long rt_ = __builtin_readcyclecounter();
 #endif
         int Hc[W];
-        // Fp/Op arrive holding the previous row's OUTGOING candidates -- or, when the previous
-        // row announced this one as its sibling (an alternative allele: the same single predecessor),
-        // that row's own F/O, which are this row's too.
-        const bool sib = next_sib;
+        // Fp/Op arrive holding the previous row's OUTGOING candidates.  (Rounds 1-5 had a sibling rule: a row whose successor has
+        // the same single predecessor -- an alternative allele, 15 % of the rows -- kept its own F/O for it and the successor fetched
+        // only the diagonal.  Round 6 measured it as a LOSS: "update in place or keep" was a merge the register allocator resolved
+        // with a second set of 2 W registers and 22 v_mov at the top of four rows in five, and the second store path doubled the
+        // loop's code.  Without it a sibling unpacks F/O from its predecessor's stored row like any other row: headline
+        // 1 859 -> 1 786 ms on one box, 1 417 -> 1 025 static VALU instructions and 132 -> 42 v_mov in the loop.)
 // words of the stored row of predecessor p_ (slot sl_) and the column to their left (stored with the row: every word of
 // a stored row was written by the lane that reads it).  sl_ <= -2: the row is one of the LDS_ROWS on-chip copies.
 #define P16_FETCH(p_, sl_, wr_, hl_)                                                                        \
@@ -558,19 +559,6 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         // ascending pass needs cost 11-23 v_mov per row.
         if ((EXP & 32) || (np <= 1 && p0 == i - 1)) {
             // register predecessor: its outgoing candidates ARE this row's F and O
-        } else if (sib) {
-            int hl;
-            if (ring_plane && s0 >= 0 && p0 != 0) {
-                int fd_[1], od_[1];
-                P16_FETCH_PLANE(p0, false, Hp, fd_, od_, hl);
-                (void)fd_; (void)od_;
-            } else {
-                u32x2 wr[W];
-                P16_FETCH(p0, s0, wr, hl);
-#pragma unroll
-                for (int k = 0; k < W; ++k) Hp[k] = (int)wr[k].x;
-            }
-            Hleft = hl;
         } else {
             // Several predecessors: D, F and O are plain maxima over them (which predecessor won is re-derived by the
             // traceback), so the fold order is free: when the previous row is one of them (ROW_REGPRED) the registers are
@@ -762,13 +750,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         }
 
         RP_MARK(5);  // hand-over + end-cell bookkeeping
-        // ---- outgoing candidates (see p16_pack_row), ring store, band store.  A sibling successor --
-        // single predecessor, the same as mine, not me -- wants my own F/O left in place instead.
-        next_sib = false;
-        if (np <= 1 && i < N) {
-            const int nnp = dnext[1] & 0xffff, np0 = dnext[2];
-            next_sib = nnp <= 1 && np0 == p0 && np0 != i;
-        }
+        // ---- outgoing candidates (see p16_pack_row), ring store, band store
         // band of this row: strips [bs0, bs0 + BS); my wave covers lo strips [128 wv, 128 wv + 64) and the
         // hi strips 64 further on.  (wave-uniform tests; the lane test is ONE exec mask around all W stores)
         const int bs0 = band_first_strip(hint, W, BS, T);
@@ -834,18 +816,13 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
         }                                                                                                   \
         }                                                                                                   \
     } while (0)
-        if (!next_sib) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) {
-                Fp[k] = pk_max(P16_DEC(Hc[k], Gm, G2), P16_DEC(Fp[k], Em, E2));
-                if (CVX) Op[k] = pk_max(P16_DEC(Hc[k], Qm, Q2), P16_DEC(Op[k], Cm, C2));
-                SXG_PIN("+v"(Fp[k]), "+v"(Op[k]));
-            }
-            P16_STORES(Fp[k], Op[k]);
-        } else if (ring || band_lo || band_hi) {
-            // (a sibling follows: Fp/Op stay this row's own F/O, the outgoing candidates are temporaries)
-            P16_STORES(pk_max(P16_DEC(Hc[k], Gm, G2), P16_DEC(Fp[k], Em, E2)), (CVX ? pk_max(P16_DEC(Hc[k], Qm, Q2), P16_DEC(Op[k], Cm, C2)) : NEG2));
+        for (int k = 0; k < W; ++k) {
+            Fp[k] = pk_max(P16_DEC(Hc[k], Gm, G2), P16_DEC(Fp[k], Em, E2));
+            if (CVX) Op[k] = pk_max(P16_DEC(Hc[k], Qm, Q2), P16_DEC(Op[k], Cm, C2));
+            SXG_PIN("+v"(Fp[k]), "+v"(Op[k]));
         }
+        P16_STORES(Fp[k], Op[k]);
 #undef P16_STORES
 #undef P16_LDS_ROW
 #pragma unroll
