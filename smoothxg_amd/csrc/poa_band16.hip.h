@@ -11,9 +11,16 @@
 //     last column a wave_shr;
 //   * a band of ~925 columns (5 kbp) costs a quarter of the full row, and sixteen one-wave workgroups share a
 //     CU instead of four four-wave ones;
-//   * there is no row ring: every row writes its band to the plane (one dword per cell, slot = strip mod BS,
-//     the layout the traceback of poa_dp16.hip.h reads) and predecessor rows that are not in registers are
-//     fetched from there by ABSOLUTE strip, so a predecessor may have had any window origin;
+//   * there is no row ring: every row writes its band to the plane (slot = strip mod BS, the layout the traceback of
+//     poa_dp16.hip.h reads) and predecessor rows that are not in registers are fetched from there by ABSOLUTE strip, so
+//     a predecessor may have had any window origin;
+//   * CB = 4: one dword per cell (H | H - oF | H - oO).  CB = 2 (round 6, local alignment): the 2-byte delta codes of the
+//     packed sweep -- a strip is W + 1 halfwords: the H of its OWN first column, then the W codes, the first with step 0
+//     (the packed sweep's "strip 0" convention, here for every strip: a band that starts at a strip boundary can make the
+//     step INTO a strip arbitrarily large -- the row to the left may not exist in a predecessor -- while inside a strip
+//     the bounds of DESIGN.md 3.1 hold, because bands are whole strips).  The sweep sits at the HBM roof (0.50-0.58 of
+//     the 8 TB/s peak = 80-90 % of what a copy kernel reaches on the box): 5 instead of 8 dwords per strip of 8 columns
+//     is the lever.  A reader gets the column LEFT of a strip from its left neighbour's decoded last column (lane shift);
 //   * the window moves rarely (its 128 strips hold a band of ~86 with slack on both sides): when the band
 //     would leave it, the origin is re-centred, the letters of the new strips are loaded and the previous row,
 //     if needed, is fetched from the plane like any stored row;
@@ -61,7 +68,7 @@ __device__ __forceinline__ void band_strips_of(const int hint, const int w, cons
     bh = min((hint + w) / W, last_strip);
 }
 
-template <bool CVX, int W, bool SW = true>
+template <bool CVX, int W, bool SW = true, int CB = 4>
 __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView R, const int N_, const uint8_t* seq, const int L_,
                                                const DpBuffers B, char* smem, unsigned long long* cells_out) {
     DpResult res;
@@ -78,6 +85,17 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
     const int We = W * e, Wc = W * c;
     const int BS = __builtin_amdgcn_readfirstlane(B.band_strips), bw = __builtin_amdgcn_readfirstlane(B.band_w);
     const int last_strip = L / W;   // the strip that holds column L
+    static_assert(CB == 4 || SW, "2-byte band cells: local alignment only (every cell of a band is a real score)");
+    constexpr int SD = p16_slot_dwords(W, CB);   // dwords of one strip in a plane row
+    // (CB = 2) the delta code's constants, as in dp_fill_p16
+    const P16Delta DF = p16_delta_of(S);
+    const int dbH_ = __builtin_amdgcn_readfirstlane(DF.bH), dbF_ = __builtin_amdgcn_readfirstlane(DF.bF);
+    const int KF2 = pk2(1 << dbH_, 1 << dbH_), KO2 = pk2(1 << (dbH_ + dbF_), 1 << (dbH_ + dbF_));
+    const int D_SH1 = pk2(dbH_, dbH_), D_SH2 = pk2(dbH_ + dbF_, dbH_ + dbF_);
+    const int D_MH = pk2((1 << dbH_) - 1, (1 << dbH_) - 1), D_MF = pk2((1 << dbF_) - 1, (1 << dbF_) - 1);
+    const int d_cst_ = g + ((-e) << dbH_) + ((CVX ? -c : 0) << (dbH_ + dbF_));
+    const int D_CST = pk2(d_cst_, d_cst_);
+    const int D_EA = pk2(-e, -e), D_CA = pk2(-c, -c);
     SXG_GLOBAL uint32_t* const g_tb = sxg_uniform(sxg_global((uint32_t*)B.tb));
     SXG_GLOBAL const int32_t* const g_meta = sxg_uniform(sxg_global((const int32_t*)R.meta));
     SXG_GLOBAL const int32_t* const g_preds = sxg_uniform(sxg_global((const int32_t*)R.preds));
@@ -253,6 +271,51 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             hl_ = (int)__builtin_amdgcn_perm(lb_ ? lh_ : NEGCELL, la_ ? ll_ : NEGCELL, 0x05040100u);        \
         }                                                                                                   \
     } while (0)
+// (CB = 2) the same from 2-byte strips: HS_/FS_/OS_[k] = H and the outgoing candidates of predecessor row p_ in my strips (cells
+// that do not exist: -inf), hl_ = the column left of my strips -- my left neighbour's last column (a strip hands its own
+// last H to the right; lane 0's lo strip begins the window: the strip left of it is read on its own when it matters)
+#define BAND_FETCH2(p_, hp_, HS_, FS_, OS_, hl_)                                                            \
+    do {                                                                                                    \
+        if ((p_) == 0) {   /* (local mode: row 0 is H = 0 wherever the sequence has a column) */             \
+            const int z_ = pk2(st_lo * W <= L ? 0 : NEGP, st_hi * W <= L ? 0 : NEGP);                        \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) { HS_[k] = z_; FS_[k] = pk_add(z_, G2); OS_[k] = CVX ? pk_add(z_, Q2) : NEG2; } \
+            hl_ = pk2(st_lo == 0 ? NEGP : 0, 0);                                                            \
+        } else {                                                                                            \
+            int fl_, fh_;                                                                                   \
+            if (ada) { fl_ = (hp_) & 0xffff; fh_ = (int)((unsigned)(hp_) >> 16); }                          \
+            else band_strips_of(hp_, bw, W, last_strip, fl_, fh_);                                          \
+            const __amdgpu_buffer_rsrc_t rs_ = p16_rsrc((const void*)(g_tb + (size_t)(p_) * (size_t)(SD * BS)), SD * BS * 4); \
+            const bool a_ = st_lo >= fl_ && st_lo <= fh_, b_ = st_hi >= fl_ && st_hi <= fh_;                 \
+            const int mx_ = (a_ ? 0x0000ffff : 0) | (b_ ? (int)0xffff0000 : 0);                             \
+            unsigned dl_[SD], dh_[SD];                                                                      \
+            plane_load_strip<SD>(rs_, so_lo, BS, dl_);                                                      \
+            plane_load_strip<SD>(rs_, so_hi, BS, dh_);                                                      \
+            /* the strip left of the window, for lane 0's lo strip: wave-uniform, rare (the window has slack on both sides) */ \
+            int xl_ = NEGP;                                                                                 \
+            if (s0 >= 1 && s0 - 1 >= fl_ && s0 - 1 <= fh_ && bl == s0) {                                    \
+                const unsigned dw_ = lane < SD ? __builtin_amdgcn_raw_buffer_load_b32(rs_, (unsigned)plane_cell_in_row(SD, BS, (s0 - 1) % BS, min(lane, SD - 1)) * 4u, 0, 0) : 0u; \
+                int h_ = (int)(short)((unsigned)__builtin_amdgcn_readlane((int)dw_, 0) & 0xffffu);         \
+                for (int t2 = 1; t2 < W; ++t2) {                                                            \
+                    const unsigned d_ = (unsigned)__builtin_amdgcn_readlane((int)dw_, (t2 + 1) >> 1);        \
+                    const unsigned c_ = ((((t2 + 1) & 1) ? d_ >> 16 : d_ & 0xffffu) - (unsigned)d_cst_) & 0xffffu; \
+                    h_ += (int)(c_ & (unsigned)((1 << dbH_) - 1)) + g;                                      \
+                }                                                                                           \
+                xl_ = h_;                                                                                   \
+            }                                                                                               \
+            int run_ = (int)__builtin_amdgcn_perm(dh_[0], dl_[0], 0x05040100u);   /* H of my strips' first columns */ \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
+                const int cn_ = pk_sub((int)__builtin_amdgcn_perm(dh_[(k + 1) >> 1], dl_[(k + 1) >> 1], ((k + 1) & 1) ? 0x07060302u : 0x05040100u), D_CST); \
+                if (k) run_ = pk_add(pk_add(run_, cn_ & D_MH), G2);                                          \
+                const int of_ = pk_sub(pk_sub(run_, pk_lshr(cn_, D_SH1) & D_MF), D_EA);                      \
+                const int oo_ = CVX ? pk_sub(pk_sub(run_, pk_lshr(cn_, D_SH2)), D_CA) : NEG2;                \
+                HS_[k] = (run_ & mx_) | (NEG2 & ~mx_);                                                      \
+                FS_[k] = (of_ & mx_) | (NEG2 & ~mx_);                                                       \
+                OS_[k] = CVX ? ((oo_ & mx_) | (NEG2 & ~mx_)) : NEG2;                                        \
+            }                                                                                               \
+            hl_ = sxg_wave_shr1(HS_[W - 1], 0);                                                             \
+            { const int l63_ = __builtin_amdgcn_readlane(HS_[W - 1], 63); if (lane == 0) hl_ = pk2(xl_, pk_lo(l63_)); } \
+        }                                                                                                   \
+    } while (0)
 #define BAND_LROW(ptr_)                                                                                     \
     int tp_ = lane;                                                                                         \
     asm volatile("" : "+v"(tp_));                                                                           \
@@ -284,13 +347,28 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
                     if (ada) hp = p == i - 1 ? prev_bw : (p >= 1 ? (int)load_rec(p).x : 0);
                     else hp = p >= 1 ? __builtin_amdgcn_readfirstlane(g_hint[p - 1]) : 0;
                 }
-                u32x2 wr[W];
                 int hl;
+                if (CB == 2 && !(p == i - 1 && park)) {
+                    if constexpr (CB == 2) {
+                        int hs_[W], fs_[W], os_[W];
+                        BAND_FETCH2(p, hp, hs_, fs_, os_, hl);
+#pragma unroll
+                        for (int k = 0; k < W; ++k) {
+                            if (x == 0) { Fp[k] = fs_[k]; Op[k] = os_[k]; Hc[k] = hl; }
+                            else { Fp[k] = pk_max(Fp[k], fs_[k]); if (CVX) Op[k] = pk_max(Op[k], os_[k]); Hc[k] = pk_max(Hc[k], hl); }
+                            hl = hs_[k];
+                            SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));
+                        }
+                    }
+                } else {
+                u32x2 wr[W];
                 if (p == i - 1 && park) {
 #pragma unroll
                     for (int k = 0; k < W; ++k) wr[k] = lrow_t[k];
                     hl = hleft_reg;
-                } else BAND_FETCH(p, hp, wr, hl);
+                } else {
+                    if constexpr (CB != 2) BAND_FETCH(p, hp, wr, hl);
+                }
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     int hs, fs, os;
@@ -300,9 +378,11 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
                     hl = hs;
                     SXG_PIN("+v"(Hc[k]), "+v"(Fp[k]), "+v"(Op[k]), "+v"(hl));
                 }
+                }
             }
         }
 #undef BAND_FETCH
+#undef BAND_FETCH2
 #undef BAND_LROW
         if (!CVX) {
 #pragma unroll
@@ -453,7 +533,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             else if (nnp <= 1 && np0 == i) ada_band(ml_ + 1, mr_ + 1, nhint, nbl, nbh);   // (my register successor)
             else if (next_sib) ada_band(my_pl, my_pr, nhint, nbl, nbh);                   // (same single predecessor as mine)
         }
-        const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(W * BS)), W * BS * 4);
+        const __amdgpu_buffer_rsrc_t rs_plane = p16_rsrc((const void*)(g_tb + (size_t)i * (size_t)(SD * BS)), SD * BS * 4);
 // (Round 4 measured a PLANE CUT here: rows that no later row reads back kept only 16 strips either side of the strip of their
 // greatest H, the walk reported a miss for a cell such a row had not kept and that sequence's sweep was repeated with whole
 // bands.  c3b 1 374 -> 1 206 blocks/s with 10 % of the alignments repeated, i.e. nothing gained by writing a third of the
@@ -462,6 +542,22 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
 // whose records overwrite the hints.)
 #define BAND_STORE(CF, CO)                                                                                  \
     do {                                                                                                    \
+        if constexpr (CB == 2) {                                                                            \
+            /* delta codes of my two strips (see P16Delta), both halves of a register at once; halfword 0 of a strip = H of its \
+               own first column, whose code carries the step 0 */                                              \
+            int code_[W], prev_ = Hc[0];                                                                    \
+            _Pragma("unroll") for (int k = 0; k < W; ++k) {                                                 \
+                const int h_ = Hc[k], of_ = (CF), oo_ = (CO);                                               \
+                int cd_ = pk_mad(pk_sub(h_, of_), KF2, pk_sub(h_, prev_));                                   \
+                if (CVX) cd_ = pk_mad(pk_sub(h_, oo_), KO2, cd_);                                           \
+                code_[k] = cd_;                                                                             \
+                prev_ = h_;                                                                                 \
+            }                                                                                               \
+            plane_store_strip<SD>(rs_plane, in_lo ? so_lo : P16_SLOT_OOB, BS, [&](const int x) -> unsigned { \
+                return __builtin_amdgcn_perm((unsigned)(2 * x < W ? code_[2 * x < W ? 2 * x : 0] : 0), (unsigned)(x ? code_[x ? 2 * x - 1 : 0] : Hc[0]), 0x05040100u); }); \
+            plane_store_strip<SD>(rs_plane, in_hi ? so_hi : P16_SLOT_OOB, BS, [&](const int x) -> unsigned { \
+                return __builtin_amdgcn_perm((unsigned)(2 * x < W ? code_[2 * x < W ? 2 * x : 0] : 0), (unsigned)(x ? code_[x ? 2 * x - 1 : 0] : Hc[0]), 0x07060302u); }); \
+        } else {                                                                                            \
         /* (round 6: a strip outside the band goes to a slot beyond the row's descriptor -- dropped by the hardware -- instead of \
             a lane-divergent branch around the stores: see P16_SLOT_OOB in poa_dp16.hip.h) */                  \
             plane_store_strip<W>(rs_plane, in_lo ? so_lo : P16_SLOT_OOB, BS, [&](const int k) -> unsigned { \
@@ -470,6 +566,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
             plane_store_strip<W>(rs_plane, in_hi ? so_hi : P16_SLOT_OOB, BS, [&](const int k) -> unsigned { \
                 const u32x2 w = p16_pack_row<CVX>(Hc[k], CF, CO);                                           \
                 return __builtin_amdgcn_perm(w.y, w.x, 0x07060302u); });                                    \
+        }                                                                                                   \
     } while (0)
 #pragma unroll
         for (int k = 0; k < W; ++k) {

@@ -954,7 +954,8 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
         }
         return (unsigned)(s - band_first_strip(hint, W, BS, T)) < (unsigned)BS;
     };
-    static_assert(!(BANDED && CB == 2), "the banded sweep keeps 4-byte cells");
+    // (BANDED with CB = 2 -- round 6, local alignment: every strip starts with the H of its OWN first column and a step of 0, the
+    //  packed sweep's "strip 0" form, so the decoders below need nothing of a strip's left neighbour; strips are ABSOLUTE there)
     constexpr int SD = p16_slot_dwords(W, CB);     // dwords of one strip in a plane row
     // (CB = 2) fields of a cell's code
     const P16Delta DF = p16_delta_of(S_);
@@ -1074,7 +1075,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
 #pragma unroll
                 for (int si = 0; si < NSW; ++si) {
                     unsigned tmp[SD];
-                    plane_load_slot<SD>(g_plane + (size_t)row * (size_t)(SD * BS), BS, min(s0w + si, 2 * T - 1) % BS, tmp);
+                    plane_load_slot<SD>(g_plane + (size_t)row * (size_t)(SD * BS), BS, min(s0w + si, BANDED ? last_strip : 2 * T - 1) % BS, tmp);
 #pragma unroll
                     for (int x2 = 0; x2 < SD; ++x2) R_.cells[si * SD + x2] = tmp[x2];
                 }
@@ -1115,7 +1116,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                         const unsigned dwk = R_.cells[si * SD + ((1 + k) >> 1)];
                         const unsigned cd = d_norm(((1 + k) & 1) ? dwk >> 16 : dwk & 0xffffu);
                         h += d_step(cd);
-                        if ((unsigned)(xb + k) < (unsigned)TBW_COLS && s0w + si < 2 * T) en[xb + k] = d_word(h, cd);
+                        if ((unsigned)(xb + k) < (unsigned)TBW_COLS && s0w + si <= (BANDED ? last_strip : 2 * T - 1)) en[xb + k] = d_word(h, cd);
                     }
                 }
             } else {
@@ -1127,7 +1128,7 @@ __device__ __noinline__ int traceback_p16(const RowsView R, const DpBuffers B, c
                 const int col = c0 + x2;
                 if (col >= 0 && col <= L) {
                     if (kept(ada ? d1.z : d1.w, col / W)) valid |= 1u << x2;
-                    else if (BANDED) { v[x2] = 0x0000C000u; valid |= 1u << x2; }
+                    else if (BANDED) { if constexpr (CB == 2) en[x2] = 0x0000C000u; else v[x2] = 0x0000C000u; valid |= 1u << x2; }
                 }
             }
             if constexpr (CB != 2) {

@@ -101,6 +101,11 @@ KernelFn<BlockArgs> sxg_block_kernel_part9(const Variant& v, bool cvx, bool sw) 
 #if SXG_KERN_PART == 1
 KernelFn<BlockArgs> sxg_block_kernel_part1(const Variant& v, bool cvx, bool sw) {
     if (v.RM == 3) {   // banded: the strip width is part of the semantics (decree B2), never merged or widened
+        if (v.CB == 2 && sw) {   // (round 6) 2-byte band cells: local alignment, score sets whose delta code fits 16 bits
+            if (v.W == 6) return cvx ? poa_block_kernel<64, 6, true, 3, true, 2> : poa_block_kernel<64, 6, false, 3, true, 2>;
+            if (v.W == 8) return cvx ? poa_block_kernel<64, 8, true, 3, true, 2> : poa_block_kernel<64, 8, false, 3, true, 2>;
+            return cvx ? poa_block_kernel<64, 11, true, 3, true, 2> : poa_block_kernel<64, 11, false, 3, true, 2>;
+        }
         if (v.W == 6) return pick_block<64, 6, 3>(cvx, sw);
         if (v.W == 8) return pick_block<64, 8, 3>(cvx, sw);
         return pick_block<64, 11, 3>(cvx, sw);

@@ -250,14 +250,14 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     // exist, so the traceback cannot leave the kept cells
                     V.B.band_w = band_half_width(len);
                     V.B.band_mode = band_mode;
-                    res = dp_fill_band16<CVX, W, SW>(S, V.R, N, seq, len, V.B, smem, A.cells + s);
+                    res = dp_fill_band16<CVX, W, SW, SW ? CB : 4>(S, V.R, N, seq, len, V.B, smem, A.cells + s);
                     __syncthreads();
                     PROF(2);
                     if (t == 0) lds[TBM_FLAG] = 0;
                     __syncthreads();
                     if (res.bi >= 0)
-                        traceback_p16<false, W, CVX, true>(V.R, V.B, S, seq, len, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj,
-                                                           V.G.posnode, nullptr, nullptr, smem);
+                        traceback_p16<false, W, CVX, true, SW ? CB : 4>(V.R, V.B, S, seq, len, res.best, T, min(256, (len << 8) / max(N, 1)), res.bi, res.bj,
+                                                                        V.G.posnode, nullptr, nullptr, smem);
                     __syncthreads();
                     PROF(3);
                     // (a cell outside a row's band does not exist for the banded walk, so it cannot miss: if it ever reports one,

@@ -206,6 +206,13 @@ static int plane_cell_bytes(const Scoring& S) {
     if (const char* e = getenv("SXG_POA_CELL_BYTES")) if (atoi(e) == 4) return 4;
     return p16_delta_fits(S) ? 2 : 4;
 }
+// ... and of the banded sweep (round 6): 2-byte codes for LOCAL alignments whose delta code fits -- every cell of a band is a real
+// score there; a global alignment's bands hold "minus infinity" cells, whose steps no code holds.  SXG_POA_BAND_CELL_BYTES=4: the
+// 4-byte cells of rounds 2-5 (A/B runs, tests).
+static int band_cell_bytes(const Scoring& S) {
+    if (const char* e = getenv("SXG_POA_BAND_CELL_BYTES")) if (atoi(e) == 4) return 4;
+    return S.sw ? plane_cell_bytes(S) : 4;
+}
 
 // Score ranges.  Local alignment: 0..m*L.  Global: additionally down to the all-gap path through
 // `rows` graph rows (sxg_gap_cost).  `rows` is exact for the align-only API; for whole blocks the
@@ -590,6 +597,7 @@ extern "C" int sxg_poa_batch_upload(sxg_poa_handle* h, const sxg_poa_batch_in* i
         if (bnd && (m.S.sw || bnd == 2) && m.rm == 2 && m.maxlen <= SXG_POA_MAX_SEQ_LEN) {
             m.rm = 3;
             m.variant = Variant{band_strip_width(m.maxlen), 1, 64, 3};   // decree B2: strip width from the block's longest sequence
+            m.variant.CB = band_cell_bytes(m.S);
             m.fits = true;
         }
     }
@@ -704,7 +712,7 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     if (V.RM == 3) pool_slots = 1;   // (the banded sweep has no row ring: predecessors come from the plane)
     P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false,
                         V.RM == 3 ? (any_adaptive ? BAND_WIN : band_plane_strips(maxlen, V.W)) : (V.RM == 2 ? (P.wide_band ? 2 * V.T() : plane_strips_p16(V.T(), V.W)) : 0),
-                        V.RM == 2 ? V.CB : 4, any_spoa);
+                        V.RM >= 2 ? V.CB : 4, any_spoa);
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
