@@ -74,7 +74,7 @@ typedef struct sxg_smooth_params {
                                                          decree S7', restated from memory, unverified) instead of keeping it in
                                                          order incrementally (decree S7).  DEFAULT 1 since round 6: it is what
                                                          graph.AddAlignment does at src/smooth.cpp:764, and the re-sort is a
-                                                         parallel, incremental device phase now (0.5-5 % of the kernel time,
+                                                         parallel, incremental device phase now (1-5 % of the kernel time at full batches,
                                                          DESIGN.md).  Ignored with use_abpoa (abPOA does not call spoa's sort).
                                                          0 = the order of rounds 1-5. */
 } sxg_smooth_params;
