@@ -14,7 +14,7 @@ import sys
 
 W = sys.argv[1] if len(sys.argv) > 1 else "11"
 TM = sys.argv[2] if len(sys.argv) > 2 else "256"
-KSUB = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else "dp_fill_p16ILi%sELb1ELb1ELi2ELb0ELi%sELb1E" % (W, TM)
+KSUB = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else "dp_fill_p16ILi%sELb1ELb1ELi2ELi%sELi%sELb1E" % (W, "2" if TM == "64" and int(W) <= 11 else ("1" if int(TM) <= 128 else "0"), TM)
 out = "/tmp/rowloop_budget_%s_%s.s" % (W, TM)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DSXG_DEV_ONLY_W=" + W,
                        "-DSXG_DEV_ONLY_TMAX=" + TM, "-S", "--cuda-device-only", "-o", out, "smoothxg_amd/csrc/sxg_poa.hip"] + sys.argv[4:],

@@ -147,6 +147,32 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
     bool next_sib = false;
     int best_lo = SW ? 0 : NEGP * 2, best_hi = best_lo, bi_lo = -1, bi_hi = -1, bj_lo = 0, bj_hi = 0;   // (bj: ABSOLUTE column -- the window moves)
     unsigned long long cells = 0;
+    // End cell of a LOCAL alignment (round 6: the packed sweep's keys instead of "compare, vote, search the columns" in every row that
+    // improves a lane -- nearly every row of the wave the diagonal runs through): per strip (greatest H so far) << 16 | 0xffff - row,
+    // one unsigned max per row; folded into a scalar (value, row, strip) at every 65 536th row, whenever the window moves (a lane's
+    // strips change) and at the end.  The sweep names the STRIP of the end cell (bj = -(strip + 1)), the traceback reads the column.
+    unsigned key_lo = 0u, key_hi = 0u;
+    unsigned long long ekey = 0ull;
+    auto fold_keys = [&](const int i_end, const int s0_) {
+        const unsigned ep = (unsigned)(i_end - 1) >> 16;
+        auto k64 = [&](const unsigned k, const int strip) -> unsigned long long {
+            if ((k >> 16) == 0u) return 0ull;   // (no positive score in this strip)
+            const unsigned row = (ep << 16) | (0xffffu - (k & 0xffffu));
+            return ((unsigned long long)(k >> 16) << 32) | ((unsigned long long)(0xFFFFFu - row) << 12) | (unsigned long long)(0xFFFu - (unsigned)strip);
+        };
+        unsigned long long kk = k64(key_lo, s0_ + lane);
+        const unsigned long long k2 = k64(key_hi, s0_ + 64 + lane);
+        kk = k2 > kk ? k2 : kk;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(kk, d);
+            kk = o > kk ? o : kk;
+        }
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(kk >> 32)), lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)kk);
+        const unsigned long long ku = ((unsigned long long)hi_ << 32) | lo_;
+        ekey = ku > ekey ? ku : ekey;
+        key_lo = 0u; key_hi = 0u;
+    };
 
 #ifdef SXG_ROW_PROF
     unsigned long long racc[8] = {0};
@@ -214,6 +240,7 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
         if (bh >= bl) cells += (unsigned long long)(min(L, bh * W + W - 1) - bl * W + 1);
         if (bh >= bl && (bl < s0 || bh >= s0 + BAND_WIN)) {
             // re-centre the window on this band; registers of the previous row no longer line up with it
+            if (SW && s0 > -1000000) fold_keys(i, s0);   // (the keys belong to the strips the lanes had so far)
             s0 = max(0, bl - (BAND_WIN - (bh - bl + 1)) / 2);
             regs_ok = false;
 #pragma unroll
@@ -463,19 +490,12 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
                 }
             }
         } else {
-            const bool il = pk_lo(rowmax) > best_lo, ih = pk_hi(rowmax) > best_hi;
-            if (__any(il || ih)) {
-                if (il) { best_lo = pk_lo(rowmax); bi_lo = i; }
-                if (ih) { best_hi = pk_hi(rowmax); bi_hi = i; }
-                int bk_lo = 0, bk_hi = 0;
-#pragma unroll
-                for (int k = W - 1; k >= 0; --k) {
-                    if (il && pk_lo(Hc[k]) == best_lo) bk_lo = k;
-                    if (ih && pk_hi(Hc[k]) == best_hi) bk_hi = k;
-                }
-                if (il) bj_lo = st_lo * W + bk_lo;
-                if (ih) bj_hi = st_hi * W + bk_hi;
-            }
+            // (a row that merely equals a strip's best has a smaller lower half and changes nothing: first strictly greatest, decree S4)
+            if ((i & 0xffff) == 0) fold_keys(i, s0);
+            unsigned inv = 0xffffu - ((unsigned)i & 0xffffu);
+            asm volatile("" : "+v"(inv));
+            key_lo = max(key_lo, __builtin_amdgcn_perm((unsigned)rowmax, inv, 0x05040100u));
+            key_hi = max(key_hi, ((unsigned)rowmax & 0xffff0000u) | inv);
         }
         // ---- B4: leftmost / rightmost column of the band that holds the row's greatest H; the row's record
         int ml_ = 0, mr_ = 0;
@@ -601,6 +621,18 @@ __device__ __noinline__ DpResult dp_fill_band16(const Scoring S, const RowsView 
     (void)pbl; (void)pbh;
     if (lane == 0 && cells_out) *cells_out = cells;
 
+    if (SW) {
+        // ---- end cell of a local alignment: the keys of the last stretch, then the scalar best; the column is found by the traceback
+        fold_keys(N + 1, s0);
+        const int val = (int)(unsigned)(ekey >> 32);
+        if (ekey == 0ull || val <= 0) { res.best = 0; res.bi = -1; res.bj = -1; }
+        else {
+            res.best = val;
+            res.bi = (int)(0xFFFFFu - (unsigned)((ekey >> 12) & 0xFFFFFu));
+            res.bj = -1 - (int)(0xFFFu - (unsigned)(ekey & 0xFFFu));   // -(strip + 1): see traceback_p16
+        }
+        return res;
+    }
     // ---- end cell: greatest score, then smallest row, then smallest column (two candidates per lane)
     unsigned long long key = 0;
     if (bi_lo >= 0)

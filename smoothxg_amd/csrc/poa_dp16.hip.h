@@ -256,7 +256,11 @@ __device__ __forceinline__ int band_first_strip(const int hint_col, const int W,
 // RP: the class may run with a plane that keeps every strip and read stored rows back from it (ring_plane below) -- the
 // one- and two-wave classes (TMAX = 128); the wider classes are compiled without that path (its three fetch sites and their
 // scalars cost the four-wave headline class SGPR spills in the row loop).
-template <int W, bool CVX, bool SW, int CB = 4, bool RP = false, int TFIX = 0, bool DS = false, int EXP = 0>
+// (RP: 0 = never; 1 = when the launch's plane keeps every strip, a run-time test; 2 = ALWAYS -- round 6: the one-wave classes up to W = 11
+//  cover at most 1 408 columns, their plane keeps every strip by construction (p16_band_strips), and compiled for that alone the fold has
+//  ONE form: with both, every fold ended in 30 v_mov that merged the two forms' registers.  The host sends a one-wave launch whose plane
+//  was narrowed -- the test knob SXG_POA_BAND_COLS -- to the two-wave class run at 64 threads.)
+template <int W, bool CVX, bool SW, int CB = 4, int RP = 0, int TFIX = 0, bool DS = false, int EXP = 0>
 __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R, const int N_,
                                              const uint8_t* seq, const int L_, const DpBuffers B,
                                              char* smem) {
@@ -313,7 +317,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
     // produces --, the every-strip plane of a band-miss re-run) already holds what the row ring would: stored rows are not
     // written a second time, a stored predecessor is read back from its plane row and decoded.  (Cost map of 8000 x 16 x 1 kbp,
     // round 5: ring stores 14 % of the sweep, at the HBM write roof.)
-    const bool ring_plane = RP && CB == 2 && BS == 2 * T;
+    const bool ring_plane = RP == 2 ? true : (RP == 1 && CB == 2 && BS == 2 * T);
     // ---- wave pipeline.  The waves of a workgroup do NOT meet inside the row loop.  Wave w sweeps row i as soon as wave
     // w-1 has handed over, through a ring of P16_MBOX mailboxes in LDS, the three values that cross its left edge in row i:
     // E and Q entering its first column and H of the column left of it (one 16-byte word {E, Q, H, row}, written and read
@@ -705,7 +709,7 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             if (CVX) h = pk_max(h, Q);
             h = pk_max(h, SW ? B2 : NWF2);   // (local: 0; global: P16_NWFLOOR)
             Hc[k] = h;
-            rowmax = pk_max(rowmax, h);
+            if constexpr (W >= 12 || !SW) rowmax = pk_max(rowmax, h);
             E = pk_max(P16_DEC(h, Gm, G2), P16_DEC(E, Em, E2));
             if (CVX) Q = pk_max(P16_DEC(h, Qm, Q2), P16_DEC(Q, Cm, C2));
             // (round 6: no register pin behind a column below W = 12.  The empty asm made the hazard recogniser pad every column
@@ -713,6 +717,20 @@ __device__ SXG_P16_INLINE DpResult dp_fill_p16(const Scoring S, const RowsView R
             //  halves of the row's outgoing candidates: 15 + 21 VALU instructions and 18 s_nop per row of the W = 11 headline
             //  class, 124 VGPRs instead of 120, no scratch.  The 16-wave classes W = 12, 13 spill without it.)
             if constexpr (W >= 12) SXG_PIN("+v"(Hc[k]), "+v"(E), "+v"(Q), "+v"(rowmax));
+        }
+        if constexpr (W < 12 && SW) {
+            // (round 6) the row's greatest H as a TREE over the columns: accumulated column by column the compiler sank the chain of
+            // W dependent packed maxima to the loop's end, one s_nop between each (local alignment: every H is >= the bias, no floor needed)
+            if (!(EXP & 64)) {
+                int t_[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) t_[k] = Hc[k];
+#pragma unroll
+                for (int n = W; n > 1; n = (n + 1) / 2)
+#pragma unroll
+                    for (int k = 0; k < n / 2; ++k) t_[k] = pk_max(t_[k], t_[n - 1 - k]);
+                rowmax = t_[0];
+            }
         }
         // hand my last column to the right neighbour: inside the wave by a lane shift (lane 0's hi strip begins where lane
         // 63's lo strip ends; the column left of its lo strip came in through the mailbox); lane 63's hi strip is the wave's

@@ -271,9 +271,9 @@ __global__ __launch_bounds__(TMAX, sxg_min_waves(TMAX, W, RM)) void poa_block_ke
                     for (int att = 0;; ++att) {
 #ifdef SXG_EXP
                         // (development: a sweep with parts switched off in front of the real one -- see dp_fill_p16's EXP)
-                        if (att == 0) { res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, (RM == 2 && CB == 2 && TMAX <= 512 && SXG_TFIX_OK(TMAX)) ? TMAX : 0, DS, SXG_EXP>(S, V.R, N, seq, len, V.B, smem); __syncthreads(); if (res.best == 0x7fffffff) break; }
+                        if (att == 0) { res = dp_fill_p16<W, CVX, SW, CB, (RM == 2 && CB == 2 && TMAX <= 128) ? ((TMAX == 64 && W <= 11) ? 2 : 1) : 0, (RM == 2 && CB == 2 && TMAX <= 512 && SXG_TFIX_OK(TMAX)) ? TMAX : 0, DS, SXG_EXP>(S, V.R, N, seq, len, V.B, smem); __syncthreads(); if (res.best == 0x7fffffff) break; }
 #endif
-                        res = dp_fill_p16<W, CVX, SW, CB, RM == 2 && CB == 2 && TMAX <= 128, (RM == 2 && CB == 2 && TMAX <= 512 && SXG_TFIX_OK(TMAX)) ? TMAX : 0, DS>(S, V.R, N, seq, len, V.B, smem);
+                        res = dp_fill_p16<W, CVX, SW, CB, (RM == 2 && CB == 2 && TMAX <= 128) ? ((TMAX == 64 && W <= 11) ? 2 : 1) : 0, (RM == 2 && CB == 2 && TMAX <= 512 && SXG_TFIX_OK(TMAX)) ? TMAX : 0, DS>(S, V.R, N, seq, len, V.B, smem);
                         __syncthreads();
                         PROF(2);
                         if (t == 0) { lds[TBM_FLAG] = 0; lds[TBM_RANGE] = 0; }

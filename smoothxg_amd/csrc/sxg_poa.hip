@@ -713,6 +713,9 @@ static void prepare_plan(sxg_poa_handle* h, LaunchPlan& P, int attempt) {
     P.lay = make_layout(nodes_cap, rows_cap, pool_slots, step_cap, V.T(), Lpad, wb, false,
                         V.RM == 3 ? (any_adaptive ? BAND_WIN : band_plane_strips(maxlen, V.W)) : (V.RM == 2 ? (P.wide_band ? 2 * V.T() : plane_strips_p16(V.T(), V.W)) : 0),
                         V.RM >= 2 ? V.CB : 4, any_spoa);
+    // (the one-wave 2-byte classes up to W = 11 are compiled for a plane that keeps every strip -- dp_fill_p16's RP = 2; a launch whose
+    //  plane was narrowed, SXG_POA_BAND_COLS, runs the two-wave class at 64 threads instead)
+    if (V.RM == 2 && V.CB == 2 && V.TMAX == 64 && V.W <= 11 && P.lay.band_strips != 2 * V.T()) P.variant.TMAX = 128;
     P.kern = block_kernel(P.variant, P.cvx, P.sw);
     P.smem = dp_lds_launch_bytes(Lpad, wb);
     P.park_lds = dp_park_in_lds(Lpad, wb);
