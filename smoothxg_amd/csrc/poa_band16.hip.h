@@ -26,7 +26,7 @@
 //     if needed, is fetched from the plane like any stored row;
 //   * lanes outside the band compute values nobody reads; they are forced to -inf only where the band is about
 //     to change (their strips may enter the next row's band) and kept out of the gap scan, the hand-over, the
-//     end-cell search and the stores.
+//     end-cell keys and the stores (which go to a slot beyond the row's descriptor).
 // SW = false: GLOBAL alignment (smooth_abpoa sets its band for both modes, src/smooth.cpp:259-271), adaptive band only.
 // Nothing is clamped at 0 then; a cell none of whose sources exists holds "minus infinity give or take a few penalties"
 // (NEGP +- ...), which no real score -- all within +-15 800, checked per alignment -- ever equals or falls below, and
